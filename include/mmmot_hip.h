@@ -1,0 +1,204 @@
+/*
+ * mmmot_hip.h - C ABI of libmmmot_hip.so, the MI355X (gfx950) device library
+ * behind the mmMOT per-frame-pair network forward.
+ *
+ * The reference (ZwwWayne/mmMOT) is pure Python: its "FFI" for this path is
+ * the set of ATen operators that TrackingNet.forward dispatches
+ * (modules/tracking_net.py:165-193; operator inventory SURVEY.md section 2b,
+ * K1-K18).  Each entry point below replaces a *fused group* of those
+ * operator calls; the reference call sites are cited per function.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to contiguous fp32 / int32 data unless
+ *    named h_* ; no torch types cross this boundary;
+ *  - activations are ROW-major "position-major": one row per position
+ *    (pixel / point / detection / detection-pair), channels contiguous.  This
+ *    is the transpose of the reference's N,C,L layout and is an internal
+ *    choice: MFMA A-fragments and 16-byte coalesced loads both want the
+ *    reduction (channel) axis contiguous;
+ *  - "row tiles": rows are processed in tiles of <=128 rows that never span
+ *    two normalisation groups (a group = one frame-pair, or one
+ *    (frame-pair, modality-row)); tile_row0/tile_nrows/tile_group describe
+ *    the T tiles, grp_* arrays describe the G groups;
+ *  - all launches are asynchronous on `stream` (a hipStream_t passed as
+ *    void*); the functions never synchronise and never allocate;
+ *  - return value: 0 on success, MMMOT_EINVAL (-1) for a contract violation
+ *    (bad alignment / unsupported size), otherwise the positive hipError_t
+ *    of the failed launch.
+ */
+#ifndef MMMOT_HIP_H
+#define MMMOT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMMOT_OK 0
+#define MMMOT_EINVAL (-1)
+
+/* activation codes */
+#define MMMOT_ACT_NONE 0
+#define MMMOT_ACT_RELU 1
+#define MMMOT_ACT_SIGMOID 2
+
+/* A-operand modes of mmmot_gemm_rows */
+#define MMMOT_A_PLAIN 0     /* A = X[r][k]                                  */
+#define MMMOT_A_NORM_RELU 1 /* A = max(0, X[r][k]*sc[g][k] + sh[g][k])      */
+#define MMMOT_A_PAIR 2      /* A = op(FA[a_off+i][k], FB[b_off+j][k])       */
+
+/* pairwise operators (reference modules/gcn.py:6-41) */
+#define MMMOT_PAIR_MULTIPLY 0  /* batch_multiply  gcn.py:6-14  */
+#define MMMOT_PAIR_MINUS_ABS 1 /* batch_minus_abs gcn.py:17-28 */
+#define MMMOT_PAIR_MINUS 2     /* batch_minus     gcn.py:31-41 */
+
+/* softmax modes (reference modules/tracking_net.py:106-126) */
+#define MMMOT_SM_SINGLE 1
+#define MMMOT_SM_DUAL 2
+#define MMMOT_SM_DUAL_ADD 3
+#define MMMOT_SM_DUAL_MAX 4
+
+/* fusion modes (reference modules/fusion_net.py) */
+#define MMMOT_FUSION_A 0
+#define MMMOT_FUSION_B 1
+#define MMMOT_FUSION_C 2
+
+/* library / device info -------------------------------------------------- */
+int mmmot_abi_version(void);
+/* returns 0 and fills cu_count / gcn arch string (<=32 bytes) of device 0..; */
+int mmmot_device_info(int device, int* cu_count, char* arch, int arch_len);
+
+/* ---------------------------------------------------------------------------
+ * VGG16-BN trunk layer: 3x3 conv (pad 1) + folded eval-BatchNorm + ReLU, with
+ * the following 2x2/s2 max-pool optionally fused into the epilogue.
+ * Replaces conv2d + batch_norm + relu_ (+ max_pool2d) of
+ * reference modules/vgg.py:67-80 as regrouped by
+ * modules/appear_net.py:130-157,166-172.
+ *   first=1: `in` is the reference's NCHW crop tensor [L][3][H][W]
+ *            (modules/tracking_net.py:132) and wp is [Cout][32]
+ *            (k = (ky*3+kx)*3 + c, zero padded 27->32);
+ *   first=0: `in` is NHWC [L][H][W][Cin], wp is [9][Cout][Cin].
+ *   out: NHWC [L][H][W][Cout], or [L][H/2][W/2][Cout] when pool=1.
+ * Implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32).  H, W even;
+ * Cin % 32 == 0 (first=0); Cout % 64 == 0.
+ * ------------------------------------------------------------------------- */
+int mmmot_conv3x3_bn_relu(const float* in, const float* wp, const float* bias,
+                          float* out, int L, int H, int W, int Cin, int Cout,
+                          int first, int pool, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Row GEMM with fused operand generation and statistics epilogue:
+ *   v[r][n] = sum_k A(r,k) * W[n][k] + bias[n] + dbias[rowidx[r]][n]
+ *   part[t][0][n] = S  = sum_{r in tile t} v[r][n]
+ *   part[t][1][n] = M2 = sum_{r in tile t} (v[r][n] - S/nrows_t)^2   (tile-centred)
+ *   Y[r][n] = act(v[r][n])
+ * Replaces every conv1d(k=1) / conv2d(1x1) / linear of the path
+ * (reference modules/point_net.py:28,40,125,134-138; fusion_net.py:14-29,
+ * 53-60,80-83; gcn.py:59-66; new_end.py:48-58; tracking_net.py:92-100;
+ * appear_net.py:19-25) together with the producer side of the following
+ * GroupNorm (per-tile sums; mmmot_gn_finalize turns them into scale/shift)
+ * and the consumer side of the preceding one (A_NORM_RELU prologue).
+ * A_PAIR generates the N x M pairwise tensor of modules/gcn.py:6-41 on the
+ * fly in LDS - it is never materialised in HBM.
+ * K % 32 == 0, N % 64 == 0, all leading dimensions % 4 == 0, pointers 16-byte
+ * aligned.  Y, part, bias, dbias may be NULL.
+ * ------------------------------------------------------------------------- */
+typedef struct mmmot_gemm_args {
+  const float* X; int ldx;              /* PLAIN / NORM_RELU source rows      */
+  const float* W;                       /* [N][K]                             */
+  const float* bias;                    /* [N] or NULL                        */
+  const float* dbias; const int* rowidx; int lddb; /* gathered bias or NULL   */
+  float* Y; int ldy;                    /* output rows or NULL                */
+  float* part;                          /* [T][2][N] or NULL                  */
+  const float* sc; const float* sh; int ldsc;      /* [G][ldsc] (NORM_RELU)   */
+  const float* FA; const float* FB; int ldf;       /* PAIR feature rows       */
+  const int* tile_row0; const int* tile_nrows; const int* tile_group; /* [T]  */
+  const int* grp_row0; const int* grp_M; const int* grp_aoff; const int* grp_boff; /* [G] PAIR */
+  int T; int N; int K;
+  int amode; int pairop; int act;
+} mmmot_gemm_args;
+int mmmot_gemm_rows(const mmmot_gemm_args* a, void* stream);
+
+/* GroupNorm statistics -> per-channel scale/shift (fp64 combine).
+ * part is [T][2][ldp] = per-tile (sum, tile-centred M2) as written by
+ * mmmot_gemm_rows / mmmot_pointnet_layer1 (the C channels start at part[0];
+ * ldp >= C lets one GEMM's statistics feed several norms over channel
+ * sub-ranges); tiles are merged with Chan et al.'s parallel-variance update in
+ * fp64, so the result is robust when |mean| >> std.  A group's tiles must be
+ * consecutive 128-row chunks of its rows, the last one partial;
+ * group g owns tiles [grp_tile0[g], +grp_ntiles[g]) and grp_count[g] rows;
+ * the C channels are split into NG normalisation groups (nn.GroupNorm(NG, C),
+ * eps, biased variance).  sc[g][c] = gamma[c]*rstd, sh[g][c] = beta[c]-mean*sc.
+ * Replaces the statistics half of every F.group_norm on the path. */
+int mmmot_gn_finalize(const float* part, const int* grp_tile0, const int* grp_ntiles,
+                      const int* grp_count, int G, int ldp, int C, int NG,
+                      const float* gamma, const float* beta, float eps,
+                      float* sc, float* sh, void* stream);
+
+/* Strided/ragged segment mean with optional normalise+ReLU prologue:
+ *   out[s][c] = mean_{t<count[s]} f(X[start[s] + t*stride[s]][c])
+ * Replaces the per-detection Python pooling loops of
+ * reference modules/point_net.py:32-39,139-148, adaptive_avg_pool2d of
+ * modules/appear_net.py:15,30 and the mean(dim=-2/-1) of
+ * modules/new_end.py:70-71.  C % 4 == 0. seg_group / sc / sh may be NULL. */
+int mmmot_segment_mean(const float* X, int ldx, int C,
+                       const int* seg_start, const int* seg_count, const int* seg_stride,
+                       const int* seg_group, int nseg,
+                       const float* sc, const float* sh, int ldsc, int relu,
+                       float* out, int ldo, void* stream);
+
+/* out[omap ? omap[r] : r] = post(act(sum_k f(X[r][k])*w[k] + b)),
+ * post(v) = v - (v < thr) when use_thr (reference tracking_net.py:161-162).
+ * Final 1-channel layers: gcn.py:66, new_end.py:58, tracking_net.py:99. */
+int mmmot_rowdot(const float* X, int ldx, int K, const float* w, float b,
+                 const float* sc, const float* sh, int ldsc,
+                 const int* tile_row0, const int* tile_nrows, const int* tile_group, int T,
+                 int act, int use_thr, float thr,
+                 float* out, const int* omap, void* stream);
+
+/* Per-row LayerNorm (= GroupNorm(1,C) on L x C x 1 x 1, appear_net.py:19-25):
+ * Y[r][c] = act(gamma[c]*(X[r][c]-mean_r)*rstd_r + beta[c]).  C % 64 == 0, C <= 1024 */
+int mmmot_row_layernorm(const float* X, int ldx, int C, const float* gamma, const float* beta,
+                        float eps, int relu, float* Y, int ldy, int R, void* stream);
+
+/* PointNet first shared-MLP layer with the 3x3 STN transform folded into the
+ * weights (point_net.py:119-125): Y[p][0..63] = W[64][3] x[p] + b, plus
+ * per-tile statistics like mmmot_gemm_rows. */
+int mmmot_pointnet_layer1(const float* X, const float* W, const float* bias,
+                          float* Y, float* part,
+                          const int* tile_row0, const int* tile_nrows, int T, void* stream);
+
+/* Y[r][c] = act(X[r][c]*sc[g][c] + sh[g][c]); g from the tile table. C % 4 == 0 */
+int mmmot_affine_act(const float* X, int ldx, int C, const float* sc, const float* sh, int ldsc,
+                     const int* tile_row0, const int* tile_nrows, const int* tile_group, int T,
+                     int act, float* Y, int ldy, void* stream);
+
+/* Fusion module A/B/C combine (fusion_net.py:31-42,62-70,85-92).
+ * cat: [Lt][2C] = [image | lidar] features; F: [3][Lt][C] = image, lidar, fused.
+ *  A: fused = Y0*sc0+sh0
+ *  B: fused = (Y0*sc0+sh0) + (Y1*sc1+sh1)
+ *  C: Y0=[gate_p|input_p](image), Y1=[gate_i|input_i](lidar), ld 2C:
+ *     fused = (s(g0)*(i0*sc0+sh0) + s(g1)*(i1*sc1+sh1)) / (s(g0)+s(g1)) */
+int mmmot_fusion_combine(int mode, const float* cat, const float* Y0, int ld0,
+                         const float* Y1, int ld1,
+                         const float* sc0, const float* sh0, const float* sc1, const float* sh1, int ldsc,
+                         const int* tile_row0, const int* tile_nrows, const int* tile_group, int T,
+                         float* F, int Lt, int C, void* stream);
+
+/* Softmax modes over each group's N x M logit block (tracking_net.py:106-126).
+ * logits/out rows are ordered (group, i, j); one workgroup per group. */
+int mmmot_softmax_pairs(const float* logits, float* out,
+                        const int* grp_row0, const int* grp_N, const int* grp_M, int G,
+                        int max_nm /* max over groups of N+M (LDS sizing) */,
+                        int mode, void* stream);
+
+/* MFMA fragment-layout self test: C[32][32] = A[32][K] * B[32][K]^T through
+ * the same fragment mapping the GEMM kernels use (K % 8 == 0). */
+int mmmot_selftest_mfma(const float* A, const float* B, float* C, int K, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMMOT_HIP_H */

@@ -1,0 +1,113 @@
+"""Loader and builder of ``libmmmot_hip.so`` (the C-ABI of include/mmmot_hip.h).
+
+The library is built in-tree with ``hipcc --offload-arch=gfx950`` (no torch
+headers, no CMake) and loaded with ctypes.  There is NO fallback: if the shared
+object is missing or fails to load, every op raises - the product path never
+computes on the CPU.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+LIB_PATH = os.path.join(_HERE, 'libmmmot_hip.so')
+SOURCES = ['conv3x3.hip', 'gemm_rows.hip', 'small_kernels.hip']
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+HIPFLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
+
+_lock = threading.Lock()
+_lib = None
+
+c_f = ctypes.c_void_p  # device pointers travel as integers
+c_i = ctypes.c_int
+
+
+class GemmArgs(ctypes.Structure):
+    """Mirror of ``mmmot_gemm_args`` (include/mmmot_hip.h)."""
+    _fields_ = [
+        ('X', c_f), ('ldx', c_i),
+        ('W', c_f),
+        ('bias', c_f),
+        ('dbias', c_f), ('rowidx', c_f), ('lddb', c_i),
+        ('Y', c_f), ('ldy', c_i),
+        ('part', c_f),
+        ('sc', c_f), ('sh', c_f), ('ldsc', c_i),
+        ('FA', c_f), ('FB', c_f), ('ldf', c_i),
+        ('tile_row0', c_f), ('tile_nrows', c_f), ('tile_group', c_f),
+        ('grp_row0', c_f), ('grp_M', c_f), ('grp_aoff', c_f), ('grp_boff', c_f),
+        ('T', c_i), ('N', c_i), ('K', c_i),
+        ('amode', c_i), ('pairop', c_i), ('act', c_i),
+    ]
+
+
+# name -> argtypes; every entry point declared in include/mmmot_hip.h
+SIGNATURES = {
+    'mmmot_abi_version': [],
+    'mmmot_device_info': [c_i, ctypes.POINTER(c_i), ctypes.c_char_p, c_i],
+    'mmmot_conv3x3_bn_relu': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f],
+    'mmmot_gemm_rows': [ctypes.POINTER(GemmArgs), c_f],
+    'mmmot_gn_finalize': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, ctypes.c_float, c_f, c_f, c_f],
+    'mmmot_segment_mean': [c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_f, c_f, c_i, c_i, c_f, c_i, c_f],
+    'mmmot_rowdot': [c_f, c_i, c_i, c_f, ctypes.c_float, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i,
+                     ctypes.c_float, c_f, c_f, c_f],
+    'mmmot_row_layernorm': [c_f, c_i, c_i, c_f, c_f, ctypes.c_float, c_i, c_f, c_i, c_i, c_f],
+    'mmmot_pointnet_layer1': [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f],
+    'mmmot_affine_act': [c_f, c_i, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_f, c_i, c_f],
+    'mmmot_fusion_combine': [c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_f,
+                             c_i, c_i, c_f],
+    'mmmot_softmax_pairs': [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f],
+    'mmmot_selftest_mfma': [c_f, c_f, c_f, c_i, c_f],
+}
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 and link libmmmot_hip.so in-tree."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, 'common.h'), os.path.join(_HERE, '..', 'include', 'mmmot_hip.h')]
+    if not force and os.path.exists(LIB_PATH):
+        if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+            return LIB_PATH
+    objs = []
+    procs = []
+    for s in srcs:
+        o = s[:-4] + '.o'
+        objs.append(o)
+        cmd = [HIPCC] + HIPFLAGS + ['-c', s, '-o', o]
+        if verbose:
+            print(' '.join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError('hipcc failed: %s\n%s' % (' '.join(cmd), out.decode()))
+    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def load():
+    """Return the ctypes handle; raises (never falls back) when unavailable."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    'libmmmot_hip.so is not built (%s). Run `python -c "import __graft_entry__ as g; '
+                    'g.build()"`. There is no CPU fallback for the HIP path.' % LIB_PATH)
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, argtypes in SIGNATURES.items():
+                fn = getattr(lib, name)  # AttributeError if the symbol is missing
+                fn.argtypes = argtypes
+                fn.restype = c_i
+            _lib = lib
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError('%s failed with status %d%s' % (
+            what, status, ' (MMMOT_EINVAL: contract violation)' if status == -1 else ' (hipError_t)'))

@@ -1,0 +1,454 @@
+// HBM-bound and small kernels of the mmMOT forward on gfx950: GroupNorm
+// statistics combine, ragged/strided segment means, 1-channel output layers,
+// per-row LayerNorm, the K=3 PointNet input layer, normalise+activate, fusion
+// combine and the dual-softmax.  All use 64-lane wave reductions and 16-byte
+// coalesced accesses along the channel axis.
+#include "common.h"
+
+// ---------------------------------------------------------------------------
+// GroupNorm statistics -> scale/shift.  One workgroup per (group, norm-group).
+__global__ __launch_bounds__(256) void gn_finalize_kernel(
+    const float* __restrict__ part, const int* __restrict__ grp_tile0, const int* __restrict__ grp_ntiles,
+    const int* __restrict__ grp_count, int ldp, int C, int NG, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float* __restrict__ sc, float* __restrict__ sh) {
+  __shared__ double red[2][4];
+  const int g = blockIdx.x / NG, ng = blockIdx.x % NG;
+  const int CG = C / NG, c0 = ng * CG;
+  const int tile0 = grp_tile0[g], nt = grp_ntiles[g];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // part[t][0][c] = tile sum S, part[t][1][c] = tile-centred M2 (see gemm_rows.hip epilogue).
+  // Tiles of a group are consecutive MM_BM-row chunks, the last one partial.
+  const int rows = grp_count[g];
+  const long total = (long)CG * nt;
+  double s1 = 0.0;
+  for (long idx = tid; idx < total; idx += 256) {
+    const int t = tile0 + (int)(idx / CG);
+    const int c = c0 + (int)(idx % CG);
+    s1 += (double)part[((long)t * 2 + 0) * ldp + c];
+  }
+  s1 = wave_sum_d(s1);
+  if (lane == 0) red[0][wave] = s1;
+  __syncthreads();
+  const double cnt = (double)rows * (double)CG;
+  const double mean = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / cnt;
+  // Chan et al.: M2 = sum_chunks [ M2_chunk + n_chunk (mean_chunk - mean)^2 ], chunk = (tile, channel)
+  double s2 = 0.0;
+  for (long idx = tid; idx < total; idx += 256) {
+    const int ti = (int)(idx / CG);
+    const int t = tile0 + ti;
+    const int c = c0 + (int)(idx % CG);
+    const int left = rows - ti * MM_BM;
+    const double n_t = (double)(left < MM_BM ? left : MM_BM);
+    const double d = (double)part[((long)t * 2 + 0) * ldp + c] / n_t - mean;
+    s2 += (double)part[((long)t * 2 + 1) * ldp + c] + n_t * d * d;
+  }
+  s2 = wave_sum_d(s2);
+  if (lane == 0) red[1][wave] = s2;
+  __syncthreads();
+  const double var = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / cnt;
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  for (int c = c0 + tid; c < c0 + CG; c += 256) {
+    const double scv = (double)gamma[c] * rstd;
+    sc[(long)g * C + c] = (float)scv;
+    sh[(long)g * C + c] = (float)((double)beta[c] - mean * scv);
+  }
+}
+
+extern "C" int mmmot_gn_finalize(const float* part, const int* grp_tile0, const int* grp_ntiles,
+                                 const int* grp_count, int G, int ldp, int C, int NG, const float* gamma,
+                                 const float* beta, float eps, float* sc, float* sh, void* stream) {
+  if (!part || !grp_tile0 || !grp_ntiles || !grp_count || !gamma || !beta || !sc || !sh) return MMMOT_EINVAL;
+  if (G <= 0 || C <= 0 || NG <= 0 || C % NG != 0 || ldp < C) return MMMOT_EINVAL;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(G * NG), dim3(256), 0, (hipStream_t)stream, part, grp_tile0,
+                     grp_ntiles, grp_count, ldp, C, NG, gamma, beta, eps, sc, sh);
+  return mm_check(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------
+// Strided segment mean.  grid = (nseg, ceil(C/256)); 4 waves split the rows of
+// the segment, every lane owns 4 consecutive channels (1 KiB per wave load).
+__global__ __launch_bounds__(256) void segment_mean_kernel(
+    const float* __restrict__ X, int ldx, int C, const int* __restrict__ seg_start,
+    const int* __restrict__ seg_count, const int* __restrict__ seg_stride, const int* __restrict__ seg_group,
+    const float* __restrict__ sc, const float* __restrict__ sh, int ldsc, int relu,
+    float* __restrict__ out, int ldo) {
+  __shared__ __attribute__((aligned(16))) float red[4][256];
+  const int s = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = blockIdx.y * 256 + lane * 4;
+  const bool cv = c < C;
+  const int start = seg_start[s], count = seg_count[s], stride = seg_stride ? seg_stride[s] : 1;
+  const int g = seg_group ? seg_group[s] : 0;
+  f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, h4 = {0.f, 0.f, 0.f, 0.f};
+  const bool norm = (sc != nullptr);
+  if (norm && cv) {
+    s4 = *reinterpret_cast<const f32x4*>(&sc[(long)g * ldsc + c]);
+    h4 = *reinterpret_cast<const f32x4*>(&sh[(long)g * ldsc + c]);
+  }
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+  auto ld = [&](int t) -> f32x4 {
+    f32x4 v = *reinterpret_cast<const f32x4*>(&X[((long)start + (long)t * stride) * ldx + c]);
+    if (norm) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], s4[e], h4[e]);
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    return v;
+  };
+  if (cv) {
+    int t = wave;
+    for (; t + 12 < count; t += 16) {
+      const f32x4 v0 = ld(t), v1 = ld(t + 4), v2 = ld(t + 8), v3 = ld(t + 12);
+      acc0 += v0; acc1 += v1; acc2 += v2; acc3 += v3;
+    }
+    for (; t < count; t += 4) acc0 += ld(t);
+  }
+  const f32x4 acc = (acc0 + acc1) + (acc2 + acc3);
+  *reinterpret_cast<f32x4*>(&red[wave][lane * 4]) = acc;
+  __syncthreads();
+  if (wave == 0 && cv) {
+    f32x4 r = *reinterpret_cast<const f32x4*>(&red[0][lane * 4]);
+    r += *reinterpret_cast<const f32x4*>(&red[1][lane * 4]);
+    r += *reinterpret_cast<const f32x4*>(&red[2][lane * 4]);
+    r += *reinterpret_cast<const f32x4*>(&red[3][lane * 4]);
+    const float inv = 1.f / (float)count;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] *= inv;
+    *reinterpret_cast<f32x4*>(&out[(long)s * ldo + c]) = r;
+  }
+}
+
+extern "C" int mmmot_segment_mean(const float* X, int ldx, int C, const int* seg_start, const int* seg_count,
+                                  const int* seg_stride, const int* seg_group, int nseg, const float* sc,
+                                  const float* sh, int ldsc, int relu, float* out, int ldo, void* stream) {
+  if (!X || !seg_start || !seg_count || !out || nseg <= 0 || C <= 0) return MMMOT_EINVAL;
+  if (C % 4 != 0 || ldx % 4 != 0 || ldo % 4 != 0 || !mm_al16(X) || !mm_al16(out)) return MMMOT_EINVAL;
+  if ((sc == nullptr) != (sh == nullptr)) return MMMOT_EINVAL;
+  if (sc && (ldsc % 4 != 0 || !mm_al16(sc) || !mm_al16(sh))) return MMMOT_EINVAL;
+  hipLaunchKernelGGL(segment_mean_kernel, dim3(nseg, (C + 255) / 256), dim3(256), 0, (hipStream_t)stream, X,
+                     ldx, C, seg_start, seg_count, seg_stride, seg_group, sc, sh, ldsc, relu, out, ldo);
+  return mm_check(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------
+// One-channel output layer: one wave per row, lanes stride the channel axis.
+__global__ __launch_bounds__(256) void rowdot_kernel(
+    const float* __restrict__ X, int ldx, int K, const float* __restrict__ w, float b,
+    const float* __restrict__ sc, const float* __restrict__ sh, int ldsc, const int* __restrict__ tile_row0,
+    const int* __restrict__ tile_nrows, const int* __restrict__ tile_group, int act, int use_thr, float thr,
+    float* __restrict__ out, const int* __restrict__ omap) {
+  const int t = blockIdx.x;
+  const int row0 = tile_row0[t], nrows = tile_nrows[t];
+  const int g = tile_group ? tile_group[t] : 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool norm = (sc != nullptr);
+  for (int r = wave; r < nrows; r += 4) {
+    const float* xr = X + (long)(row0 + r) * ldx;
+    float acc = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(xr + k);
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(w + k);
+      if (norm) {
+        const f32x4 s4 = *reinterpret_cast<const f32x4*>(&sc[(long)g * ldsc + k]);
+        const f32x4 h4 = *reinterpret_cast<const f32x4*>(&sh[(long)g * ldsc + k]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], s4[e], h4[e]), 0.f);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = fmaf(v[e], wv[e], acc);
+    }
+    float s = wave_sum(acc) + b;
+    s = mm_act(s, act);
+    if (use_thr && s < thr) s -= 1.f;
+    if (lane == 0) out[omap ? omap[row0 + r] : row0 + r] = s;
+  }
+}
+
+extern "C" int mmmot_rowdot(const float* X, int ldx, int K, const float* w, float b, const float* sc,
+                            const float* sh, int ldsc, const int* tile_row0, const int* tile_nrows,
+                            const int* tile_group, int T, int act, int use_thr, float thr, float* out,
+                            const int* omap, void* stream) {
+  if (!X || !w || !tile_row0 || !tile_nrows || !out || T <= 0) return MMMOT_EINVAL;
+  if (K % 4 != 0 || ldx % 4 != 0 || !mm_al16(X) || !mm_al16(w)) return MMMOT_EINVAL;
+  if ((sc == nullptr) != (sh == nullptr)) return MMMOT_EINVAL;
+  if (sc && (ldsc % 4 != 0 || !mm_al16(sc) || !mm_al16(sh))) return MMMOT_EINVAL;
+  hipLaunchKernelGGL(rowdot_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream, X, ldx, K, w, b, sc, sh, ldsc,
+                     tile_row0, tile_nrows, tile_group, act, use_thr, thr, out, omap);
+  return mm_check(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------
+// Per-row LayerNorm: one wave per row, the row lives in registers (C <= 1024).
+__global__ __launch_bounds__(256) void row_layernorm_kernel(
+    const float* __restrict__ X, int ldx, int C, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, int relu, float* __restrict__ Y, int ldy, int R) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= R) return;
+  const int per = C >> 6;  // values per lane, <= 16
+  float v[16];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    v[i] = 0.f;
+    if (i < per) { v[i] = X[(long)r * ldx + lane + 64 * i]; s += v[i]; }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    if (i < per) { const float d = v[i] - mean; q += d * d; }
+  const float var = wave_sum(q) / (float)C;
+  const float rstd = 1.f / sqrtf(var + eps);
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    if (i < per) {
+      const int c = lane + 64 * i;
+      float y = (v[i] - mean) * rstd * gamma[c] + beta[c];
+      if (relu) y = fmaxf(y, 0.f);
+      Y[(long)r * ldy + c] = y;
+    }
+}
+
+extern "C" int mmmot_row_layernorm(const float* X, int ldx, int C, const float* gamma, const float* beta,
+                                   float eps, int relu, float* Y, int ldy, int R, void* stream) {
+  if (!X || !gamma || !beta || !Y || R <= 0) return MMMOT_EINVAL;
+  if (C <= 0 || C % 64 != 0 || C > 1024) return MMMOT_EINVAL;
+  hipLaunchKernelGGL(row_layernorm_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, X, ldx, C,
+                     gamma, beta, eps, relu, Y, ldy, R);
+  return mm_check(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------
+// PointNet first shared-MLP layer (K = 3): VALU, output-write bound.
+__global__ __launch_bounds__(256) void pointnet_layer1_kernel(
+    const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
+    float* __restrict__ Y, float* __restrict__ part, const int* __restrict__ tile_row0,
+    const int* __restrict__ tile_nrows) {
+  __shared__ float xs[MM_BM * 3];
+  __shared__ float red[4][2][64];
+  const int t = blockIdx.x;
+  const int row0 = tile_row0[t], nrows = tile_nrows[t];
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < nrows * 3; idx += 256) xs[idx] = X[(long)row0 * 3 + idx];
+  __syncthreads();
+  const int c = tid & 63, rq = tid >> 6;
+  const float w0 = W[c * 3 + 0], w1 = W[c * 3 + 1], w2 = W[c * 3 + 2], bv = bias[c];
+  float s1 = 0.f;
+  for (int i = 0; i < 32; ++i) {
+    const int r = rq * 32 + i;
+    if (r < nrows) {
+      const float y = fmaf(w2, xs[r * 3 + 2], fmaf(w1, xs[r * 3 + 1], fmaf(w0, xs[r * 3 + 0], bv)));
+      Y[(long)(row0 + r) * 64 + c] = y;
+      s1 += y;
+    }
+  }
+  red[rq][0][c] = s1;
+  __syncthreads();
+  // tile-centred second moment (same statistics contract as mmmot_gemm_rows)
+  const float tot = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
+  const float mu = tot / (float)nrows;
+  float s2 = 0.f;
+  for (int i = 0; i < 32; ++i) {
+    const int r = rq * 32 + i;
+    if (r < nrows) {
+      const float y = fmaf(w2, xs[r * 3 + 2], fmaf(w1, xs[r * 3 + 1], fmaf(w0, xs[r * 3 + 0], bv)));
+      const float d = y - mu;
+      s2 += d * d;
+    }
+  }
+  red[rq][1][c] = s2;
+  __syncthreads();
+  if (tid < 64) {
+    part[((long)t * 2 + 0) * 64 + c] = tot;
+    part[((long)t * 2 + 1) * 64 + c] = red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c];
+  }
+}
+
+extern "C" int mmmot_pointnet_layer1(const float* X, const float* W, const float* bias, float* Y, float* part,
+                                     const int* tile_row0, const int* tile_nrows, int T, void* stream) {
+  if (!X || !W || !bias || !Y || !part || !tile_row0 || !tile_nrows || T <= 0) return MMMOT_EINVAL;
+  hipLaunchKernelGGL(pointnet_layer1_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream, X, W, bias, Y, part,
+                     tile_row0, tile_nrows);
+  return mm_check(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------
+// Normalise (+ activation) rows with the group's scale/shift.
+__global__ __launch_bounds__(256) void affine_act_kernel(
+    const float* __restrict__ X, int ldx, int C, const float* __restrict__ sc, const float* __restrict__ sh,
+    int ldsc, const int* __restrict__ tile_row0, const int* __restrict__ tile_nrows,
+    const int* __restrict__ tile_group, int act, float* __restrict__ Y, int ldy) {
+  const int t = blockIdx.x;
+  const int row0 = tile_row0[t], nrows = tile_nrows[t];
+  const int g = tile_group ? tile_group[t] : 0;
+  const int C4 = C >> 2;
+  for (int idx = threadIdx.x; idx < nrows * C4; idx += 256) {
+    const int r = idx / C4, c = (idx - r * C4) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(&X[(long)(row0 + r) * ldx + c]);
+    const f32x4 s4 = *reinterpret_cast<const f32x4*>(&sc[(long)g * ldsc + c]);
+    const f32x4 h4 = *reinterpret_cast<const f32x4*>(&sh[(long)g * ldsc + c]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = mm_act(fmaf(v[e], s4[e], h4[e]), act);
+    *reinterpret_cast<f32x4*>(&Y[(long)(row0 + r) * ldy + c]) = v;
+  }
+}
+
+extern "C" int mmmot_affine_act(const float* X, int ldx, int C, const float* sc, const float* sh, int ldsc,
+                                const int* tile_row0, const int* tile_nrows, const int* tile_group, int T,
+                                int act, float* Y, int ldy, void* stream) {
+  if (!X || !sc || !sh || !tile_row0 || !tile_nrows || !Y || T <= 0) return MMMOT_EINVAL;
+  if (C % 4 != 0 || ldx % 4 != 0 || ldy % 4 != 0 || ldsc % 4 != 0) return MMMOT_EINVAL;
+  if (!mm_al16(X) || !mm_al16(Y) || !mm_al16(sc) || !mm_al16(sh)) return MMMOT_EINVAL;
+  hipLaunchKernelGGL(affine_act_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream, X, ldx, C, sc, sh, ldsc,
+                     tile_row0, tile_nrows, tile_group, act, Y, ldy);
+  return mm_check(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------
+// Fusion module A/B/C combine -> F[3][Lt][C] (image, lidar, fused).
+__global__ __launch_bounds__(256) void fusion_combine_kernel(
+    int mode, const float* __restrict__ cat, const float* __restrict__ Y0, int ld0,
+    const float* __restrict__ Y1, int ld1, const float* __restrict__ sc0, const float* __restrict__ sh0,
+    const float* __restrict__ sc1, const float* __restrict__ sh1, int ldsc, const int* __restrict__ tile_row0,
+    const int* __restrict__ tile_nrows, const int* __restrict__ tile_group, float* __restrict__ F, int Lt,
+    int C) {
+  const int t = blockIdx.x;
+  const int row0 = tile_row0[t], nrows = tile_nrows[t];
+  const int g = tile_group ? tile_group[t] : 0;
+  const int C4 = C >> 2;
+  for (int idx = threadIdx.x; idx < nrows * C4; idx += 256) {
+    const int r = idx / C4, c = (idx - r * C4) * 4;
+    const long d = row0 + r;
+    const f32x4 fi = *reinterpret_cast<const f32x4*>(&cat[d * 2 * C + c]);
+    const f32x4 fl = *reinterpret_cast<const f32x4*>(&cat[d * 2 * C + C + c]);
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(&sc0[(long)g * ldsc + c]);
+    const f32x4 h0 = *reinterpret_cast<const f32x4*>(&sh0[(long)g * ldsc + c]);
+    f32x4 fused;
+    if (mode == MMMOT_FUSION_A) {
+      const f32x4 y0 = *reinterpret_cast<const f32x4*>(&Y0[d * ld0 + c]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) fused[e] = fmaf(y0[e], s0[e], h0[e]);
+    } else {
+      const f32x4 s1 = *reinterpret_cast<const f32x4*>(&sc1[(long)g * ldsc + c]);
+      const f32x4 h1 = *reinterpret_cast<const f32x4*>(&sh1[(long)g * ldsc + c]);
+      if (mode == MMMOT_FUSION_B) {
+        const f32x4 y0 = *reinterpret_cast<const f32x4*>(&Y0[d * ld0 + c]);
+        const f32x4 y1 = *reinterpret_cast<const f32x4*>(&Y1[d * ld1 + c]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fused[e] = fmaf(y0[e], s0[e], h0[e]) + fmaf(y1[e], s1[e], h1[e]);
+      } else {
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(&Y0[d * ld0 + c]);
+        const f32x4 i0 = *reinterpret_cast<const f32x4*>(&Y0[d * ld0 + C + c]);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(&Y1[d * ld1 + c]);
+        const f32x4 i1 = *reinterpret_cast<const f32x4*>(&Y1[d * ld1 + C + c]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a0 = mm_sigmoid(g0[e]), a1 = mm_sigmoid(g1[e]);
+          const float num = a0 * fmaf(i0[e], s0[e], h0[e]) + a1 * fmaf(i1[e], s1[e], h1[e]);
+          fused[e] = num / (a0 + a1);
+        }
+      }
+    }
+    *reinterpret_cast<f32x4*>(&F[(0L * Lt + d) * C + c]) = fi;
+    *reinterpret_cast<f32x4*>(&F[(1L * Lt + d) * C + c]) = fl;
+    *reinterpret_cast<f32x4*>(&F[(2L * Lt + d) * C + c]) = fused;
+  }
+}
+
+extern "C" int mmmot_fusion_combine(int mode, const float* cat, const float* Y0, int ld0, const float* Y1,
+                                    int ld1, const float* sc0, const float* sh0, const float* sc1,
+                                    const float* sh1, int ldsc, const int* tile_row0, const int* tile_nrows,
+                                    const int* tile_group, int T, float* F, int Lt, int C, void* stream) {
+  if (!cat || !Y0 || !sc0 || !sh0 || !tile_row0 || !tile_nrows || !F || T <= 0 || Lt <= 0) return MMMOT_EINVAL;
+  if (mode < MMMOT_FUSION_A || mode > MMMOT_FUSION_C) return MMMOT_EINVAL;
+  if (mode != MMMOT_FUSION_A && (!Y1 || !sc1 || !sh1)) return MMMOT_EINVAL;
+  if (C % 4 != 0 || ld0 % 4 != 0 || ldsc % 4 != 0 || (Y1 && ld1 % 4 != 0)) return MMMOT_EINVAL;
+  hipLaunchKernelGGL(fusion_combine_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream, mode, cat, Y0, ld0, Y1,
+                     ld1, sc0, sh0, sc1, sh1, ldsc, tile_row0, tile_nrows, tile_group, F, Lt, C);
+  return mm_check(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------
+// Softmax modes over each group's N x M logit block (one workgroup per group):
+// row statistics by wave reductions, column statistics by one thread per column
+// (coalesced across the wave), then a single normalising pass.
+__global__ __launch_bounds__(256) void softmax_pairs_kernel(
+    const float* __restrict__ logits, float* __restrict__ out, const int* __restrict__ grp_row0,
+    const int* __restrict__ grp_N, const int* __restrict__ grp_M, int mode) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int g = blockIdx.x;
+  const int N = grp_N[g], M = grp_M[g];
+  const float* x = logits + grp_row0[g];
+  float* o = out + grp_row0[g];
+  float* rmax = sm;
+  float* rsum = sm + N;
+  float* cmax = sm + 2 * N;
+  float* csum = sm + 2 * N + M;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool dual = (mode != MMMOT_SM_SINGLE);
+  for (int i = wave; i < N; i += 4) {
+    float mx = -INFINITY;
+    for (int j = lane; j < M; j += 64) mx = fmaxf(mx, x[(long)i * M + j]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int j = lane; j < M; j += 64) s += expf(x[(long)i * M + j] - mx);
+    s = wave_sum(s);
+    if (lane == 0) { rmax[i] = mx; rsum[i] = s; }
+  }
+  if (dual) {
+    for (int j = tid; j < M; j += 256) {
+      float mx = -INFINITY;
+      for (int i = 0; i < N; ++i) mx = fmaxf(mx, x[(long)i * M + j]);
+      float s = 0.f;
+      for (int i = 0; i < N; ++i) s += expf(x[(long)i * M + j] - mx);
+      cmax[j] = mx;
+      csum[j] = s;
+    }
+  }
+  __syncthreads();
+  const int total = N * M;
+  for (int idx = tid; idx < total; idx += 256) {
+    const int i = idx / M, j = idx - i * M;
+    const float v = x[idx];
+    const float p = expf(v - rmax[i]) / rsum[i];
+    float r = p;
+    if (dual) {
+      const float q = expf(v - cmax[j]) / csum[j];
+      if (mode == MMMOT_SM_DUAL) r = p * q;
+      else if (mode == MMMOT_SM_DUAL_ADD) r = (p + q) / 2.f;
+      else r = fmaxf(p, q);
+    }
+    o[idx] = r;
+  }
+}
+
+extern "C" int mmmot_softmax_pairs(const float* logits, float* out, const int* grp_row0, const int* grp_N,
+                                   const int* grp_M, int G, int max_nm, int mode, void* stream) {
+  if (!logits || !out || !grp_row0 || !grp_N || !grp_M || G <= 0 || max_nm <= 0) return MMMOT_EINVAL;
+  if (mode < MMMOT_SM_SINGLE || mode > MMMOT_SM_DUAL_MAX) return MMMOT_EINVAL;
+  const size_t lds = (size_t)2 * max_nm * sizeof(float);
+  if (lds > 64 * 1024) return MMMOT_EINVAL;
+  hipLaunchKernelGGL(softmax_pairs_kernel, dim3(G), dim3(256), lds, (hipStream_t)stream, logits, out, grp_row0,
+                     grp_N, grp_M, mode);
+  return mm_check(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------
+extern "C" int mmmot_abi_version(void) { return 1; }
+
+extern "C" int mmmot_device_info(int device, int* cu_count, char* arch, int arch_len) {
+  hipDeviceProp_t p;
+  hipError_t e = hipGetDeviceProperties(&p, device);
+  if (e != hipSuccess) return (int)e;
+  if (cu_count) *cu_count = p.multiProcessorCount;
+  if (arch && arch_len > 0) {
+    int i = 0;
+    for (; i < arch_len - 1 && p.gcnArchName[i]; ++i) arch[i] = p.gcnArchName[i];
+    arch[i] = 0;
+  }
+  return MMMOT_OK;
+}

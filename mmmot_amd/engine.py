@@ -1,0 +1,250 @@
+"""Launch schedule of the mmMOT forward over the device operator layer.
+
+One ``Engine`` owns the packed weights of a ``TrackingNet`` and a workspace
+arena; ``forward(plan, crops, points)`` issues the kernel sequence for a whole
+batch of samples on the current HIP stream and returns device tensors.  The
+schedule follows the data flow of reference modules/tracking_net.py:128-193
+(feature -> determine_det -> associate) but not its module structure: every
+normalisation on the path is a whole-sample reduction, so the schedule is a
+chain of  GEMM(+stats epilogue) -> finalize -> next GEMM(normalise prologue).
+
+``ops`` is the operator backend: ``mmmot_amd.ops.HipOps`` in the product.  The
+engine itself only allocates memory and orders launches.
+"""
+import torch
+
+from .ops import (ACT_NONE, ACT_RELU, ACT_SIGMOID, A_NORM_RELU, A_PAIR, A_PLAIN, FUSION_MODES, PAIR_OPS,
+                  SOFTMAX_MODES)
+
+EPS = 1e-5  # nn.GroupNorm / nn.BatchNorm default used everywhere in the reference
+
+
+class Engine:
+    def __init__(self, packed, ops, fusion='A', affinity_op='multiply', softmax_mode='none',
+                 neg_threshold=0.0, score_arch='branch_cls', end_mode='avg'):
+        if affinity_op not in PAIR_OPS:
+            raise ValueError('unknown affinity_op %r' % (affinity_op,))
+        if softmax_mode not in SOFTMAX_MODES and softmax_mode != 'none':
+            softmax_mode = 'none'  # reference falls through to the raw logits (tracking_net.py:123-124)
+        if end_mode != 'avg':
+            raise NotImplementedError("end_mode='max' is not built (no shipped config uses it)")
+        self.P = packed
+        self.ops = ops
+        self.fusion = fusion
+        self.affinity_op = affinity_op
+        self.softmax_mode = softmax_mode
+        self.neg_threshold = float(neg_threshold)
+        self.score_arch = score_arch
+        self.ws = {}
+        self.keep = None  # optional dict collecting per-stage tensors (tests)
+
+    # ---- workspace arena ---------------------------------------------------
+    def buf(self, name, *shape, device=None):
+        n = 1
+        for s in shape:
+            n *= int(s)
+        t = self.ws.get(name)
+        if t is None or t.numel() < n or (device is not None and t.device != torch.device(device)):
+            t = torch.empty(max(n, 4), dtype=torch.float32, device=device if device is not None else self.dev)
+            self.ws[name] = t
+        return t[:n].view(*shape)
+
+    def _finalize(self, name, part, tiles, C, NG, gamma, beta):
+        sc = self.buf(name + '_sc', tiles.G, C)
+        sh = self.buf(name + '_sh', tiles.G, C)
+        self.ops.gn_finalize(part, tiles, C, NG, gamma, beta, EPS, sc, sh)
+        return sc, sh
+
+    def _part(self, tiles, N):
+        return self.buf('part', tiles.T, 2, N)
+
+    def _stash(self, key, t):
+        if self.keep is not None:
+            self.keep[key] = t.detach().clone()
+
+    # ---- image branch: VGG16-BN trunk + SkipPool heads ---------------------
+    def appearance(self, plan, crops, cat):
+        """crops [Lt,3,S,S] NCHW (reference contract) -> cat[:, 0:512]."""
+        ops, Lt, S = self.ops, plan.Lt, plan.S
+        x, H, W = crops, S, S
+        for li, cv in enumerate(self.P['vgg']):
+            Ho, Wo = (H // 2, W // 2) if cv['pool'] else (H, W)
+            out = self.buf('vgg%d' % (li & 1), Lt * Ho * Wo, cv['cout'])
+            ops.conv3x3(x, cv['wp'], cv['bias'], out, Lt, H, W, cv['cin'], cv['cout'], li == 0, cv['pool'])
+            x, H, W = out, Ho, Wo
+            if cv['last']:
+                self._stash('vgg_stage%d' % cv['stage'], x)
+                self._skippool(plan, cv['stage'], x, H * W, cv['cout'], cat)
+
+    def _skippool(self, plan, s, x, hw, C, cat):
+        """reference modules/appear_net.py:9-32 for stage s -> cat[:, 128 s : 128 (s+1)]."""
+        ops, Lt, hd, T = self.ops, plan.Lt, self.P['skippool'][s], plan.det_tiles
+        pooled = self.buf('sp_pool', Lt, C)
+        ops.segment_mean(x, C, plan.crop_segments(hw), pooled, use_group=False)
+        ln0 = self.buf('sp_ln0', Lt, C)
+        ops.row_layernorm(pooled, C, hd['g0'], hd['b0'], EPS, False, ln0, Lt)
+        C4 = hd['w1'].shape[0]
+        h1 = self.buf('sp_h1', Lt, C4)
+        ops.gemm(hd['w1'], T, C4, C, X=ln0, bias=hd['c1'], Y=h1)
+        ln1 = self.buf('sp_ln1', Lt, C4)
+        ops.row_layernorm(h1, C4, hd['g2'], hd['b2'], EPS, True, ln1, Lt)
+        h2 = self.buf('sp_h2', Lt, 128)
+        ops.gemm(hd['w4'], T, 128, C4, X=ln1, bias=hd['c4'], Y=h2)
+        ops.row_layernorm(h2, 128, hd['g5'], hd['b5'], EPS, True, cat[:, 128 * s:128 * (s + 1)], Lt)
+
+    # ---- LiDAR branch: PointNet with folded transforms ----------------------
+    def pointnet(self, plan, points, cat):
+        """points [P,3] -> cat[:, 512:1024]; reference modules/point_net.py:25-44,115-153."""
+        ops, pn, T, D, Pn, Lt = self.ops, self.P['pointnet'], plan.pt_tiles, plan.det_tiles, plan.P, plan.Lt
+        y1 = self.buf('pn_y1', Pn, 64)
+        part = self._part(T, 64)
+        ops.pointnet_layer1(points, pn['w1'], pn['b1'], y1, part, T)
+        sc1, sh1 = self._finalize('pn1', part, T, 64, 64, pn['g1'], pn['be1'])
+        # conv2..conv5: each consumes relu(gn(previous)) through the GEMM prologue
+        x, sc, sh = y1, sc1, sh1
+        for i, (N, K) in zip((2, 3, 4, 5), ((64, 64), (64, 64), (128, 64), (1024, 128))):
+            y = self.buf('pn_y%d' % i, Pn, N)
+            part = self._part(T, N)
+            ops.gemm(pn['w%d' % i], T, N, K, X=x, bias=pn['b%d' % i], Y=y, part=part, sc=sc, sh=sh,
+                     amode=A_NORM_RELU)
+            sc, sh = self._finalize('pn%d' % i, part, T, N, N, pn['g%d' % i], pn['be%d' % i])
+            x = y
+        # per-detection average of relu(gn5(conv5)) (named max_feats in the reference, point_net.py:139-148)
+        seg1024 = self.buf('pn_seg1024', Lt, 1024)
+        ops.segment_mean(x, 1024, plan.det_segs, seg1024, sc=sc, sh=sh, relu=True)
+        self._stash('pn_seg1024', seg1024)
+        # PointNet_v1.conv1 split: per-detection 1024-channel part becomes a gathered bias
+        dbias = self.buf('pn_dbias', Lt, 512)
+        ops.gemm(pn['wc1b'], D, 512, 1024, X=seg1024, bias=pn['bc1'], Y=dbias)
+        yc1 = self.buf('pn_yc1', Pn, 512)
+        part = self._part(T, 512)
+        ops.gemm(pn['wc1a'], T, 512, 64, X=y1, Y=yc1, part=part, sc=sc1, sh=sh1, amode=A_NORM_RELU,
+                 dbias=dbias, rowidx=plan.row_det)
+        scc, shc = self._finalize('pnc1', part, T, 512, 512, pn['gc1'], pn['bec1'])
+        seg512 = self.buf('pn_seg512', Lt, 512)
+        ops.segment_mean(yc1, 512, plan.det_segs, seg512, sc=scc, sh=shc, relu=True)
+        yc2 = self.buf('pn_yc2', Lt, 512)
+        part = self._part(D, 512)
+        ops.gemm(pn['wc2'], D, 512, 512, X=seg512, bias=pn['bc2'], Y=yc2, part=part)
+        sc2, sh2 = self._finalize('pnc2', part, D, 512, 16, pn['gc2'], pn['bec2'])
+        ops.affine_act(yc2, 512, sc2, sh2, D, ACT_RELU, cat[:, 512:1024])
+
+    # ---- fusion module A / B / C --------------------------------------------
+    def fuse(self, plan, cat, F):
+        """cat [Lt,1024] -> F [3,Lt,512]; reference modules/fusion_net.py."""
+        ops, fu, D, Lt = self.ops, self.P['fusion'], plan.det_tiles, plan.Lt
+        mode = FUSION_MODES[self.fusion]
+        img, pts = cat[:, 0:512], cat[:, 512:1024]
+        if self.fusion == 'A':
+            y0 = self.buf('fu_y0', Lt, 512)
+            part = self._part(D, 512)
+            ops.gemm(fu['w0'], D, 512, 1024, X=cat, bias=fu['b0'], Y=y0, part=part)
+            sc0, sh0 = self._finalize('fu0', part, D, 512, 512, fu['g0'], fu['be0'])
+            ops.fusion_combine(mode, cat, y0, None, sc0, sh0, None, None, D, F, Lt, 512)
+            return
+        N = 512 if self.fusion == 'B' else 1024
+        ys, scs, shs = [], [], []
+        for j, x in enumerate((img, pts)):  # NB: *_p weights consume the IMAGE features
+            y = self.buf('fu_y%d' % j, Lt, N)
+            part = self._part(D, N)
+            ops.gemm(fu['w%d' % j], D, N, 512, X=x, bias=fu['b%d' % j], Y=y, part=part)
+            sc, sh = self._finalize('fu%d' % j, part, D, N, N, fu['g%d' % j], fu['be%d' % j])
+            ys.append(y)
+            scs.append(sc[:, N - 512:])
+            shs.append(sh[:, N - 512:])
+        ops.fusion_combine(mode, cat, ys[0], ys[1], scs[0], shs[0], scs[1], shs[1], D, F, Lt, 512)
+
+    # ---- negative-rejection head --------------------------------------------
+    def det_scores(self, plan, F):
+        """F [nR,Lt,512] -> [nR,Lt]; reference modules/tracking_net.py:91-100,149-163 (eval)."""
+        ops, wd, T = self.ops, self.P['w_det'], plan.F_tiles
+        R = plan.nR * plan.Lt
+        X = F.view(R, 512)
+        h0 = self.buf('det_h0', R, 512)
+        ops.gemm(wd['w0'], T, 512, 512, X=X, bias=wd['b0'], Y=h0, act=ACT_RELU)
+        h1 = self.buf('det_h1', R, 256)
+        ops.gemm(wd['w3'], T, 256, 512, X=h0, bias=wd['b3'], Y=h1, act=ACT_RELU)
+        out = torch.empty(plan.nR, plan.Lt, dtype=torch.float32, device=F.device)
+        act = ACT_SIGMOID if 'cls' in self.score_arch else ACT_NONE
+        ops.rowdot(h1, 256, wd['w6'], wd['b6'], T, out.view(-1), act=act, use_thr=True, thr=self.neg_threshold)
+        return out
+
+    # ---- pairwise affinity + new/end + softmax ------------------------------
+    def affinity(self, plan, F):
+        """reference modules/gcn.py:68-82, new_end.py:62-82, tracking_net.py:106-126."""
+        ops, lk, PT, VT = self.ops, self.P['w_link'], plan.pair_tiles, plan.v_tiles
+        nR, Lt, R = plan.nR, plan.Lt, plan.pair_tiles.R
+        Ff = F.view(nR * Lt, 512)
+        pair = dict(row0=PT.g_row0, M=plan.pg_M, aoff=plan.pg_aoff, boff=plan.pg_boff)
+        # stacked [new_end.conv0 ; conv1.0] over the on-the-fly pairwise tensor
+        ya = self.buf('aff_ya', R, 1024)
+        part = self._part(PT, 1024)
+        ops.gemm(lk['wa'], PT, 1024, 512, FA=Ff, FB=Ff, pair=pair, amode=A_PAIR,
+                 pairop=PAIR_OPS[self.affinity_op], bias=lk['ba'], Y=ya, part=part)
+        sc_ne, sh_ne = self._finalize('aff_ne0', part[:, :, 0:512], PT, 512, 1, lk['g_ne0'], lk['be_ne0'])
+        sc1, sh1 = self._finalize('aff_1', part[:, :, 512:1024], PT, 512, 512, lk['g1'], lk['be1'])
+        # new / end vectors: strided means of relu(gn(conv0)) over the prev / curr axis
+        V = self.buf('aff_v', VT.R, 512)
+        ops.segment_mean(ya[:, 0:512], 512, plan.v_segs, V, sc=sc_ne, sh=sh_ne, relu=True)
+        self._stash('aff_v', V)
+        vh0 = self.buf('aff_vh0', VT.R, 512)
+        part = self._part(VT, 512)
+        ops.gemm(lk['nw0'], VT, 512, 512, X=V, bias=lk['nb0'], Y=vh0, part=part)
+        scv, shv = self._finalize('aff_v1', part, VT, 512, 1, lk['ng1'], lk['nbe1'])
+        vh1 = self.buf('aff_vh1', VT.R, 128)
+        part = self._part(VT, 128)
+        ops.gemm(lk['nw3'], VT, 128, 512, X=vh0, bias=lk['nb3'], Y=vh1, part=part, sc=scv, sh=shv,
+                 amode=A_NORM_RELU)
+        scv2, shv2 = self._finalize('aff_v4', part, VT, 128, 1, lk['ng4'], lk['nbe4'])
+        ne = torch.zeros(2, nR, Lt, dtype=torch.float32, device=F.device)  # eval-mode zero padding (tracking_net.py:183-189)
+        ops.rowdot(vh1, 128, lk['nw6'], lk['nb6'], VT, ne.view(-1), sc=scv2, sh=shv2, act=ACT_SIGMOID,
+                   omap=plan.v_omap)
+        # link branch
+        y3 = self.buf('aff_y3', R, 512)
+        part = self._part(PT, 512)
+        ops.gemm(lk['w3'], PT, 512, 512, X=ya[:, 512:1024], bias=lk['b3'], Y=y3, part=part, sc=sc1, sh=sh1,
+                 amode=A_NORM_RELU)
+        sc4, sh4 = self._finalize('aff_4', part, PT, 512, 512, lk['g4'], lk['be4'])
+        y6 = self.buf('aff_y6', R, 128)
+        part = self._part(PT, 128)
+        ops.gemm(lk['w6'], PT, 128, 512, X=y3, bias=lk['b6'], Y=y6, part=part, sc=sc4, sh=sh4,
+                 amode=A_NORM_RELU)
+        sc7, sh7 = self._finalize('aff_7', part, PT, 128, 128, lk['g7'], lk['be7'])
+        logits = torch.empty(R, dtype=torch.float32, device=F.device)
+        ops.rowdot(y6, 128, lk['w9'], lk['b9'], PT, logits, sc=sc7, sh=sh7)
+        link = logits
+        if self.softmax_mode != 'none':
+            link = torch.empty_like(logits)
+            ops.softmax_pairs(logits, link, PT.g_row0, plan.pg_N, plan.pg_M, PT.G, plan.max_nm,
+                              SOFTMAX_MODES[self.softmax_mode])
+        return link, ne[0], ne[1]
+
+    # ---- whole forward -------------------------------------------------------
+    def forward(self, plan, crops=None, points=None):
+        """Returns dict(det [nR,Lt], link flat, new [nR,Lt], end [nR,Lt], feats F, cat)."""
+        rows = plan.rows
+        need_img = (0 in rows) or (2 in rows)
+        need_pts = (1 in rows) or (2 in rows)
+        dev = crops.device if crops is not None else points.device
+        self.dev = dev
+        Lt = plan.Lt
+        cat = self.buf('cat', Lt, 1024)
+        if need_img:
+            if crops is None or tuple(crops.shape) != (Lt, 3, plan.S, plan.S) or not crops.is_contiguous():
+                raise ValueError('crops must be a contiguous [%d,3,%d,%d] tensor' % (Lt, plan.S, plan.S))
+            self.appearance(plan, crops, cat)
+        if need_pts:
+            if points is None or tuple(points.shape) != (plan.P, 3) or not points.is_contiguous():
+                raise ValueError('points must be a contiguous [%d,3] tensor' % plan.P)
+            self.pointnet(plan, points, cat)
+        F = self.buf('F', plan.nR, Lt, 512)
+        if rows == (0, 1, 2):
+            self.fuse(plan, cat, F)
+        else:
+            for ri, r in enumerate(rows):  # single-modality rows: a device copy, no arithmetic
+                if r == 2:
+                    raise ValueError('the fused row needs rows=(0,1,2)')
+                F[ri].copy_(cat[:, 512 * r:512 * (r + 1)])
+        det = self.det_scores(plan, F)
+        link, new, end = self.affinity(plan, F)
+        return dict(det=det, link=link, new=new, end=end, F=F, cat=cat)

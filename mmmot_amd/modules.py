@@ -1,0 +1,403 @@
+"""Drop-in ``nn.Module`` mirror of the reference network API.
+
+Same constructor keywords, same ``state_dict`` keys / shapes, same
+``forward(dets, det_info, dets_split)`` signature and return tuple as reference
+modules/tracking_net.py:17-35,165-193 - so ``tracking_model.py`` /
+``eval_seq.py`` keep working when ``build_model`` imports ``TrackingNet`` from
+here.  The torch sub-modules below are *parameter containers only* (they give
+the reference key names and ``load_state_dict`` semantics); none of their
+``forward`` methods is ever called.  All arithmetic happens in
+libmmmot_hip.so through ``Engine``; CPU tensors are rejected (no fallback).
+
+Inference (eval mode) only: the north-star path is the forward; ``train()``
+mode raises.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .engine import Engine
+from .pack import VGG_STAGES, pack_weights
+from .plan import BatchPlan
+
+
+def _gn(groups, ch):
+    return nn.GroupNorm(groups, ch)
+
+
+class SkipPool(nn.Module):
+    """Parameter layout of reference modules/appear_net.py:9-32 (``fc`` indices 0,1,2,4,5)."""
+
+    def __init__(self, channels, reduction, out_channels, dropblock_size=0):
+        super().__init__()
+        mid = max(channels // reduction, 64)
+        self.channels = channels
+        self.fc = nn.Sequential(_gn(1, channels), nn.Conv2d(channels, mid, 1), _gn(1, mid), nn.ReLU(inplace=True),
+                                nn.Conv2d(mid, out_channels, 1), _gn(1, out_channels), nn.ReLU(inplace=True))
+
+
+class AppearanceNet(nn.Module):
+    """VGG16-BN + SkipPool image-crop encoder (reference modules/appear_net.py:35-59,130-190)."""
+
+    def __init__(self, arch='vgg', out_channels=512, skippool=True, fpn=False, dropblock=0):
+        super().__init__()
+        if arch != 'vgg' or not skippool or fpn or out_channels != 512:
+            raise NotImplementedError('HIP path builds the vgg16_bn_512 + skippool encoder only '
+                                      '(every shipped config; resnet/fpn branches need torchvision downloads)')
+        self.arch, self.skippool, self.fpn, self.out_channels, self.dropblock = arch, skippool, fpn, out_channels, dropblock
+        stages, heads = [], []
+        for stage in VGG_STAGES:
+            mods = []
+            for (_, cin, cout, pool) in stage:
+                mods += [nn.Conv2d(cin, cout, 3, padding=1), nn.BatchNorm2d(cout), nn.ReLU(inplace=True)]
+                if pool:
+                    mods.append(nn.MaxPool2d(2, 2))
+            stages.append(nn.Sequential(*mods))
+            heads.append(SkipPool(stage[-1][2], 4, out_channels // 4, 0))
+        self.layers = nn.ModuleList(stages)
+        self.global_pool = nn.ModuleList(heads)
+        self._engine = None
+
+    def forward(self, x):
+        """x: L x 3 x S x S crops -> L x 512 (HIP)."""
+        eng = _standalone_engine(self, 'appearance.')
+        L, S = x.shape[0], x.shape[-1]
+        plan = BatchPlan(_dummy_samples(L), S, x.device, use_points=False)
+        eng.dev = x.device
+        cat = eng.buf('cat', L, 1024)
+        eng.appearance(plan, x.contiguous(), cat)
+        return cat[:, :512].clone()
+
+
+class STN3d(nn.Module):
+    """Parameter layout of reference modules/point_net.py:47-70."""
+
+    def __init__(self, in_channels, out_size=3, feature_channels=512):
+        super().__init__()
+        self.out_size = out_size
+        self.conv1 = nn.Conv1d(in_channels, 64, 1)
+        self.bn1 = _gn(64, 64)
+        self.conv2 = nn.Conv1d(64, 128, 1)
+        self.bn2 = _gn(128, 128)
+        self.conv3 = nn.Conv1d(128, 1024, 1)
+        self.bn3 = _gn(1024, 1024)
+        self.idt = nn.Parameter(torch.eye(out_size), requires_grad=False)
+        self.fc1 = nn.Linear(1024, 512)
+        self.fc_bn1 = _gn(512, 512)
+        self.fc2 = nn.Linear(512, 256)
+        self.fc_bn2 = _gn(256, 256)
+        self.output = nn.Linear(256, out_size * out_size)
+        nn.init.zeros_(self.output.weight)
+        nn.init.zeros_(self.output.bias)
+
+
+class PointNetfeatGN(nn.Module):
+    """Parameter layout of reference modules/point_net.py:89-113."""
+
+    def __init__(self, in_channels=3, out_channels=512, global_feat=True):
+        super().__init__()
+        self.stn1 = STN3d(in_channels, in_channels, out_channels)
+        self.conv1 = nn.Conv1d(in_channels, 64, 1)
+        self.bn1 = _gn(64, 64)
+        self.conv2 = nn.Conv1d(64, 64, 1)
+        self.bn2 = _gn(64, 64)
+        self.stn2 = STN3d(64, 64, out_channels)
+        self.conv3 = nn.Conv1d(64, 64, 1)
+        self.bn3 = _gn(64, 64)
+        self.conv4 = nn.Conv1d(64, 128, 1)
+        self.bn4 = _gn(128, 128)
+        self.conv5 = nn.Conv1d(128, 1024, 1)
+        self.bn5 = _gn(1024, 1024)
+
+
+class PointNet_v1(nn.Module):
+    """LiDAR encoder (reference modules/point_net.py:5-44)."""
+
+    def __init__(self, in_channels, out_channels=512, use_dropout=False):
+        super().__init__()
+        if in_channels != 3 or out_channels != 512:
+            raise NotImplementedError('HIP path builds PointNet_v1(3 -> 512) (without_reflectivity=True, point_len=512)')
+        self.out_channels = out_channels
+        self.feat = PointNetfeatGN(in_channels, out_channels)
+        self.conv1 = nn.Conv1d(1088, 512, 1)
+        self.conv2 = nn.Conv1d(512, out_channels, 1)
+        self.bn1 = _gn(512, 512)
+        self.bn2 = _gn(16, out_channels)
+        self.avg_bn = _gn(512, 512)  # unused by the reference forward too; kept for key parity
+        self.dropout = None  # eval-only path; reference dropout is identity in eval (point_net.py:29-30)
+
+    def forward(self, x, point_split):
+        """x: 1 x 3 x P, point_split: (L+1,) -> (L x 512, [1x3x3, 1x64x64]) (HIP)."""
+        eng = _standalone_engine(self, 'point_net.')
+        ps = point_split.detach().cpu().numpy().astype(np.int64)
+        L = ps.shape[0] - 1
+        plan = BatchPlan([(_dummy_samples(L)[0][0], ps)], 32, x.device)
+        eng.dev = x.device
+        cat = eng.buf('cat', L, 1024)
+        pts = x[0].t().contiguous()
+        eng.pointnet(plan, pts, cat)
+        pn = eng.P['pointnet']
+        return cat[:, 512:].clone(), [pn['trans1'].unsqueeze(0).clone(), pn['trans2'].unsqueeze(0).clone()]
+
+
+def _conv_gn(cin, cout, groups):
+    return nn.Sequential(nn.Conv1d(cin, cout, 1, 1), _gn(groups, cout))
+
+
+class _FusionBase(nn.Module):
+    mode = None
+
+    def forward(self, objs):
+        """objs: 1 x 2D x L -> 3 x D x L (HIP)."""
+        eng = _standalone_engine(self, 'fusion_module.', fusion=self.mode)
+        L = objs.shape[-1]
+        plan = BatchPlan(_dummy_samples(L), 32, objs.device, use_points=False)
+        eng.dev = objs.device
+        cat = eng.buf('cat', L, 1024)
+        cat.copy_(objs[0].t())
+        F = eng.buf('F', 3, L, 512)
+        eng.fuse(plan, cat, F)
+        return F.permute(0, 2, 1).contiguous()
+
+
+class fusion_module_A(_FusionBase):
+    """reference modules/fusion_net.py:73-92"""
+    mode = 'A'
+
+    def __init__(self, appear_len, point_len, out_channels):
+        super().__init__()
+        self.appear_len, self.point_len = appear_len, point_len
+        self.input_w = _conv_gn(out_channels * 2, out_channels, out_channels)
+
+
+class fusion_module_B(_FusionBase):
+    """reference modules/fusion_net.py:45-70"""
+    mode = 'B'
+
+    def __init__(self, appear_len, point_len, out_channels):
+        super().__init__()
+        self.appear_len, self.point_len = appear_len, point_len
+        self.input_p = _conv_gn(out_channels, out_channels, out_channels)
+        self.input_i = _conv_gn(out_channels, out_channels, out_channels)
+
+
+class fusion_module_C(_FusionBase):
+    """reference modules/fusion_net.py:6-42"""
+    mode = 'C'
+
+    def __init__(self, appear_len, point_len, out_channels):
+        super().__init__()
+        self.appear_len, self.point_len = appear_len, point_len
+        self.gate_p = nn.Sequential(nn.Conv1d(point_len, point_len, 1, 1), nn.Sigmoid())
+        self.gate_i = nn.Sequential(nn.Conv1d(appear_len, appear_len, 1, 1), nn.Sigmoid())
+        self.input_p = _conv_gn(point_len, out_channels, out_channels)
+        self.input_i = _conv_gn(appear_len, out_channels, out_channels)
+
+
+FUSION_CLASSES = {'A': fusion_module_A, 'B': fusion_module_B, 'C': fusion_module_C}
+
+
+class NewEndIndicator_v2(nn.Module):
+    """Parameter layout of reference modules/new_end.py:43-60."""
+
+    def __init__(self, in_channels, kernel_size=5, reduction=4, mode='avg'):
+        super().__init__()
+        self.mode = mode
+        mid = min(in_channels, 512)
+        self.conv0 = nn.Sequential(nn.Conv2d(in_channels, in_channels, 1, 1), _gn(1, in_channels), nn.ReLU(inplace=True))
+        self.conv1 = nn.Sequential(nn.Conv1d(in_channels, mid, 1, 1), _gn(1, mid), nn.ReLU(inplace=True),
+                                   nn.Conv1d(mid, in_channels // reduction, 1, 1), _gn(1, in_channels // reduction),
+                                   nn.ReLU(inplace=True), nn.Conv1d(in_channels // reduction, 1, 1, 1), nn.Sigmoid())
+
+
+class affinity_module(nn.Module):
+    """Pairwise affinity + new/end heads (reference modules/gcn.py:45-82)."""
+
+    def __init__(self, in_channels, new_end=None, affinity_op='multiply'):
+        super().__init__()
+        if in_channels != 512:
+            raise NotImplementedError('HIP path builds the 512-channel affinity module')
+        self.in_channels = in_channels
+        self.affinity_op = affinity_op
+        self.w_new_end = new_end(in_channels) if new_end is not None else NewEndIndicator_v2(in_channels)
+        c = in_channels
+        self.conv1 = nn.Sequential(nn.Conv2d(c, c, 1, 1), _gn(c, c), nn.ReLU(inplace=True),
+                                   nn.Conv2d(c, c, 1, 1), _gn(c, c), nn.ReLU(inplace=True),
+                                   nn.Conv2d(c, c // 4, 1, 1), _gn(c // 4, c // 4), nn.ReLU(inplace=True),
+                                   nn.Conv2d(c // 4, 1, 1, 1))
+
+    def forward(self, objs, dets):
+        """objs R x D x N, dets R x D x M -> (R x 1 x N x M logits, R x M new, R x N end) (HIP)."""
+        eng = _standalone_engine(self, 'w_link.', affinity_op=self.affinity_op)
+        R, _, N = objs.shape
+        M = dets.shape[-1]
+        plan = BatchPlan([([N, M], None)], 32, objs.device, rows=tuple(range(R)), use_points=False)
+        eng.dev = objs.device
+        F = eng.buf('F', R, N + M, 512)
+        F[:, :N].copy_(objs.permute(0, 2, 1))
+        F[:, N:].copy_(dets.permute(0, 2, 1))
+        link, new, end = eng.affinity(plan, F)
+        return link.view(R, 1, N, M), new[:, N:].clone(), end[:, :N].clone()
+
+
+def _dummy_samples(L):
+    """One sample of L detections split over two frames (sub-module calls carry no frame split)."""
+    if L < 2:
+        raise ValueError('stand-alone sub-module calls need >= 2 detections')
+    return [([L // 2, L - L // 2], None)]
+
+
+def _standalone_engine(module, prefix, **cfg):
+    """Engine for calling a sub-module on its own (module-level parity tests)."""
+    ver = tuple(p._version for p in module.state_dict().values())
+    cache = getattr(module, '_eng_cache', None)
+    if cache is None or cache[0] != ver:
+        from .ops import HipOps
+        dev = next(module.parameters()).device
+        sd = {prefix + k: v for k, v in module.state_dict().items()}
+        packed = pack_weights(sd, cfg.get('fusion', 'A'), dev)
+        eng = Engine(packed, HipOps(), **cfg)
+        object.__setattr__(module, '_eng_cache', (ver, eng))
+        cache = module._eng_cache
+    return cache[1]
+
+
+class TrackingNet(nn.Module):
+    """Reference-compatible tracking network (modules/tracking_net.py:15-193), HIP forward."""
+
+    def __init__(self, seq_len, appear_len=512, appear_skippool=False, appear_fpn=False, score_arch='vgg',
+                 score_fusion_arch='C', appear_arch='vgg', point_arch='v1', point_len=512,
+                 softmax_mode='single', test_mode=0, affinity_op='multiply', dropblock=5, end_arch='v2',
+                 end_mode='avg', without_reflectivity=True, neg_threshold=0, use_dropout=False):
+        super().__init__()
+        if appear_len != 512 or point_len != 512 or point_arch != 'v1' or end_arch != 'v2':
+            raise NotImplementedError('HIP path covers appear_len=point_len=512, point_arch=v1, end_arch=v2 '
+                                      '(all shipped configs); single-modality runs use forward_rows()')
+        if score_arch not in ('branch_cls', 'branch_reg'):
+            raise NotImplementedError("score_arch must be 'branch_cls' or 'branch_reg' (reference builds no w_det otherwise)")
+        if score_fusion_arch not in FUSION_CLASSES:
+            raise ValueError('unknown score_fusion_arch %r' % (score_fusion_arch,))
+        self.seq_len = seq_len
+        self.score_arch = score_arch
+        self.neg_threshold = neg_threshold
+        self.test_mode = test_mode  # read by the host tracker (tracking_model.py:19-22)
+        self.softmax_mode = softmax_mode
+        self.affinity_op = affinity_op
+        self.score_fusion_arch = score_fusion_arch
+        self.end_mode = end_mode
+        self.fusion_module = FUSION_CLASSES[score_fusion_arch](appear_len, point_len, out_channels=point_len)
+        self.appearance = AppearanceNet(appear_arch, appear_len, skippool=appear_skippool, fpn=appear_fpn,
+                                        dropblock=dropblock)
+        self.point_net = PointNet_v1(4 - int(without_reflectivity), out_channels=point_len, use_dropout=use_dropout)
+        self.w_link = affinity_module(
+            point_len, new_end=lambda c: NewEndIndicator_v2(c, kernel_size=5, reduction=4, mode=end_mode),
+            affinity_op=affinity_op)
+        c = point_len
+        self.w_det = nn.Sequential(nn.Conv1d(c, c, 1, 1), nn.BatchNorm1d(c), nn.ReLU(inplace=True),
+                                   nn.Conv1d(c, c // 2, 1, 1), nn.BatchNorm1d(c // 2), nn.ReLU(inplace=True),
+                                   nn.Conv1d(c // 2, 1, 1, 1))
+        self._ops = None       # operator backend (HipOps unless a test injects another)
+        self._engine = None
+        self._engine_key = None
+        self._plans = {}
+
+    # ---- backend / packing ---------------------------------------------------
+    def set_ops(self, ops):
+        """Inject an operator backend (tests use a torch emulation of the C-ABI to
+        check the host logic on CPU; the product default is HipOps)."""
+        self._ops = ops
+        self._engine = None
+
+    def engine(self):
+        """Packed-weight engine; rebuilt after load_state_dict / .to() / .cuda() (call
+        ``invalidate()`` after editing parameters in place)."""
+        if self._engine is None:
+            dev = next(self.parameters()).device
+            if self._ops is None:
+                from .ops import HipOps
+                self._ops = HipOps()  # raises if libmmmot_hip.so is missing: no fallback
+            packed = pack_weights(self.state_dict(), self.score_fusion_arch, dev)
+            self._engine = Engine(packed, self._ops, fusion=self.score_fusion_arch, affinity_op=self.affinity_op,
+                                  softmax_mode=self.softmax_mode, neg_threshold=self.neg_threshold,
+                                  score_arch=self.score_arch, end_mode=self.end_mode)
+            self._plans = {}
+        return self._engine
+
+    def invalidate(self):
+        self._engine = None
+
+    def _apply(self, fn, *a, **k):
+        self._engine = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, state_dict, strict=True, **k):
+        self._engine = None
+        return super().load_state_dict(state_dict, strict=strict, **k)
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError('mmmot_amd.TrackingNet is inference-only (the HIP path is the forward)')
+        return super().train(False)
+
+    def make_plan(self, samples, crop_hw, rows=(0, 1, 2)):
+        """samples: list of (frame_counts, points_split) - see BatchPlan."""
+        dev = next(self.parameters()).device
+        return BatchPlan(samples, crop_hw, dev, rows=rows, use_points=(1 in rows or 2 in rows))
+
+    # ---- batched entry (no reference counterpart: the reference batch is 1) --
+    def forward_batch(self, plan, crops, points):
+        """crops [Lt,3,S,S], points [P,3] (device, concatenated over the plan's samples).
+        Returns per-sample reference-shaped tuples."""
+        if self.training:
+            raise NotImplementedError('inference only')
+        out = self.engine().forward(plan, crops, points)
+        res = []
+        pi = 0
+        nR = plan.nR
+        for b, fc in enumerate(plan.frame_counts):
+            d0, d1 = int(plan.det_off[b]), int(plan.det_off[b + 1])
+            links = []
+            for f in range(len(fc) - 1):
+                _, _, N, _, M = plan.pairs[pi]
+                o = plan.link_off[pi]
+                links.append(out['link'][o:o + nR * N * M].view(nR, N, M))
+                pi += 1
+            res.append((out['det'][:, d0:d1], links, out['new'][:, d0:d1], out['end'][:, d0:d1]))
+        return res
+
+    def trans(self):
+        pn = self.engine().P['pointnet']
+        return [pn['trans1'].unsqueeze(0), pn['trans2'].unsqueeze(0)]
+
+    # ---- reference entry ------------------------------------------------------
+    def forward(self, dets, det_info, dets_split):
+        """Same contract as reference modules/tracking_net.py:165-193 (eval mode):
+        returns (det_scores 3xL, [link_scores 3xNxM ...], new_scores 3xL, end_scores 3xL, trans)."""
+        return self.forward_rows(dets, det_info, dets_split, rows=(0, 1, 2))
+
+    def forward_rows(self, dets, det_info, dets_split, rows=(0, 1, 2)):
+        """Single-modality variant: rows=(0,) image-only skips PointNet+fusion, rows=(1,) LiDAR-only
+        skips VGG+fusion; the returned tensors hold only the requested modality rows."""
+        fc = [int(d.item()) if torch.is_tensor(d) else int(d) for d in dets_split]
+        rows = tuple(rows)
+        need_pts = (1 in rows) or (2 in rows)
+        need_img = (0 in rows) or (2 in rows)
+        ps = None
+        points = None
+        if need_pts:
+            ps_t = det_info['points_split'].reshape(-1)
+            ps = ps_t.detach().to('cpu').numpy().astype(np.int64)  # one D2H copy (reference: 2 .item() per detection)
+            points = det_info['points'].reshape(-1, 3).contiguous()
+        S = int(dets.shape[-1]) if dets is not None else 0
+        key = (tuple(fc), None if ps is None else ps.tobytes(), S, rows)
+        plan = self._plans.get(key)
+        if plan is None:
+            if len(self._plans) > 64:
+                self._plans.clear()
+            dev = points.device if points is not None else dets.device
+            plan = BatchPlan([(fc, ps)], S, dev, rows=rows, use_points=need_pts)
+            self._plans[key] = plan
+        crops = dets.contiguous() if need_img else None
+        det, links, new, end = self.forward_batch(plan, crops, points)[0]
+        trans = self.trans() if need_pts else None
+        return det, links, new, end, trans

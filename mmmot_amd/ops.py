@@ -1,0 +1,135 @@
+"""Python-side operator layer over the C-ABI (include/mmmot_hip.h).
+
+``HipOps`` takes torch CUDA tensors (possibly 2-D row-strided views), extracts
+raw device pointers / leading dimensions and calls libmmmot_hip.so on torch's
+current HIP stream.  torch is used for device memory and streams only - no
+torch operator computes anything on this path.  CPU tensors are rejected:
+there is no fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+A_PLAIN, A_NORM_RELU, A_PAIR = 0, 1, 2
+PAIR_OPS = {'multiply': 0, 'minus_abs': 1, 'minus': 2}
+SOFTMAX_MODES = {'single': 1, 'dual': 2, 'dual_add': 3, 'dual_max': 4}
+FUSION_MODES = {'A': 0, 'B': 1, 'C': 2}
+
+
+def _ptr(t, dtype=torch.float32):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('mmmot_amd HIP ops need device tensors (got %s); there is no CPU fallback' % t.device)
+    if t.dtype != dtype:
+        raise TypeError('expected %s, got %s' % (dtype, t.dtype))
+    return t.data_ptr()
+
+
+def _iptr(t):
+    return _ptr(t, torch.int32)
+
+
+def _ld(t):
+    """Leading dimension of a 2-D row-strided view (unit inner stride)."""
+    if t is None:
+        return 0
+    if t.dim() == 1:
+        return t.shape[0]
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise ValueError('expected a 2-D view with unit inner stride, got shape %s stride %s' % (
+            tuple(t.shape), tuple(t.stride())))
+    return t.stride(0)
+
+
+class HipOps:
+    """The product backend: every method is one C-ABI call."""
+    name = 'hip'
+
+    def __init__(self):
+        self.lib = _lib.load()
+
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    def conv3x3(self, inp, wp, bias, out, L, H, W, Cin, Cout, first, pool):
+        st = self.lib.mmmot_conv3x3_bn_relu(_ptr(inp), _ptr(wp), _ptr(bias), _ptr(out), L, H, W, Cin, Cout,
+                                            int(first), int(pool), self._stream())
+        _lib.check(st, 'mmmot_conv3x3_bn_relu')
+
+    def gemm(self, W, tiles, N, K, X=None, bias=None, dbias=None, rowidx=None, Y=None, part=None,
+             sc=None, sh=None, FA=None, FB=None, pair=None, amode=A_PLAIN, pairop=0, act=ACT_NONE):
+        a = _lib.GemmArgs()
+        a.X, a.ldx = _ptr(X), _ld(X)
+        a.W = _ptr(W)
+        a.bias = _ptr(bias)
+        a.dbias, a.rowidx, a.lddb = _ptr(dbias), _iptr(rowidx), _ld(dbias)
+        a.Y, a.ldy = _ptr(Y), _ld(Y)
+        a.part = _ptr(part)
+        a.sc, a.sh, a.ldsc = _ptr(sc), _ptr(sh), _ld(sc)
+        a.FA, a.FB, a.ldf = _ptr(FA), _ptr(FB), _ld(FA)
+        a.tile_row0, a.tile_nrows, a.tile_group = _iptr(tiles.row0), _iptr(tiles.nrows), _iptr(tiles.group)
+        if pair is not None:
+            a.grp_row0, a.grp_M = _iptr(pair['row0']), _iptr(pair['M'])
+            a.grp_aoff, a.grp_boff = _iptr(pair['aoff']), _iptr(pair['boff'])
+        a.T, a.N, a.K = tiles.T, N, K
+        a.amode, a.pairop, a.act = amode, pairop, act
+        _lib.check(self.lib.mmmot_gemm_rows(ctypes.byref(a), self._stream()), 'mmmot_gemm_rows')
+
+    def gn_finalize(self, part, tiles, C, NG, gamma, beta, eps, sc, sh):
+        """part: [T][2][>=C] view (unit inner stride); statistics of its first C channels."""
+        if part.dim() != 3 or part.stride(2) != 1 or part.stride(0) != 2 * part.stride(1):
+            raise ValueError('part must be a [T][2][C] view of a [T][2][ldp] buffer')
+        st = self.lib.mmmot_gn_finalize(_ptr(part), _iptr(tiles.g_tile0), _iptr(tiles.g_ntiles),
+                                        _iptr(tiles.g_count), tiles.G, part.stride(1), C, NG, _ptr(gamma), _ptr(beta),
+                                        float(eps), _ptr(sc), _ptr(sh), self._stream())
+        _lib.check(st, 'mmmot_gn_finalize')
+
+    def segment_mean(self, X, C, segs, out, sc=None, sh=None, relu=False, use_group=True):
+        st = self.lib.mmmot_segment_mean(_ptr(X), _ld(X), C, _iptr(segs.start), _iptr(segs.count),
+                                         _iptr(segs.stride), _iptr(segs.group) if use_group else None, segs.n,
+                                         _ptr(sc), _ptr(sh), _ld(sc), int(relu), _ptr(out), _ld(out),
+                                         self._stream())
+        _lib.check(st, 'mmmot_segment_mean')
+
+    def rowdot(self, X, K, w, b, tiles, out, sc=None, sh=None, act=ACT_NONE, use_thr=False, thr=0.0, omap=None):
+        st = self.lib.mmmot_rowdot(_ptr(X), _ld(X), K, _ptr(w), float(b), _ptr(sc), _ptr(sh), _ld(sc),
+                                   _iptr(tiles.row0), _iptr(tiles.nrows), _iptr(tiles.group), tiles.T, act,
+                                   int(use_thr), float(thr), _ptr(out), _iptr(omap), self._stream())
+        _lib.check(st, 'mmmot_rowdot')
+
+    def row_layernorm(self, X, C, gamma, beta, eps, relu, Y, R):
+        st = self.lib.mmmot_row_layernorm(_ptr(X), _ld(X), C, _ptr(gamma), _ptr(beta), float(eps), int(relu),
+                                          _ptr(Y), _ld(Y), R, self._stream())
+        _lib.check(st, 'mmmot_row_layernorm')
+
+    def pointnet_layer1(self, X, W, bias, Y, part, tiles):
+        st = self.lib.mmmot_pointnet_layer1(_ptr(X), _ptr(W), _ptr(bias), _ptr(Y), _ptr(part),
+                                            _iptr(tiles.row0), _iptr(tiles.nrows), tiles.T, self._stream())
+        _lib.check(st, 'mmmot_pointnet_layer1')
+
+    def affine_act(self, X, C, sc, sh, tiles, act, Y):
+        st = self.lib.mmmot_affine_act(_ptr(X), _ld(X), C, _ptr(sc), _ptr(sh), _ld(sc), _iptr(tiles.row0),
+                                       _iptr(tiles.nrows), _iptr(tiles.group), tiles.T, act, _ptr(Y), _ld(Y),
+                                       self._stream())
+        _lib.check(st, 'mmmot_affine_act')
+
+    def fusion_combine(self, mode, cat, Y0, Y1, sc0, sh0, sc1, sh1, tiles, F, Lt, C):
+        st = self.lib.mmmot_fusion_combine(mode, _ptr(cat), _ptr(Y0), _ld(Y0), _ptr(Y1), _ld(Y1), _ptr(sc0),
+                                           _ptr(sh0), _ptr(sc1), _ptr(sh1), _ld(sc0), _iptr(tiles.row0),
+                                           _iptr(tiles.nrows), _iptr(tiles.group), tiles.T, _ptr(F), Lt, C,
+                                           self._stream())
+        _lib.check(st, 'mmmot_fusion_combine')
+
+    def softmax_pairs(self, logits, out, row0, gN, gM, G, max_nm, mode):
+        st = self.lib.mmmot_softmax_pairs(_ptr(logits), _ptr(out), _iptr(row0), _iptr(gN), _iptr(gM), G,
+                                          max_nm, mode, self._stream())
+        _lib.check(st, 'mmmot_softmax_pairs')
+
+    def selftest_mfma(self, A, B, C, K):
+        _lib.check(self.lib.mmmot_selftest_mfma(_ptr(A), _ptr(B), _ptr(C), K, self._stream()),
+                   'mmmot_selftest_mfma')

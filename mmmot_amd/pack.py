@@ -1,0 +1,174 @@
+"""Host-side weight packing for the HIP path (done once per load_state_dict).
+
+Everything here is exact algebra on the reference's parameters, carried out in
+fp64 and rounded once to fp32:
+
+* eval-mode BatchNorm folded into the preceding conv
+  (reference modules/vgg.py:74-76, modules/tracking_net.py:92-100);
+* conv weights re-laid out for the implicit-GEMM kernel
+  ([9][Cout][Cin] tap-major; first layer [Cout][32] with k = tap*3 + c);
+* the two PointNet spatial transforms evaluated in closed form and folded into
+  the adjacent 1x1 convs.  STN3d (modules/point_net.py:72-86) ends in
+  GroupNorm(C, C) over a 1 x C tensor: every group holds ONE value, so the
+  normalised value is 0 and the output is the affine bias; hence
+  ``trans = output(relu(fc_bn2.bias)) + I`` independent of the points
+  (torch >= 1.6 refuses that GroupNorm call outright);
+* PointNet_v1.conv1 (1088 -> 512, point_net.py:26-28) split into its per-point
+  64-channel part and its per-detection 1024-channel part;
+* weight matrices that consume the same input stacked along N
+  (fusion C gates + inputs, new_end.conv0 + w_link.conv1.0).
+"""
+import torch
+
+
+def _d(t):
+    return t.detach().to('cpu', torch.float64)
+
+
+def fold_bn(w, b, bn_w, bn_b, mean, var, eps=1e-5):
+    s = _d(bn_w) / torch.sqrt(_d(var) + eps)
+    wf = _d(w) * s.reshape(-1, *([1] * (w.dim() - 1)))
+    bf = (_d(b) - _d(mean)) * s + _d(bn_b)
+    return wf, bf
+
+
+def stn_transform(sd, prefix, k):
+    """Closed-form STN3d output (k x k), fp64."""
+    beta2 = _d(sd[prefix + 'fc_bn2.bias'])
+    out = _d(sd[prefix + 'output.weight']) @ torch.relu(beta2) + _d(sd[prefix + 'output.bias'])
+    return out.reshape(k, k) + _d(sd[prefix + 'idt'])
+
+
+# (sequential index of each conv inside its stage, pool-after flag), per stage;
+# mirrors how appear_net.py:130-157 regroups vgg16_bn.features (the first
+# max-pool does not close a stage).
+VGG_STAGES = [
+    [(0, 3, 64, False), (3, 64, 64, True), (7, 64, 128, False), (10, 128, 128, True)],
+    [(0, 128, 256, False), (3, 256, 256, False), (6, 256, 256, True)],
+    [(0, 256, 512, False), (3, 512, 512, False), (6, 512, 512, True)],
+    [(0, 512, 512, False), (3, 512, 512, False), (6, 512, 512, True)],
+]
+
+
+def pack_weights(sd, fusion, device, eps=1e-5):
+    """sd: reference-keyed state_dict (TrackingNet).  Returns dict of fp32 device tensors."""
+    f32 = lambda t: t.to(torch.float32).contiguous().to(device)
+    P = {}
+
+    # ---- VGG trunk ---------------------------------------------------------
+    if 'appearance.layers.0.0.weight' in sd:
+        convs = []
+        for s, stage in enumerate(VGG_STAGES):
+            for (idx, cin, cout, pool) in stage:
+                p = 'appearance.layers.%d.' % s
+                w, b = fold_bn(sd[p + '%d.weight' % idx], sd[p + '%d.bias' % idx],
+                               sd[p + '%d.weight' % (idx + 1)], sd[p + '%d.bias' % (idx + 1)],
+                               sd[p + '%d.running_mean' % (idx + 1)], sd[p + '%d.running_var' % (idx + 1)], eps)
+                if cin == 3:
+                    # [Cout][3][3][3] (n,c,ky,kx) -> [Cout][k = (ky*3+kx)*3 + c], padded to 32
+                    wk = w.permute(0, 2, 3, 1).reshape(cout, 27)
+                    wp = torch.zeros(cout, 32, dtype=torch.float64)
+                    wp[:, :27] = wk
+                else:
+                    # -> [tap = ky*3+kx][Cout][Cin]
+                    wp = w.permute(2, 3, 0, 1).reshape(9, cout, cin)
+                convs.append(dict(wp=f32(wp), bias=f32(b), cin=cin, cout=cout, pool=pool, stage=s,
+                                  last=(idx == stage[-1][0])))
+        P['vgg'] = convs
+        heads = []
+        for s in range(4):
+            p = 'appearance.global_pool.%d.fc.' % s
+            heads.append(dict(
+                g0=f32(_d(sd[p + '0.weight'])), b0=f32(_d(sd[p + '0.bias'])),
+                w1=f32(_d(sd[p + '1.weight']).flatten(1)), c1=f32(_d(sd[p + '1.bias'])),
+                g2=f32(_d(sd[p + '2.weight'])), b2=f32(_d(sd[p + '2.bias'])),
+                w4=f32(_d(sd[p + '4.weight']).flatten(1)), c4=f32(_d(sd[p + '4.bias'])),
+                g5=f32(_d(sd[p + '5.weight'])), b5=f32(_d(sd[p + '5.bias'])),
+            ))
+        P['skippool'] = heads
+
+    # ---- PointNet ----------------------------------------------------------
+    if 'point_net.feat.conv1.weight' in sd:
+        q = 'point_net.feat.'
+        T1 = stn_transform(sd, q + 'stn1.', 3)
+        T2 = stn_transform(sd, q + 'stn2.', 64)
+        cw = lambda name: _d(sd[name]).flatten(1)
+        pn = dict(trans1=f32(T1), trans2=f32(T2))
+        pn['w1'] = f32(cw(q + 'conv1.weight') @ T1.t())          # [64][3]
+        pn['b1'] = f32(_d(sd[q + 'conv1.bias']))
+        pn['w2'] = f32(cw(q + 'conv2.weight') @ T2.t())          # [64][64] acts on relu(gn1(.))
+        pn['b2'] = f32(_d(sd[q + 'conv2.bias']))
+        for i in (3, 4, 5):
+            pn['w%d' % i] = f32(cw(q + 'conv%d.weight' % i))
+            pn['b%d' % i] = f32(_d(sd[q + 'conv%d.bias' % i]))
+        for i in (1, 2, 3, 4, 5):
+            pn['g%d' % i] = f32(_d(sd[q + 'bn%d.weight' % i]))
+            pn['be%d' % i] = f32(_d(sd[q + 'bn%d.bias' % i]))
+        wc1 = cw('point_net.conv1.weight')                        # [512][1088]
+        pn['wc1a'] = f32(wc1[:, :64] @ T2.t())                    # per-point part (on relu(gn1(.)))
+        pn['wc1b'] = f32(wc1[:, 64:])                             # per-detection part [512][1024]
+        pn['bc1'] = f32(_d(sd['point_net.conv1.bias']))
+        pn['gc1'] = f32(_d(sd['point_net.bn1.weight']))
+        pn['bec1'] = f32(_d(sd['point_net.bn1.bias']))
+        pn['wc2'] = f32(cw('point_net.conv2.weight'))
+        pn['bc2'] = f32(_d(sd['point_net.conv2.bias']))
+        pn['gc2'] = f32(_d(sd['point_net.bn2.weight']))
+        pn['bec2'] = f32(_d(sd['point_net.bn2.bias']))
+        P['pointnet'] = pn
+
+    # ---- fusion ------------------------------------------------------------
+    fm = 'fusion_module.'
+    C = 512
+    fu = dict(mode=fusion)
+    cw = lambda name: _d(sd[name]).flatten(1)
+    if fusion == 'A' and fm + 'input_w.0.weight' in sd:
+        fu['w0'] = f32(cw(fm + 'input_w.0.weight'))              # [512][1024]
+        fu['b0'] = f32(_d(sd[fm + 'input_w.0.bias']))
+        fu['g0'] = f32(_d(sd[fm + 'input_w.1.weight']))
+        fu['be0'] = f32(_d(sd[fm + 'input_w.1.bias']))
+    elif fusion == 'B' and fm + 'input_p.0.weight' in sd:
+        # NB reference naming trap: *_p is applied to feats[:1] = IMAGE
+        for j, nm in enumerate(('input_p', 'input_i')):
+            fu['w%d' % j] = f32(cw(fm + nm + '.0.weight'))
+            fu['b%d' % j] = f32(_d(sd[fm + nm + '.0.bias']))
+            fu['g%d' % j] = f32(_d(sd[fm + nm + '.1.weight']))
+            fu['be%d' % j] = f32(_d(sd[fm + nm + '.1.bias']))
+    elif fusion == 'C' and fm + 'gate_p.0.weight' in sd:
+        for j, (gn, inn) in enumerate((('gate_p', 'input_p'), ('gate_i', 'input_i'))):
+            fu['w%d' % j] = f32(torch.cat([cw(fm + gn + '.0.weight'), cw(fm + inn + '.0.weight')], 0))  # [1024][512]
+            fu['b%d' % j] = f32(torch.cat([_d(sd[fm + gn + '.0.bias']), _d(sd[fm + inn + '.0.bias'])], 0))
+            one, zero = torch.ones(C, dtype=torch.float64), torch.zeros(C, dtype=torch.float64)
+            fu['g%d' % j] = f32(torch.cat([one, _d(sd[fm + inn + '.1.weight'])], 0))
+            fu['be%d' % j] = f32(torch.cat([zero, _d(sd[fm + inn + '.1.bias'])], 0))
+    P['fusion'] = fu
+
+    # ---- w_det (BatchNorm1d folded) ---------------------------------------
+    if 'w_det.0.weight' in sd:
+        w0, b0 = fold_bn(sd['w_det.0.weight'], sd['w_det.0.bias'], sd['w_det.1.weight'], sd['w_det.1.bias'],
+                         sd['w_det.1.running_mean'], sd['w_det.1.running_var'], eps)
+        w3, b3 = fold_bn(sd['w_det.3.weight'], sd['w_det.3.bias'], sd['w_det.4.weight'], sd['w_det.4.bias'],
+                         sd['w_det.4.running_mean'], sd['w_det.4.running_var'], eps)
+        P['w_det'] = dict(w0=f32(w0.flatten(1)), b0=f32(b0), w3=f32(w3.flatten(1)), b3=f32(b3),
+                          w6=f32(_d(sd['w_det.6.weight']).reshape(-1)), b6=float(sd['w_det.6.bias'].item()))
+
+    # ---- w_link (affinity + new/end) --------------------------------------
+    if 'w_link.conv1.0.weight' in sd:
+        wl = 'w_link.'
+        ne = wl + 'w_new_end.'
+        lk = {}
+        lk['wa'] = f32(torch.cat([cw(ne + 'conv0.0.weight'), cw(wl + 'conv1.0.weight')], 0))   # [1024][512]
+        lk['ba'] = f32(torch.cat([_d(sd[ne + 'conv0.0.bias']), _d(sd[wl + 'conv1.0.bias'])], 0))
+        lk['g_ne0'] = f32(_d(sd[ne + 'conv0.1.weight'])); lk['be_ne0'] = f32(_d(sd[ne + 'conv0.1.bias']))
+        lk['g1'] = f32(_d(sd[wl + 'conv1.1.weight'])); lk['be1'] = f32(_d(sd[wl + 'conv1.1.bias']))
+        lk['w3'] = f32(cw(wl + 'conv1.3.weight')); lk['b3'] = f32(_d(sd[wl + 'conv1.3.bias']))
+        lk['g4'] = f32(_d(sd[wl + 'conv1.4.weight'])); lk['be4'] = f32(_d(sd[wl + 'conv1.4.bias']))
+        lk['w6'] = f32(cw(wl + 'conv1.6.weight')); lk['b6'] = f32(_d(sd[wl + 'conv1.6.bias']))
+        lk['g7'] = f32(_d(sd[wl + 'conv1.7.weight'])); lk['be7'] = f32(_d(sd[wl + 'conv1.7.bias']))
+        lk['w9'] = f32(_d(sd[wl + 'conv1.9.weight']).reshape(-1)); lk['b9'] = float(sd[wl + 'conv1.9.bias'].item())
+        lk['nw0'] = f32(cw(ne + 'conv1.0.weight')); lk['nb0'] = f32(_d(sd[ne + 'conv1.0.bias']))
+        lk['ng1'] = f32(_d(sd[ne + 'conv1.1.weight'])); lk['nbe1'] = f32(_d(sd[ne + 'conv1.1.bias']))
+        lk['nw3'] = f32(cw(ne + 'conv1.3.weight')); lk['nb3'] = f32(_d(sd[ne + 'conv1.3.bias']))
+        lk['ng4'] = f32(_d(sd[ne + 'conv1.4.weight'])); lk['nbe4'] = f32(_d(sd[ne + 'conv1.4.bias']))
+        lk['nw6'] = f32(_d(sd[ne + 'conv1.6.weight']).reshape(-1)); lk['nb6'] = float(sd[ne + 'conv1.6.bias'].item())
+        P['w_link'] = lk
+    return P

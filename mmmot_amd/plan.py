@@ -1,0 +1,174 @@
+"""Batch plan: every integer table the device kernels need for one batch of
+frame samples, built once on the host (numpy) and uploaded.
+
+A *sample* is what the reference calls one dataset item: the detections of
+``sample_max_len`` consecutive frames (always 2 in the shipped configs,
+reference experiments/*/config.yaml:23) with their crops and LiDAR points.
+The reference processes exactly one sample per forward (batch_size 1,
+eval_seq.py:153); the plan generalises to B independent samples per launch:
+normalisation statistics never cross samples (SURVEY 8a GN note), so each
+sample is a *group* in the row-tile tables.
+
+Row spaces (all "position-major", channels contiguous):
+  points  P_t rows   group = sample                 (PointNet shared MLP)
+  dets    L_t rows   group = sample                 (fusion, PointNet head)
+  F       nR*L_t     no groups                      (w_det; nR modality rows)
+  pairs   sum nR*N*M group = (assoc pair, row)      (affinity N x M blocks)
+  V       sum nR*(M+N) group = (pair, row, new|end) (new/end heads)
+"""
+import numpy as np
+import torch
+
+TILE = 128
+
+
+class RowTiles:
+    """Tiles of <=128 rows over contiguous groups of rows."""
+
+    def __init__(self, counts, device):
+        counts = [int(c) for c in counts]
+        row0, nrows, group, g_tile0, g_ntiles, g_row0 = [], [], [], [], [], []
+        r = 0
+        for g, c in enumerate(counts):
+            g_tile0.append(len(row0))
+            g_row0.append(r)
+            nt = (c + TILE - 1) // TILE
+            for t in range(nt):
+                row0.append(r + t * TILE)
+                nrows.append(min(TILE, c - t * TILE))
+                group.append(g)
+            g_ntiles.append(nt)
+            r += c
+        self.R = r
+        self.T = len(row0)
+        self.G = len(counts)
+        self.h_row0 = np.asarray(row0, np.int32)
+        self.h_nrows = np.asarray(nrows, np.int32)
+        self.h_group = np.asarray(group, np.int32)
+        self.h_g_tile0 = np.asarray(g_tile0, np.int32)
+        self.h_g_ntiles = np.asarray(g_ntiles, np.int32)
+        self.h_g_count = np.asarray(counts, np.int32)
+        self.h_g_row0 = np.asarray(g_row0, np.int32)
+        up = lambda a: torch.from_numpy(a).to(device)
+        self.row0, self.nrows, self.group = up(self.h_row0), up(self.h_nrows), up(self.h_group)
+        self.g_tile0, self.g_ntiles = up(self.h_g_tile0), up(self.h_g_ntiles)
+        self.g_count, self.g_row0 = up(self.h_g_count), up(self.h_g_row0)
+
+
+class Segments:
+    def __init__(self, start, count, stride, group, device):
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
+        self.n = len(start)
+        self.h_start, self.h_count = np.asarray(start, np.int64), np.asarray(count, np.int64)
+        self.h_stride, self.h_group = np.asarray(stride, np.int64), np.asarray(group, np.int64)
+        self.start, self.count, self.stride, self.group = up(start), up(count), up(stride), up(group)
+
+
+class BatchPlan:
+    """samples: list of (frame_counts, points_split) with frame_counts a list of
+    per-frame detection counts and points_split the sample-local cumulative point
+    offsets (L_b + 1 integers, first 0) - the reference's ``dets_split`` /
+    ``det_info['points_split']`` (dataset/test_seq_dataset.py:224-244)."""
+
+    def __init__(self, samples, crop_hw, device, rows=(0, 1, 2), use_points=True, use_images=True):
+        self.device = device
+        self.rows = tuple(rows)
+        self.nR = nR = len(self.rows)
+        self.S = int(crop_hw)
+        self.B = len(samples)
+        frame_counts = []
+        L = []
+        for fc, _ in samples:
+            fc = [int(x) for x in fc]
+            if len(fc) < 2 or min(fc) < 1:
+                raise ValueError('every sample needs >= 2 frames with >= 1 detection each, got %r' % (fc,))
+            frame_counts.append(fc)
+            L.append(sum(fc))
+        self.frame_counts = frame_counts
+        self.L = L
+        self.det_off = np.concatenate([[0], np.cumsum(L)]).astype(np.int64)
+        self.Lt = Lt = int(self.det_off[-1])
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
+
+        # ---- point space -------------------------------------------------
+        self.use_points = use_points
+        if use_points:
+            gsplit = [0]
+            P_b = []
+            for b, (_, ps) in enumerate(samples):
+                ps = np.asarray(ps).astype(np.int64).reshape(-1)
+                if ps.shape[0] != L[b] + 1 or ps[0] != 0:
+                    raise ValueError('points_split of sample %d must have L+1=%d entries starting at 0' % (b, L[b] + 1))
+                cnt = np.diff(ps)
+                if (cnt < 1).any():
+                    raise ValueError('every detection needs >= 1 point (reference pads empty boxes with one '
+                                     'zero point, point_cloud/preprocess.py:80-81)')
+                base = gsplit[-1]
+                gsplit.extend((base + ps[1:]).tolist())
+                P_b.append(int(ps[-1]))
+            self.pt_split = np.asarray(gsplit, np.int64)
+            self.P = int(self.pt_split[-1])
+            if self.P >= 2 ** 31 - TILE:
+                raise ValueError('too many points for int32 row indices')
+            self.P_b = P_b
+            self.pt_tiles = RowTiles(P_b, device)
+            cnts = np.diff(self.pt_split)
+            self.row_det = up(np.repeat(np.arange(Lt, dtype=np.int64), cnts))
+            det_sample = np.repeat(np.arange(self.B), L)
+            self.det_segs = Segments(self.pt_split[:-1], cnts, np.ones(Lt), det_sample, device)
+
+        # ---- detection spaces -------------------------------------------
+        self.det_tiles = RowTiles(L, device)
+        self.F_tiles = RowTiles([nR * Lt], device)
+        self.crop_segs = {}  # (h*w) -> Segments over crops, built lazily
+
+        # ---- association pairs ------------------------------------------
+        pairs = []  # (sample, a_det0, N, b_det0, M)
+        for b, fc in enumerate(frame_counts):
+            d0 = int(self.det_off[b])
+            for f in range(len(fc) - 1):
+                pairs.append((b, d0, fc[f], d0 + fc[f], fc[f + 1]))
+                d0 += fc[f]
+        self.pairs = pairs
+        g_N, g_M, g_aoff, g_boff, g_cnt = [], [], [], [], []
+        for (b, a0, N, b0, M) in pairs:
+            for ri in range(nR):
+                g_N.append(N); g_M.append(M)
+                g_aoff.append(ri * Lt + a0); g_boff.append(ri * Lt + b0)
+                g_cnt.append(N * M)
+        self.pair_tiles = RowTiles(g_cnt, device)
+        if self.pair_tiles.R >= 2 ** 31 - TILE:
+            raise ValueError('too many detection pairs for int32 row indices')
+        self.pg_N, self.pg_M = up(g_N), up(g_M)
+        self.pg_aoff, self.pg_boff = up(g_aoff), up(g_boff)
+        self.h_pg_N, self.h_pg_M = np.asarray(g_N), np.asarray(g_M)
+        self.h_pg_aoff, self.h_pg_boff = np.asarray(g_aoff), np.asarray(g_boff)
+        self.max_nm = int(max(n + m for n, m in zip(g_N, g_M)))
+        self.link_off = [int(self.pair_tiles.h_g_row0[p * nR]) for p in range(len(pairs))]
+
+        # ---- new / end vectors ------------------------------------------
+        v_cnt, s_start, s_count, s_stride, s_group, omap = [], [], [], [], [], []
+        for p, (b, a0, N, b0, M) in enumerate(pairs):
+            for ri in range(nR):
+                g = p * nR + ri
+                r0 = int(self.pair_tiles.h_g_row0[g])
+                # "new": mean over previous-frame index i, one row per current detection j
+                v_cnt.append(M)
+                for j in range(M):
+                    s_start.append(r0 + j); s_count.append(N); s_stride.append(M); s_group.append(g)
+                    omap.append(0 * nR * Lt + ri * Lt + b0 + j)
+                # "end": mean over current-frame index j, one row per previous detection i
+                v_cnt.append(N)
+                for i in range(N):
+                    s_start.append(r0 + i * M); s_count.append(M); s_stride.append(1); s_group.append(g)
+                    omap.append(1 * nR * Lt + ri * Lt + a0 + i)
+        self.v_tiles = RowTiles(v_cnt, device)
+        self.v_segs = Segments(s_start, s_count, s_stride, s_group, device)
+        self.v_omap = up(omap)
+
+    def crop_segments(self, hw):
+        """Segments 'all pixels of one crop' for the global average pool."""
+        if hw not in self.crop_segs:
+            Lt = self.Lt
+            self.crop_segs[hw] = Segments(np.arange(Lt) * hw, np.full(Lt, hw), np.ones(Lt), np.zeros(Lt), self.device)
+        return self.crop_segs[hw]

@@ -1,0 +1,229 @@
+"""ORACLE - test infrastructure, not product code.
+
+CPU (PyTorch fp32) restatement of the reference's per-frame-pair network
+forward, ``TrackingNet.forward`` in eval mode (reference
+modules/tracking_net.py:165-193).  Only ``tests/``, ``__graft_entry__.smoke()``
+and ``bench.py``'s ``cpu_baseline`` leg may import this file; the product
+(``mmmot_amd``) never does.
+
+Pinning: the reference ships no tests / golden vectors for this path (SURVEY
+section 4), so the oracle is pinned against the REAL reference imported in the
+build container: ``oracle/gen_golden.py`` loads the same generated weights into
+``/root/reference/modules.TrackingNet`` and into this restatement, asserts
+agreement (<= 2e-5 on every output) and writes the reference's outputs to
+``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` re-checks this file
+against those fixtures wherever the repo runs.
+
+It is written functionally over a reference-keyed ``state_dict`` - one
+function per reference function, each citing the lines it follows.  Layout is
+the reference's own (N,C,L / N,C,H,W), deliberately different from the HIP
+path's position-major layout so that the two share no code.
+"""
+import torch
+import torch.nn.functional as F
+
+EPS = 1e-5
+
+
+def _gn(x, sd, key, groups):
+    return F.group_norm(x, groups, sd[key + '.weight'], sd[key + '.bias'], EPS)
+
+
+def vgg_stage(x, sd, stage):
+    """One regrouped VGG16-BN stage: reference modules/appear_net.py:130-157 (regrouping),
+    modules/vgg.py:67-80 (conv3x3 pad1 -> BatchNorm2d(eval) -> ReLU, 'M' = MaxPool 2x2)."""
+    layout = {0: [64, 64, 'M', 128, 128, 'M'], 1: [256, 256, 256, 'M'], 2: [512, 512, 512, 'M'],
+              3: [512, 512, 512, 'M']}[stage]
+    p = 'appearance.layers.%d.' % stage
+    idx = 0
+    for v in layout:
+        if v == 'M':
+            x = F.max_pool2d(x, 2, 2)
+            idx += 1
+        else:
+            x = F.conv2d(x, sd[p + '%d.weight' % idx], sd[p + '%d.bias' % idx], padding=1)
+            b = p + '%d.' % (idx + 1)
+            x = F.batch_norm(x, sd[b + 'running_mean'], sd[b + 'running_var'], sd[b + 'weight'], sd[b + 'bias'],
+                             False, 0.0, EPS)
+            x = F.relu(x)
+            idx += 3
+    return x
+
+
+def skippool(x, sd, stage):
+    """reference modules/appear_net.py:9-32: global avg pool -> GN(1) -> 1x1 -> GN(1) -> ReLU -> 1x1 -> GN(1) -> ReLU."""
+    p = 'appearance.global_pool.%d.fc.' % stage
+    o = F.adaptive_avg_pool2d(x, 1)
+    o = _gn(o, sd, p + '0', 1)
+    o = F.conv2d(o, sd[p + '1.weight'], sd[p + '1.bias'])
+    o = F.relu(_gn(o, sd, p + '2', 1))
+    o = F.conv2d(o, sd[p + '4.weight'], sd[p + '4.bias'])
+    o = F.relu(_gn(o, sd, p + '5', 1))
+    return o.flatten(1)
+
+
+def appearance(crops, sd, keep=None):
+    """reference modules/appear_net.py:166-190 (vgg + skippool path): L x 3 x S x S -> L x 512."""
+    outs = []
+    x = crops
+    for s in range(4):
+        x = vgg_stage(x, sd, s)
+        if keep is not None:
+            keep['vgg_stage%d' % s] = x
+        outs.append(skippool(x, sd, s))
+    return torch.cat(outs, dim=-1)
+
+
+def stn_transform(sd, prefix, k):
+    """reference modules/point_net.py:72-86.  fc_bn1 / fc_bn2 are GroupNorm(C, C) applied to a 1 x C
+    tensor: one value per group, so the normalised value is exactly 0 and the layer returns its
+    bias; the conv trunk and the global max therefore never reach the output:
+        trans = output(relu(fc_bn2.bias)) + I
+    (verified against the imported reference in oracle/gen_golden.py)."""
+    h = F.relu(sd[prefix + 'fc_bn2.bias'])
+    t = F.linear(h, sd[prefix + 'output.weight'], sd[prefix + 'output.bias'])
+    return t.view(1, k, k) + sd[prefix + 'idt']
+
+
+def _segment_avg(x, split):
+    """per-detection average over point ranges: reference modules/point_net.py:32-39 / 139-146."""
+    cols = [x[:, :, int(split[i]):int(split[i + 1])].mean(dim=-1, keepdim=True) for i in range(len(split) - 1)]
+    return torch.cat(cols, dim=-1)
+
+
+def pointnet(points, split, sd, keep=None):
+    """reference modules/point_net.py:25-44 + 115-153.  points 1 x 3 x P, split (L+1,) -> L x 512, trans."""
+    q = 'point_net.feat.'
+    t1 = stn_transform(sd, q + 'stn1.', 3)
+    x = torch.bmm(points.transpose(2, 1), t1).transpose(2, 1)                       # :119-123
+    x = F.relu(_gn(F.conv1d(x, sd[q + 'conv1.weight'], sd[q + 'conv1.bias']), sd, q + 'bn1', 64))  # :125
+    t2 = stn_transform(sd, q + 'stn2.', 64)
+    x = torch.bmm(x.transpose(2, 1), t2).transpose(2, 1)                            # :127-131
+    skip = x                                                                         # :132
+    for i, g in ((2, 64), (3, 64), (4, 128), (5, 1024)):                             # :134-138
+        x = F.relu(_gn(F.conv1d(x, sd[q + 'conv%d.weight' % i], sd[q + 'conv%d.bias' % i]), sd, q + 'bn%d' % i, g))
+    avg = _segment_avg(x, split)                                                     # 1 x 1024 x L  (:139-146)
+    if keep is not None:
+        keep['pn_seg1024'] = avg[0].t()
+    counts = (split[1:] - split[:-1]).long()
+    rep = torch.repeat_interleave(avg, counts, dim=-1)                               # broadcast back to points (:145)
+    x = torch.cat([skip, rep], dim=1)                                                # 1088 ch (point_net.py:26-27)
+    x = F.relu(_gn(F.conv1d(x, sd['point_net.conv1.weight'], sd['point_net.conv1.bias']), sd, 'point_net.bn1', 512))
+    x = _segment_avg(x, split)                                                       # :32-39
+    x = F.relu(_gn(F.conv1d(x, sd['point_net.conv2.weight'], sd['point_net.conv2.bias']), sd, 'point_net.bn2', 16))
+    return x[0].t(), [t1, t2]
+
+
+def fusion(feats, sd, mode):
+    """reference modules/fusion_net.py:31-42 (C), 62-70 (B), 85-92 (A).  feats 1 x 1024 x L -> 3 x 512 x L."""
+    p = 'fusion_module.'
+    two = feats.view(2, -1, feats.size(-1))
+    img, pts = two[:1], two[1:]  # feats[0] = image features; the *_p parameters act on them (naming trap)
+    lin = lambda x, name: _gn(F.conv1d(x, sd[p + name + '.0.weight'], sd[p + name + '.0.bias']), sd, p + name + '.1', 512)
+    if mode == 'A':
+        fused = lin(feats, 'input_w')
+    elif mode == 'B':
+        fused = lin(img, 'input_p') + lin(pts, 'input_i')
+    else:
+        gp = torch.sigmoid(F.conv1d(img, sd[p + 'gate_p.0.weight'], sd[p + 'gate_p.0.bias']))
+        gi = torch.sigmoid(F.conv1d(pts, sd[p + 'gate_i.0.weight'], sd[p + 'gate_i.0.bias']))
+        fused = (gp * lin(img, 'input_p') + gi * lin(pts, 'input_i')) / (gp + gi)
+    return torch.cat([two, fused], dim=0)
+
+
+def det_head(feats, sd, score_arch, neg_threshold):
+    """reference modules/tracking_net.py:91-100 (w_det) + 149-163 (eval branch)."""
+    x = feats
+    for i, bn in ((0, 1), (3, 4)):
+        x = F.conv1d(x, sd['w_det.%d.weight' % i], sd['w_det.%d.bias' % i])
+        b = 'w_det.%d.' % bn
+        x = F.relu(F.batch_norm(x, sd[b + 'running_mean'], sd[b + 'running_var'], sd[b + 'weight'], sd[b + 'bias'],
+                                False, 0.0, EPS))
+    s = F.conv1d(x, sd['w_det.6.weight'], sd['w_det.6.bias']).squeeze(1)
+    if 'cls' in score_arch:
+        s = torch.sigmoid(s)
+    return s - (s < neg_threshold).float()
+
+
+def pairwise(a, b, op):
+    """reference modules/gcn.py:6-14 / 17-28 / 31-41: R x C x N , R x C x M -> R x C x N x M."""
+    if op == 'multiply':
+        return a.unsqueeze(-1) * b.unsqueeze(-2)
+    d = (a.unsqueeze(-1) - b.unsqueeze(-2)) / 2
+    return d.abs() if op == 'minus_abs' else d
+
+
+def new_end(x, sd, keep=None):
+    """reference modules/new_end.py:62-82 (v2, mode 'avg')."""
+    p = 'w_link.w_new_end.'
+    x = F.relu(_gn(F.conv2d(x, sd[p + 'conv0.0.weight'], sd[p + 'conv0.0.bias']), sd, p + 'conv0.1', 1))
+    new_vec, end_vec = x.mean(dim=-2), x.mean(dim=-1)
+
+    def head(v):
+        v = F.relu(_gn(F.conv1d(v, sd[p + 'conv1.0.weight'], sd[p + 'conv1.0.bias']), sd, p + 'conv1.1', 1))
+        v = F.relu(_gn(F.conv1d(v, sd[p + 'conv1.3.weight'], sd[p + 'conv1.3.bias']), sd, p + 'conv1.4', 1))
+        return torch.sigmoid(F.conv1d(v, sd[p + 'conv1.6.weight'], sd[p + 'conv1.6.bias'])).squeeze(1)
+
+    if keep is not None:
+        keep['new_vec'], keep['end_vec'] = new_vec, end_vec
+    return head(new_vec), head(end_vec)
+
+
+def affinity(a, b, sd, op, keep=None):
+    """reference modules/gcn.py:68-82: link logits R x 1 x N x M, new R x M, end R x N."""
+    x = pairwise(a, b, op)
+    new, end = new_end(x, sd, keep)
+    p = 'w_link.conv1.'
+    for i, g in ((0, 512), (3, 512), (6, 128)):
+        x = F.relu(_gn(F.conv2d(x, sd[p + '%d.weight' % i], sd[p + '%d.bias' % i]), sd, p + '%d' % (i + 1), g))
+    x = F.conv2d(x, sd[p + '9.weight'], sd[p + '9.bias'])
+    return x, new, end
+
+
+def softmax_mode(link, mode):
+    """reference modules/tracking_net.py:106-126."""
+    if mode == 'single':
+        return F.softmax(link, dim=-1)
+    if mode in ('dual', 'dual_add', 'dual_max'):
+        p, q = F.softmax(link, dim=-1), F.softmax(link, dim=-2)
+        return p * q if mode == 'dual' else (p + q) / 2 if mode == 'dual_add' else torch.max(p, q)
+    return link
+
+
+def tracking_forward(sd, cfg, dets, points, points_split, dets_split, keep=None, rows=(0, 1, 2)):
+    """Eval-mode ``TrackingNet.forward`` (reference modules/tracking_net.py:128-193).
+
+    sd: reference-keyed state_dict (fp32 CPU); cfg: dict(fusion, affinity_op, softmax_mode,
+    neg_threshold, score_arch); dets L x 3 x S x S; points 1 x P x 3; points_split (L+1,);
+    dets_split list of frame counts.  rows != (0,1,2) evaluates single-modality rows only
+    (rows are independent: SURVEY 8a), skipping the unused encoder."""
+    rows = tuple(rows)
+    trans = None
+    feats = {}
+    if 0 in rows or 2 in rows:
+        feats[0] = appearance(dets, sd, keep)                                   # :131-133
+    if 1 in rows or 2 in rows:
+        split = points_split.reshape(-1).long()
+        feats[1], trans = pointnet(points.transpose(-1, -2), split, sd, keep)    # :136-140
+    if rows == (0, 1, 2):
+        cat = torch.cat([feats[0], feats[1]], dim=-1).t().unsqueeze(0)           # :142
+        F3 = fusion(cat, sd, cfg['fusion'])                                      # :143-145
+    else:
+        F3 = torch.stack([feats[r].t() for r in rows], dim=0)
+    if keep is not None:
+        keep['F'] = F3
+    det = det_head(F3, sd, cfg.get('score_arch', 'branch_cls'), cfg['neg_threshold'])  # :167
+    counts = [int(c) for c in dets_split]
+    links, news, ends = [], [], []
+    start = 0
+    for i in range(len(counts) - 1):                                             # :173-181
+        mid, stop = start + counts[i], start + counts[i] + counts[i + 1]
+        logit, new, end = affinity(F3[:, :, start:mid], F3[:, :, mid:stop], sd, cfg['affinity_op'], keep)
+        links.append(softmax_mode(logit, cfg['softmax_mode']).squeeze(1))
+        news.append(new)
+        ends.append(end)
+        start = mid
+    R = F3.size(0)
+    new = torch.cat([F3.new_zeros(R, counts[0])] + news, dim=1)                  # :183-189 (eval padding)
+    end = torch.cat(ends + [F3.new_zeros(R, counts[-1])], dim=1)
+    return det, links, new, end, trans

@@ -1,0 +1,169 @@
+"""TEST-ONLY torch emulation of the C-ABI operator semantics (include/mmmot_hip.h).
+
+Purpose: the GPU-less (``-m "not gpu"``) suite uses it to validate the HOST
+logic - weight packing / BN + STN folding, the batch plan's integer tables and
+the engine's launch schedule - against the golden vectors, so that a failure
+on the GPU box isolates to the HIP kernels.  It lives under tests/, is injected
+explicitly with ``TrackingNet.set_ops`` and is unreachable from the product
+path (``mmmot_amd`` never imports tests; HipOps rejects CPU tensors).
+
+Each method documents the contract of one entry point in executable form; the
+per-kernel GPU tests compare the HIP kernels against these same functions.
+"""
+import torch
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+
+
+def _act(v, act):
+    if act == ACT_RELU:
+        return torch.relu(v)
+    if act == ACT_SIGMOID:
+        return torch.sigmoid(v)
+    return v
+
+
+def _rows_groups(tiles):
+    """row -> group for every row covered by the tile table."""
+    g = torch.empty(tiles.R, dtype=torch.long)
+    for t in range(tiles.T):
+        r0, n = int(tiles.h_row0[t]), int(tiles.h_nrows[t])
+        g[r0:r0 + n] = int(tiles.h_group[t])
+    return g
+
+
+class TorchOps:
+    name = 'torch-emulation'
+
+    def __init__(self, dtype=torch.float32):
+        self.dtype = dtype
+
+    def conv3x3(self, inp, wp, bias, out, L, H, W, Cin, Cout, first, pool):
+        if first:
+            x = inp.view(L, 3, H, W)
+            w = wp[:, :27].view(Cout, 3, 3, 3).permute(0, 3, 1, 2)  # [n][ky][kx][c] -> [n][c][ky][kx]
+        else:
+            x = inp.view(L, H, W, Cin).permute(0, 3, 1, 2)
+            w = wp.view(3, 3, Cout, Cin).permute(2, 3, 0, 1)
+        y = torch.relu(torch.nn.functional.conv2d(x.to(self.dtype), w.to(self.dtype), bias.to(self.dtype), padding=1))
+        if pool:
+            y = torch.nn.functional.max_pool2d(y, 2, 2)
+        out.view(L, y.shape[2], y.shape[3], Cout).copy_(y.permute(0, 2, 3, 1).to(out.dtype))
+
+    def gemm(self, W, tiles, N, K, X=None, bias=None, dbias=None, rowidx=None, Y=None, part=None,
+             sc=None, sh=None, FA=None, FB=None, pair=None, amode=0, pairop=0, act=ACT_NONE):
+        R = tiles.R
+        grp = _rows_groups(tiles)
+        if amode == 2:
+            row0, M = pair['row0'].long(), pair['M'].long()
+            r = torch.arange(R)
+            q = r - row0[grp]
+            i, j = q // M[grp], q % M[grp]
+            a = FA[pair['aoff'].long()[grp] + i, :K]
+            b = FB[pair['boff'].long()[grp] + j, :K]
+            A = a * b if pairop == 0 else ((a - b) / 2).abs() if pairop == 1 else (a - b) / 2
+        else:
+            A = X[:R, :K]
+            if amode == 1:
+                A = torch.relu(A * sc[grp, :K] + sh[grp, :K])
+        v = A.to(self.dtype) @ W[:N, :K].to(self.dtype).t()
+        if bias is not None:
+            v = v + bias[:N]
+        if dbias is not None:
+            v = v + dbias[rowidx.long()[:R], :N]
+        if part is not None:
+            for t in range(tiles.T):
+                r0, n = int(tiles.h_row0[t]), int(tiles.h_nrows[t])
+                part[t, 0, :N] = v[r0:r0 + n].sum(0)
+                part[t, 1, :N] = ((v[r0:r0 + n] - part[t, 0, :N] / n) ** 2).sum(0)
+        if Y is not None:
+            Y[:R, :N] = _act(v, act).to(Y.dtype)
+
+    def gn_finalize(self, part, tiles, C, NG, gamma, beta, eps, sc, sh):
+        CG = C // NG
+        for g in range(tiles.G):
+            t0, nt, cnt = int(tiles.h_g_tile0[g]), int(tiles.h_g_ntiles[g]), int(tiles.h_g_count[g])
+            p = part[t0:t0 + nt, :, :C].double()                      # [nt][2][C]: tile sum, tile-centred M2
+            n_t = torch.as_tensor(tiles.h_nrows[t0:t0 + nt]).double().view(nt, 1)
+            s1 = p[:, 0].sum(0).view(NG, CG).sum(1) / (cnt * CG)      # group mean
+            dev = p[:, 0] / n_t - s1.repeat_interleave(CG)            # tile-channel mean minus group mean
+            m2 = (p[:, 1] + n_t * dev * dev).sum(0).view(NG, CG).sum(1)   # Chan et al. parallel combine
+            var = m2 / (cnt * CG)
+            rstd = 1.0 / torch.sqrt(var + eps)
+            scv = gamma.double() * rstd.repeat_interleave(CG)
+            sc[g, :C] = scv.float()
+            sh[g, :C] = (beta.double() - s1.repeat_interleave(CG) * scv).float()
+
+    def segment_mean(self, X, C, segs, out, sc=None, sh=None, relu=False, use_group=True):
+        for s in range(segs.n):
+            st, cnt, stride = int(segs.h_start[s]), int(segs.h_count[s]), int(segs.h_stride[s])
+            rows = X[st:st + (cnt - 1) * stride + 1:stride, :C]
+            if sc is not None:
+                g = int(segs.h_group[s]) if use_group else 0
+                rows = rows * sc[g, :C] + sh[g, :C]
+            if relu:
+                rows = torch.relu(rows)
+            out[s, :C] = rows.mean(0)
+
+    def rowdot(self, X, K, w, b, tiles, out, sc=None, sh=None, act=ACT_NONE, use_thr=False, thr=0.0, omap=None):
+        R = tiles.R
+        A = X[:R, :K]
+        if sc is not None:
+            grp = _rows_groups(tiles)
+            A = torch.relu(A * sc[grp, :K] + sh[grp, :K])
+        s = _act(A @ w[:K] + b, act)
+        if use_thr:
+            s = s - (s < thr).float()
+        if omap is not None:
+            out[omap.long()[:R]] = s
+        else:
+            out[:R] = s
+
+    def row_layernorm(self, X, C, gamma, beta, eps, relu, Y, R):
+        x = X[:R, :C]
+        mu = x.mean(1, keepdim=True)
+        var = ((x - mu) ** 2).mean(1, keepdim=True)
+        y = (x - mu) / torch.sqrt(var + eps) * gamma + beta
+        Y[:R, :C] = torch.relu(y) if relu else y
+
+    def pointnet_layer1(self, X, W, bias, Y, part, tiles):
+        v = X @ W.t() + bias
+        Y[:tiles.R] = v
+        for t in range(tiles.T):
+            r0, n = int(tiles.h_row0[t]), int(tiles.h_nrows[t])
+            part[t, 0, :64] = v[r0:r0 + n].sum(0)
+            part[t, 1, :64] = ((v[r0:r0 + n] - part[t, 0, :64] / n) ** 2).sum(0)
+
+    def affine_act(self, X, C, sc, sh, tiles, act, Y):
+        grp = _rows_groups(tiles)
+        Y[:tiles.R, :C] = _act(X[:tiles.R, :C] * sc[grp, :C] + sh[grp, :C], act)
+
+    def fusion_combine(self, mode, cat, Y0, Y1, sc0, sh0, sc1, sh1, tiles, F, Lt, C):
+        grp = _rows_groups(tiles)
+        F[0] = cat[:, :C]
+        F[1] = cat[:, C:2 * C]
+        n0 = lambda: Y0[:, -C:] * sc0[grp, :C] + sh0[grp, :C]
+        n1 = lambda: Y1[:, -C:] * sc1[grp, :C] + sh1[grp, :C]
+        if mode == 0:
+            F[2] = Y0[:, :C] * sc0[grp, :C] + sh0[grp, :C]
+        elif mode == 1:
+            F[2] = (Y0[:, :C] * sc0[grp, :C] + sh0[grp, :C]) + (Y1[:, :C] * sc1[grp, :C] + sh1[grp, :C])
+        else:
+            g0, g1 = torch.sigmoid(Y0[:, :C]), torch.sigmoid(Y1[:, :C])
+            F[2] = (g0 * n0() + g1 * n1()) / (g0 + g1)
+
+    def softmax_pairs(self, logits, out, row0, gN, gM, G, max_nm, mode):
+        for g in range(G):
+            r0, N, M = int(row0[g]), int(gN[g]), int(gM[g])
+            assert N + M <= max_nm
+            x = logits[r0:r0 + N * M].view(N, M)
+            p = torch.softmax(x, dim=1)
+            if mode == 1:
+                r = p
+            else:
+                q = torch.softmax(x, dim=0)
+                r = p * q if mode == 2 else (p + q) / 2 if mode == 3 else torch.max(p, q)
+            out[r0:r0 + N * M] = r.reshape(-1)
+
+    def selftest_mfma(self, A, B, C, K):
+        C.copy_(A.view(32, K) @ B.view(32, K).t())
