@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""Throughput benchmark of the mmMOT per-frame-pair network forward on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): frame-pairs/sec of the full eval-mode
+``TrackingNet.forward`` at N_det=64, inputs resident in HBM.  Workload = the
+N_det=64 configuration the metric is quoted on, ``configs[2]`` (= SURVEY cfg3):
+Fusion C, N=M=64 (128 crops of 128x128), 2048 LiDAR points per detection.
+One step = one pass of the hot path over one batch of ``--pairs`` synthetic
+frame pairs per GPU.  Multi-GPU: one process per GPU (torch.distributed, RCCL),
+samples sharded, no data-path collective, one flat result gather per step
+(weak scaling: per-GPU work is fixed).
+
+Prints ONE JSON line on rank 0 with the contract fields plus
+  roofline     - the dominant kernel (conv3x3 implicit GEMM, fp32 MFMA), measured
+                 with HIP events around every trunk launch inside the timed region
+  cpu_baseline - the oracle (CPU restatement of the reference) on the host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from mmmot_amd import TrackingNet  # noqa: E402
+from mmmot_amd.dist import gather_results  # noqa: E402
+from mmmot_amd.synth import make_pair  # noqa: E402
+from mmmot_amd.weights import init_module  # noqa: E402
+
+METRIC = 'frame-pairs/sec (fusion+affinity fwd) at N_det=64; affinity L∞ vs CPU ref'
+WORKLOADS = {
+    # name: (fusion, affinity_op, softmax_mode, N, M, S, pts/det)
+    'cfg3': ('C', 'multiply', 'none', 64, 64, 128, 2048),
+    'cfg2': ('A', 'multiply', 'none', 32, 32, 64, 512),
+    'cfg4': ('C', 'minus_abs', 'dual_add', 128, 128, 64, 512),
+    'tiny': ('C', 'multiply', 'none', 6, 5, 32, 40),
+}
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+BASE_KW = dict(seq_len=2, score_arch='branch_cls', appear_arch='vgg', appear_len=512, appear_skippool=True,
+               appear_fpn=False, point_arch='v1', point_len=512, without_reflectivity=True, end_arch='v2',
+               end_mode='avg', test_mode=2, neg_threshold=0.2, dropblock=0, use_dropout=False)
+
+
+def reference_flops_per_pair(N, M, S, P, fusion):
+    """F_ref of SURVEY 8d (reference-as-written FLOPs, 2 x MAC)."""
+    L = N + M
+    f_fus = 524288 if fusion in ('A', 'B') else 1048576
+    return 2 * (L * (305856 * S * S + 204800) + P * 991625 + L * 262144 + 2.36e6 + L * f_fus + 3 * L * 393472 +
+                3 * N * M * 852096 + 3 * L * 327808)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=6)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', default='cfg3', choices=sorted(WORKLOADS))
+    ap.add_argument('--pairs', type=int, default=2, help='frame pairs per step per GPU')
+    ap.add_argument('--cpu-pairs', type=int, default=2, help='timed pairs of the CPU baseline (0 disables)')
+    ap.add_argument('--no-gather', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    fusion, aff, sm, N, M, S, pts = WORKLOADS[args.workload]
+    model = TrackingNet(**dict(BASE_KW, score_fusion_arch=fusion, affinity_op=aff, softmax_mode=sm))
+    init_module(model, seed=0)
+    model.eval().to(dev)
+    eng = model.engine()
+
+    # synthetic batch: distinct seeds per (rank, pair); inputs resident in HBM before timing
+    B = args.pairs
+    ins = [make_pair(N, M, S, pts, seed=1000 + rank * B + i) for i in range(B)]
+    samples = [([N, M], x[1]['points_split'].reshape(-1).long().numpy()) for x in ins]
+    plan = model.make_plan(samples, S)
+    crops = torch.cat([x[0] for x in ins]).to(dev)
+    points = torch.cat([x[1]['points'].reshape(-1, 3) for x in ins]).to(dev)
+    torch.cuda.synchronize()
+
+    def step():
+        res = model.forward_batch(plan, crops, points)
+        if not args.no_gather:
+            res = gather_results(res, same_layout=True)  # trivial for world == 1
+        return res
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    eng.conv_events = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    events, eng.conv_events = eng.conv_events, None
+
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    # ---- roofline of the dominant kernel (rank-local; HIP events on the launch stream) ----
+    per_layer = {}
+    for li, rows, cin, cout, e0, e1 in events:
+        ms = e0.elapsed_time(e1)
+        fl = 2.0 * rows * 9 * cin * cout
+        a = per_layer.setdefault(li, [0.0, 0.0, 0, rows, cin, cout])
+        a[0] += ms
+        a[1] += fl
+        a[2] += 1
+    conv_ms = sum(a[0] for a in per_layer.values())
+    conv_fl = sum(a[1] for a in per_layer.values())
+    n_launch = sum(a[2] for a in per_layer.values())
+    achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+
+    pairs_total = args.steps * B * world
+    value = pairs_total / dt
+    out = {
+        'metric': METRIC, 'value': round(value, 4), 'unit': 'frame-pairs/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': '%s: Fusion %s, %s/%s, N=M=%d (%d crops of %dx%d), %d pts/det; %d pairs/step/GPU' % (
+            args.workload, fusion, aff, sm, N, N + M, S, S, pts, B), 'pairs_per_step_per_gpu': B,
+            'parallelism': 'sample-sharded x%d, flat all_gather of scores' % world},
+        'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_kernel (VGG16-BN trunk, 13 launches/step)',
+                     'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                     'avg_launch_ms': round(conv_ms / max(n_launch, 1), 4),
+                     'trunk_share_of_step': round(conv_ms / (dt * 1e3), 4),
+                     'flops_basis': 'algorithmic 2*9*Cin*Cout per output pixel (conv1_1 counted at Cin=3)'},
+        'end_to_end': {'ref_gflop_per_pair': round(reference_flops_per_pair(N, M, S, (N + M) * pts, fusion) / 1e9, 1),
+                       'ref_tflops_equiv': round(reference_flops_per_pair(N, M, S, (N + M) * pts, fusion) * value / 1e12 / world, 2)},
+    }
+
+    if rank == 0:
+        prof_dir = os.path.join(ROOT, 'gpurun_out')
+        try:
+            os.makedirs(prof_dir, exist_ok=True)
+            with open(os.path.join(prof_dir, 'bench_conv_layers_n%d.json' % world), 'w') as f:
+                json.dump({str(li): dict(ms_per_launch=a[0] / a[2], tflops=a[1] / (a[0] * 1e-3) / 1e12 if a[0] else 0,
+                                         rows=a[3], cin=a[4], cout=a[5]) for li, a in sorted(per_layer.items())}, f, indent=1)
+        except OSError:
+            pass
+
+    # ---- CPU baseline + parity on the same inputs (rank 0, single-GPU runs only) ----
+    if rank == 0 and world == 1 and args.cpu_pairs > 0:
+        from oracle import restatement as R  # checker / baseline only - never on the product path
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        cfg = dict(fusion=fusion, affinity_op=aff, softmax_mode=sm, neg_threshold=BASE_KW['neg_threshold'],
+                   score_arch=BASE_KW['score_arch'])
+        torch.set_num_threads(os.cpu_count())
+        times, linf = [], 0.0
+        with torch.no_grad():
+            for i in range(min(args.cpu_pairs + 1, B + 1)):
+                dets, info, _ = ins[i % B]
+                t1 = time.perf_counter()
+                o = R.tracking_forward(sd, cfg, dets, info['points'], info['points_split'], [N, M])
+                if i > 0:
+                    times.append(time.perf_counter() - t1)
+                det, links, new, end = res[i % B]
+                linf = max(linf, (links[0].cpu() - o[1][0]).abs().max().item(), (det.cpu() - o[0]).abs().max().item(),
+                           (new.cpu() - o[2]).abs().max().item(), (end.cpu() - o[3]).abs().max().item())
+        times.sort()
+        med = times[len(times) // 2]
+        out['cpu_baseline'] = {'value': round(1.0 / med, 4), 'unit': 'frame-pairs/s', 'cores': torch.get_num_threads(),
+                               'kind': 'port',
+                               'sample': '%d pairs of the same workload after 1 warm-up pair, median s/pair %.3f, '
+                                         'torch %s CPU fp32, batch-1 loop like the reference' % (len(times), med, torch.__version__)}
+        out['parity'] = {'linf_vs_cpu_oracle': linf, 'tolerance': 1e-3}
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -36,7 +36,9 @@ class Engine:
         self.neg_threshold = float(neg_threshold)
         self.score_arch = score_arch
         self.ws = {}
-        self.keep = None  # optional dict collecting per-stage tensors (tests)
+        self.dev = None
+        self.keep = None         # optional dict collecting per-stage tensors (tests)
+        self.conv_events = None  # optional list collecting per-launch HIP events (bench.py)
 
     # ---- workspace arena ---------------------------------------------------
     def buf(self, name, *shape, device=None):
@@ -70,7 +72,13 @@ class Engine:
         for li, cv in enumerate(self.P['vgg']):
             Ho, Wo = (H // 2, W // 2) if cv['pool'] else (H, W)
             out = self.buf('vgg%d' % (li & 1), Lt * Ho * Wo, cv['cout'])
+            if self.conv_events is not None:  # bench.py: HIP events around every trunk launch
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             ops.conv3x3(x, cv['wp'], cv['bias'], out, Lt, H, W, cv['cin'], cv['cout'], li == 0, cv['pool'])
+            if self.conv_events is not None:
+                e1.record()
+                self.conv_events.append((li, Lt * H * W, cv['cin'], cv['cout'], e0, e1))
             x, H, W = out, Ho, Wo
             if cv['last']:
                 self._stash('vgg_stage%d' % cv['stage'], x)

@@ -1,0 +1,40 @@
+"""The C-ABI shared library builds for gfx950, loads without a GPU and exports
+every symbol that include/mmmot_hip.h declares (no compute calls here)."""
+import ctypes
+import os
+import re
+
+from mmmot_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'mmmot_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\bint\s+(mmmot_\w+)\s*\(', text)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    path = _lib.build()
+    assert os.path.exists(path)
+    lib = ctypes.CDLL(path)
+    syms = declared_symbols()
+    assert len(syms) >= 13, syms
+    for s in syms:
+        assert hasattr(lib, s), 'symbol %s declared in include/mmmot_hip.h but not exported' % s
+    assert set(syms) == set(_lib.SIGNATURES), (set(syms) ^ set(_lib.SIGNATURES))
+
+
+def test_abi_version_and_argument_checks_without_gpu():
+    lib = _lib.load()
+    assert lib.mmmot_abi_version() == 1
+    # contract violations are rejected before any launch (safe on a GPU-less host)
+    assert lib.mmmot_gemm_rows(None, None) == -1
+    assert lib.mmmot_conv3x3_bn_relu(None, None, None, None, 1, 8, 8, 64, 64, 0, 0, None) == -1
+    assert lib.mmmot_softmax_pairs(None, None, None, None, None, 1, 4, 3, None) == -1
+
+
+def test_gemm_args_struct_layout_matches_header():
+    # 23 pointers/ints in declaration order; size must equal the C struct's (LP64: 8-byte pointers, 4-byte ints)
+    assert ctypes.sizeof(_lib.GemmArgs) == 208

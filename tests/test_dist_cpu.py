@@ -1,0 +1,63 @@
+"""world_size-2 gloo test of the N>1 path: contiguous sample sharding and the
+single flat result gather (mmmot_amd/dist.py), without a GPU."""
+import os
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from mmmot_amd.dist import flatten_results, gather_flat, gather_results, shard_range, unflatten_results
+
+
+def fake_result(seed, N, M):
+    g = torch.Generator().manual_seed(seed)
+    L = N + M
+    return (torch.rand(3, L, generator=g), [torch.rand(3, N, M, generator=g)], torch.rand(3, L, generator=g),
+            torch.rand(3, L, generator=g))
+
+
+def test_shard_range_is_a_partition():
+    for B in (0, 1, 7, 8, 256):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(B, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_flatten_roundtrip():
+    res = [fake_result(1, 3, 4), fake_result(2, 1, 1)]
+    flat, layout = flatten_results(res)
+    back = unflatten_results(flat, layout)
+    for a, b in zip(res, back):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1][0], b[1][0]) and torch.equal(a[3], b[3])
+
+
+def _worker(rank, world, port, B, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    shapes = [(2 + i % 3, 1 + i % 4) for i in range(B)]
+    lo, hi = shard_range(B, rank, world)
+    local = [fake_result(100 + i, *shapes[i]) for i in range(lo, hi)]
+    every = gather_results(local)                      # ragged shapes: object exchange + flat gather
+    ok = len(every) == B
+    for i, r in enumerate(every):
+        exp = fake_result(100 + i, *shapes[i])
+        ok = ok and torch.equal(r[0], exp[0]) and torch.equal(r[1][0], exp[1][0]) and torch.equal(r[2], exp[2])
+    same = [fake_result(7 + rank * 10 + i, 4, 5) for i in range(2)]
+    every2 = gather_results(same, same_layout=True)    # benchmark path: no object exchange
+    ok = ok and len(every2) == 2 * world and torch.equal(every2[2 * rank][0], same[0][0])
+    flats = gather_flat(torch.arange(rank + 1, dtype=torch.float32))
+    ok = ok and [f.numel() for f in flats] == list(range(1, world + 1))
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_gloo():
+    world, B = 2, 5
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(world, port, B, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}

@@ -1,0 +1,106 @@
+"""Host logic (weight packing / folding, batch plan tables, launch schedule)
+validated WITHOUT a GPU: the engine runs over tests/fake_ops.TorchOps - a
+test-only executable statement of the C-ABI contracts - and must reproduce the
+reference golden vectors.  On the GPU box the same engine code runs over
+HipOps (tests/test_parity_gpu.py)."""
+import numpy as np
+import pytest
+import torch
+
+from common import TOL, build_model, case_inputs, case_names, compare_outputs, get_case, golden
+from fake_ops import TorchOps
+from mmmot_amd import TrackingNet, build_model as build_from_config, model_kwargs_from_config
+from mmmot_amd.plan import BatchPlan, RowTiles
+from mmmot_amd.weights import gen_tensor
+
+
+@pytest.mark.parametrize('name', case_names(light_only=True))
+def test_engine_schedule_matches_golden(name):
+    c, base = get_case(name)
+    m = build_model(c, base, ops=TorchOps())
+    out = m(*case_inputs(c))
+    compare_outputs(out, golden(name), tol=2e-4)
+
+
+def test_batched_plan_equals_single_samples():
+    """B samples in one plan (ragged sizes) == each sample alone: statistics never cross samples."""
+    ca, base = get_case('s2_C_minus_abs_dual_add')
+    cb, _ = get_case('s1_C_minus_abs_dual_add')
+    m = build_model(ca, base, ops=TorchOps())
+    ins = [case_inputs(ca), case_inputs(dict(cb, S=ca['S']))]
+    singles = [m(*x) for x in ins]
+    samples = [([int(d) for d in ds], info['points_split'].reshape(-1).long().numpy()) for _, info, ds in ins]
+    plan = m.make_plan(samples, ca['S'])
+    crops = torch.cat([x[0] for x in ins])
+    points = torch.cat([x[1]['points'].reshape(-1, 3) for x in ins])
+    batch = m.forward_batch(plan, crops, points)
+    for (det, links, new, end), (sdet, slinks, snew, send, _) in zip(batch, singles):
+        assert torch.allclose(det, sdet, atol=1e-6) and torch.allclose(new, snew, atol=1e-6)
+        assert torch.allclose(end, send, atol=1e-6) and torch.allclose(links[0], slinks[0], atol=1e-6)
+
+
+def test_single_modality_rows():
+    c, base = get_case('s2_C_multiply_none')
+    m = build_model(c, base, ops=TorchOps())
+    dets, info, ds = case_inputs(c)
+    g = golden(c['name'])
+    out0 = m.forward_rows(dets, info, ds, rows=(0,))
+    compare_outputs(out0, g, tol=2e-4, rows=(0,))
+    out1 = m.forward_rows(None, info, ds, rows=(1,))
+    compare_outputs(out1, g, tol=2e-4, rows=(1,))
+
+
+def test_state_dict_keys_match_reference_golden_manifest():
+    """The reference state_dict (fusion C) has 21 218 212 elements (probe of the imported reference)."""
+    c, base = get_case('s2_C_multiply_none')
+    m = build_model(c, base)
+    assert sum(v.numel() for v in m.state_dict().values()) == 21218212
+    ka = build_model(get_case('s2_A_multiply_none')[0], base).state_dict().keys()
+    assert 'fusion_module.input_w.0.weight' in ka and 'w_link.w_new_end.conv1.6.bias' in ka
+    assert 'appearance.layers.0.10.weight' in ka and 'point_net.feat.stn2.output.weight' in ka
+
+
+def test_build_model_from_reference_yaml_dict():
+    common = dict(sample_max_len=2, without_reflectivity=True, dropblock=0, use_dropout=False,
+                  model=dict(point_arch='v1', point_len=512, appear_arch='vgg', appear_len=512, appear_skippool=True,
+                             appear_fpn=False, end_arch='v2', end_mode='avg', affinity_op='minus_abs',
+                             softmax_mode='dual_add', score_arch='branch_cls', neg_threshold=0.2,
+                             score_fusion_arch='C', test_mode=2))
+    m = build_from_config({'common': common})
+    assert isinstance(m, TrackingNet) and m.test_mode == 2 and m.affinity_op == 'minus_abs'
+    assert model_kwargs_from_config(common)['seq_len'] == 2
+
+
+def test_inference_only_and_no_cpu_fallback():
+    c, base = get_case('s1_A_multiply_none')
+    m = build_model(c, base)
+    with pytest.raises(NotImplementedError):
+        m.train()
+    # default backend = HipOps: CPU tensors must be refused, never computed on the host
+    with pytest.raises(RuntimeError):
+        m(*case_inputs(c))
+
+
+def test_plan_tables():
+    t = RowTiles([5, 300, 128], 'cpu')
+    assert t.T == 1 + 3 + 1 and t.R == 433
+    assert list(t.h_nrows) == [5, 128, 128, 44, 128] and list(t.h_group) == [0, 1, 1, 1, 2]
+    assert list(t.h_g_tile0) == [0, 1, 4] and list(t.h_row0) == [0, 5, 133, 261, 305]
+    ps = np.array([0, 3, 4, 10, 12, 20])
+    p = BatchPlan([([2, 3], ps)], 32, 'cpu')
+    assert p.Lt == 5 and p.P == 20 and p.pairs == [(0, 0, 2, 2, 3)]
+    assert list(p.row_det.numpy()) == [0] * 3 + [1] + [2] * 6 + [3] * 2 + [4] * 8
+    # new rows scatter to current-frame detections, end rows to previous-frame ones, per modality row
+    om = p.v_omap.numpy().reshape(3, 5)
+    assert list(om[0]) == [2, 3, 4, 15 + 0, 15 + 1] and list(om[1]) == [7, 8, 9, 20, 21]
+    with pytest.raises(ValueError):
+        BatchPlan([([2, 0], ps)], 32, 'cpu')
+    with pytest.raises(ValueError):
+        BatchPlan([([2, 3], np.array([0, 3, 3, 10, 12, 20]))], 32, 'cpu')  # empty detection
+
+
+def test_weight_generator_is_order_independent():
+    a = gen_tensor('w_det.0.weight', (512, 512, 1), 0)
+    b = gen_tensor('w_det.0.weight', (512, 512, 1), 0)
+    assert np.array_equal(a, b) and not np.array_equal(a, gen_tensor('w_det.3.weight', (512, 512, 1), 0))
+    assert np.array_equal(gen_tensor('x.idt', (3, 3)), np.eye(3, dtype=np.float32))

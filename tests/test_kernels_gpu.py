@@ -1,0 +1,309 @@
+"""Per-kernel parity: every C-ABI entry point (called through ctypes on the GPU)
+against the executable contract in tests/fake_ops.py (torch fp32/fp64 on CPU).
+
+fp32 MFMA accumulates as an fmaf chain in k order, torch CPU uses a different
+summation order, so GEMM-type results agree to ~1e-6 relative; tolerances are
+written per test as (rtol on the tensor's max magnitude)."""
+import numpy as np
+import pytest
+import torch
+
+from fake_ops import TorchOps
+from mmmot_amd.plan import RowTiles, Segments
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def hip():
+    assert torch.cuda.is_available(), 'gpu tests need a GPU'
+    from mmmot_amd.ops import HipOps
+    return HipOps()
+
+
+def G(t):
+    return None if t is None else t.cuda()
+
+
+def close(got, ref, rtol, what):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), '%s: non-finite values' % what
+    scale = max(ref.abs().max().item(), 1e-6)
+    err = (got - ref).abs().max().item()
+    if err > rtol * scale:
+        idx = np.unravel_index(int((got - ref).abs().argmax()), got.shape)
+        nbad = int(((got - ref).abs() > rtol * scale).sum())
+        raise AssertionError('%s: max|err| %.3e (scale %.3e, rtol %.1e) at %s got %.6g ref %.6g; %d/%d bad' % (
+            what, err, scale, rtol, idx, got[idx].item(), ref[idx].item(), nbad, got.numel()))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+class DevTiles:
+    """RowTiles pair: host copy for the emulation, device copy for HIP."""
+
+    def __init__(self, counts):
+        self.cpu = RowTiles(counts, 'cpu')
+        self.gpu = RowTiles(counts, 'cuda')
+
+
+@pytest.mark.parametrize('K', [8, 32, 96])
+def test_mfma_fragment_layout(hip, K):
+    # asymmetric operands: a transposed C write or a swapped A/B mapping cannot pass
+    A = (torch.arange(32 * K).float().view(32, K) % 17 - 8) / 8 + rnd(32, K, seed=1) * 0.01
+    B = (torch.arange(32 * K).float().view(32, K) % 13 - 3) / 5 + rnd(32, K, seed=2) * 0.01
+    C = torch.zeros(32, 32).cuda()
+    hip.selftest_mfma(A.cuda(), B.cuda(), C, K)
+    close(C, A.double() @ B.double().t(), 2e-6, 'mfma 32x32 K=%d' % K)
+
+
+CONV_CASES = [
+    # first pool L  H   W  Cin Cout
+    (1, 0, 3, 8, 8, 3, 64),
+    (1, 1, 2, 8, 12, 3, 64),
+    (0, 1, 2, 8, 8, 64, 64),
+    (0, 0, 2, 8, 12, 64, 128),
+    (0, 1, 3, 4, 4, 128, 256),
+    (0, 0, 5, 6, 10, 32, 64),
+    (0, 1, 7, 2, 2, 256, 512),
+    (0, 0, 1, 16, 16, 512, 512),
+]
+
+
+@pytest.mark.parametrize('first,pool,L,H,W,Cin,Cout', CONV_CASES)
+def test_conv3x3(hip, first, pool, L, H, W, Cin, Cout):
+    emu = TorchOps(torch.float64)
+    x = rnd(L, 3, H, W, seed=3) if first else torch.relu(rnd(L, H, W, Cin, seed=3))
+    wp = rnd(Cout, 32, seed=4, scale=0.2) if first else rnd(9, Cout, Cin, seed=4, scale=(2.0 / (9 * Cin)) ** 0.5)
+    if first:
+        wp[:, 27:] = 0
+    bias = rnd(Cout, seed=5, scale=0.1)
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    ref = torch.zeros(L * Ho * Wo, Cout)
+    emu.conv3x3(x, wp, bias, ref, L, H, W, Cin, Cout, first, pool)
+    out = torch.full((L * Ho * Wo, Cout), float('nan')).cuda()
+    hip.conv3x3(x.cuda(), wp.cuda(), bias.cuda(), out, L, H, W, Cin, Cout, first, pool)
+    close(out, ref, 3e-6, 'conv3x3')
+
+
+def _gemm_inputs(counts, N, K, seed):
+    R = sum(counts)
+    X = rnd(R, K, seed=seed)
+    W = rnd(N, K, seed=seed + 1, scale=K ** -0.5)
+    bias = rnd(N, seed=seed + 2, scale=0.2)
+    return R, X, W, bias
+
+
+@pytest.mark.parametrize('N,K', [(64, 64), (128, 64), (512, 512), (1024, 128), (256, 512), (64, 1024)])
+@pytest.mark.parametrize('counts', [[5, 300, 128], [1], [257]])
+def test_gemm_plain_stats(hip, N, K, counts):
+    emu = TorchOps(torch.float64)
+    tl = DevTiles(counts)
+    R, X, W, bias = _gemm_inputs(counts, N, K, 10)
+    X = X + 3.0  # non-zero mean: exercises the centred second moment
+    Y, part = torch.zeros(R, N), torch.zeros(tl.cpu.T, 2, N)
+    emu.gemm(W, tl.cpu, N, K, X=X, bias=bias, Y=Y, part=part, act=1)
+    Yg, pg = torch.full((R, N), float('nan')).cuda(), torch.full((tl.cpu.T, 2, N), float('nan')).cuda()
+    hip.gemm(W.cuda(), tl.gpu, N, K, X=X.cuda(), bias=bias.cuda(), Y=Yg, part=pg, act=1)
+    close(Yg, Y, 3e-6, 'gemm Y')
+    close(pg[:, 0], part[:, 0], 1e-5, 'gemm tile sums')
+    close(pg[:, 1], part[:, 1], 1e-4, 'gemm tile M2')
+
+
+def test_gemm_norm_relu_dbias_strided(hip):
+    emu = TorchOps(torch.float64)
+    counts = [70, 200]
+    tl = DevTiles(counts)
+    N, K, R = 128, 64, 270
+    buf = rnd(R, 2 * K, seed=20)           # X is a column slice of a wider buffer (ld = 2K)
+    X = buf[:, K:]
+    W = rnd(N, K, seed=21, scale=K ** -0.5)
+    sc, sh = rnd(2, K, seed=22).abs() + 0.5, rnd(2, K, seed=23)
+    ndet = 9
+    dbias = rnd(ndet, N, seed=24)
+    rowidx = (torch.arange(R) * ndet // R).int()
+    out = torch.zeros(R, 3 * N)            # Y is a column slice too
+    emu.gemm(W, tl.cpu, N, K, X=X, Y=out[:, N:2 * N], sc=sc, sh=sh, amode=1, dbias=dbias, rowidx=rowidx)
+    outg = torch.zeros(R, 3 * N).cuda()
+    bufg = buf.cuda()
+    hip.gemm(W.cuda(), tl.gpu, N, K, X=bufg[:, K:], Y=outg[:, N:2 * N], sc=sc.cuda(), sh=sh.cuda(), amode=1,
+             dbias=dbias.cuda(), rowidx=rowidx.cuda())
+    close(outg, out, 3e-6, 'gemm norm_relu + dbias (strided views)')
+
+
+@pytest.mark.parametrize('pairop', [0, 1, 2])
+def test_gemm_pair(hip, pairop):
+    emu = TorchOps(torch.float64)
+    # two groups: 5x7 and 130x3 pairs, features shared in one [rows][512] matrix
+    NM = [(5, 7), (130, 3)]
+    counts = [n * m for n, m in NM]
+    tl = DevTiles(counts)
+    K, N = 512, 128
+    Fm = rnd(150, K, seed=30)
+    W = rnd(N, K, seed=31, scale=K ** -0.5)
+    bias = rnd(N, seed=32)
+    aoff, boff = [0, 12], [5, 142]
+    mk = lambda dev: dict(row0=torch.tensor(tl.cpu.h_g_row0).to(dev), M=torch.tensor([7, 3], dtype=torch.int32).to(dev),
+                          aoff=torch.tensor(aoff, dtype=torch.int32).to(dev),
+                          boff=torch.tensor(boff, dtype=torch.int32).to(dev))
+    R = sum(counts)
+    Y, part = torch.zeros(R, N), torch.zeros(tl.cpu.T, 2, N)
+    emu.gemm(W, tl.cpu, N, K, FA=Fm, FB=Fm, pair=mk('cpu'), amode=2, pairop=pairop, bias=bias, Y=Y, part=part)
+    Yg, pg = torch.zeros(R, N).cuda(), torch.zeros(tl.cpu.T, 2, N).cuda()
+    Fg = Fm.cuda()
+    hip.gemm(W.cuda(), tl.gpu, N, K, FA=Fg, FB=Fg, pair=mk('cuda'), amode=2, pairop=pairop, bias=bias.cuda(), Y=Yg,
+             part=pg)
+    close(Yg, Y, 3e-6, 'gemm pair')
+    close(pg[:, 0], part[:, 0], 1e-5, 'pair tile sums')
+
+
+@pytest.mark.parametrize('C,NG', [(64, 64), (512, 1), (512, 16), (1024, 1024), (128, 128)])
+def test_gn_finalize(hip, C, NG):
+    emu = TorchOps()
+    counts = [300, 5, 128]
+    tl = DevTiles(counts)
+    g = torch.Generator().manual_seed(40)
+    part = torch.zeros(tl.cpu.T, 2, 2 * C)
+    n_t = torch.tensor(tl.cpu.h_nrows).float().view(-1, 1)
+    part[:, 0] = torch.randn(tl.cpu.T, 2 * C, generator=g) * n_t * 3     # sums with a large mean
+    part[:, 1] = torch.rand(tl.cpu.T, 2 * C, generator=g) * n_t * 0.01   # tiny within-tile M2
+    gamma, beta = rnd(C, seed=41).abs() + 0.5, rnd(C, seed=42)
+    sc, sh = torch.zeros(3, C), torch.zeros(3, C)
+    emu.gn_finalize(part[:, :, C:], tl.cpu, C, NG, gamma, beta, 1e-5, sc, sh)
+    scg, shg = torch.zeros(3, C).cuda(), torch.zeros(3, C).cuda()
+    pg = part.cuda()
+    hip.gn_finalize(pg[:, :, C:], tl.gpu, C, NG, gamma.cuda(), beta.cuda(), 1e-5, scg, shg)
+    close(scg, sc, 1e-6, 'gn scale')
+    close(shg, sh, 1e-6, 'gn shift')
+
+
+@pytest.mark.parametrize('C', [128, 512, 1024])
+def test_segment_mean(hip, C):
+    emu = TorchOps()
+    R = 400
+    X = rnd(R, C + 64, seed=50)[:, 32:32 + C]          # strided view, 16-byte aligned offset
+    start = [0, 7, 300, 3, 399]
+    count = [7, 293, 100, 50, 1]
+    stride = [1, 1, 1, 5, 1]
+    group = [0, 1, 0, 1, 1]
+    sc, sh = rnd(2, C, seed=51), rnd(2, C, seed=52)
+    for norm in (False, True):
+        sg_c, sg_g = Segments(start, count, stride, group, 'cpu'), Segments(start, count, stride, group, 'cuda')
+        out = torch.zeros(5, C)
+        emu.segment_mean(X, C, sg_c, out, sc=sc if norm else None, sh=sh if norm else None, relu=norm)
+        Xg = rnd(R, C + 64, seed=50).cuda()[:, 32:32 + C]
+        outg = torch.full((5, C), float('nan')).cuda()
+        hip.segment_mean(Xg, C, sg_g, outg, sc=G(sc) if norm else None, sh=G(sh) if norm else None, relu=norm)
+        close(outg, out, 2e-6, 'segment_mean norm=%s' % norm)
+
+
+@pytest.mark.parametrize('K', [128, 256, 512])
+def test_rowdot(hip, K):
+    emu = TorchOps()
+    counts = [3, 200, 130]
+    tl = DevTiles(counts)
+    R = sum(counts)
+    X, w = rnd(R, K, seed=60), rnd(K, seed=61, scale=K ** -0.5)
+    sc, sh = rnd(3, K, seed=62), rnd(3, K, seed=63)
+    omap = torch.randperm(R + 10, generator=torch.Generator().manual_seed(64))[:R].int()
+    out = torch.zeros(R + 10)
+    emu.rowdot(X, K, w, 0.3, tl.cpu, out, sc=sc, sh=sh, act=2, omap=omap)
+    outg = torch.zeros(R + 10).cuda()
+    hip.rowdot(X.cuda(), K, w.cuda(), 0.3, tl.gpu, outg, sc=sc.cuda(), sh=sh.cuda(), act=2, omap=omap.cuda())
+    close(outg, out, 2e-6, 'rowdot norm+sigmoid+omap')
+    out2 = torch.zeros(R)
+    emu.rowdot(X, K, w, -0.1, tl.cpu, out2, act=2, use_thr=True, thr=0.45)
+    outg2 = torch.zeros(R).cuda()
+    hip.rowdot(X.cuda(), K, w.cuda(), -0.1, tl.gpu, outg2, act=2, use_thr=True, thr=0.45)
+    # values within 1e-6 of the threshold may legitimately flip
+    safe = (torch.sigmoid(X @ w - 0.1) - 0.45).abs() > 1e-5
+    close(outg2.cpu()[safe], out2[safe], 2e-6, 'rowdot threshold')
+
+
+@pytest.mark.parametrize('C', [64, 128, 512])
+def test_row_layernorm(hip, C):
+    emu = TorchOps()
+    R = 37
+    X = rnd(R, C, seed=70) * 3 + 5
+    gamma, beta = rnd(C, seed=71), rnd(C, seed=72)
+    Y = torch.zeros(R, 2 * C)
+    emu.row_layernorm(X, C, gamma, beta, 1e-5, True, Y[:, C:], R)
+    Yg = torch.zeros(R, 2 * C).cuda()
+    hip.row_layernorm(X.cuda(), C, gamma.cuda(), beta.cuda(), 1e-5, True, Yg[:, C:], R)
+    close(Yg, Y, 3e-6, 'row_layernorm')
+
+
+def test_pointnet_layer1(hip):
+    emu = TorchOps()
+    counts = [1000, 3, 129]
+    tl = DevTiles(counts)
+    R = sum(counts)
+    X = rnd(R, 3, seed=80) * 10 + torch.tensor([30.0, -5.0, -1.0])
+    W, b = rnd(64, 3, seed=81), rnd(64, seed=82)
+    Y, part = torch.zeros(R, 64), torch.zeros(tl.cpu.T, 2, 64)
+    emu.pointnet_layer1(X, W, b, Y, part, tl.cpu)
+    Yg, pg = torch.zeros(R, 64).cuda(), torch.zeros(tl.cpu.T, 2, 64).cuda()
+    hip.pointnet_layer1(X.cuda(), W.cuda(), b.cuda(), Yg, pg, tl.gpu)
+    close(Yg, Y, 2e-6, 'pointnet layer1')
+    close(pg[:, 0], part[:, 0], 1e-5, 'layer1 sums')
+    close(pg[:, 1], part[:, 1], 1e-4, 'layer1 M2')
+
+
+def test_affine_act(hip):
+    emu = TorchOps()
+    counts = [40, 130]
+    tl = DevTiles(counts)
+    C, R = 512, 170
+    X, sc, sh = rnd(R, C, seed=90), rnd(2, C, seed=91), rnd(2, C, seed=92)
+    Y = torch.zeros(R, 2 * C)
+    emu.affine_act(X, C, sc, sh, tl.cpu, 1, Y[:, C:])
+    Yg = torch.zeros(R, 2 * C).cuda()
+    hip.affine_act(X.cuda(), C, sc.cuda(), sh.cuda(), tl.gpu, 1, Yg[:, C:])
+    close(Yg, Y, 1e-6, 'affine_act')
+
+
+@pytest.mark.parametrize('mode', [0, 1, 2])
+def test_fusion_combine(hip, mode):
+    emu = TorchOps()
+    counts = [12, 140]
+    tl = DevTiles(counts)
+    C, Lt = 512, 152
+    N = 2 * C if mode == 2 else C
+    cat = rnd(Lt, 2 * C, seed=100)
+    Y0, Y1 = rnd(Lt, N, seed=101), rnd(Lt, N, seed=102)
+    s0, h0, s1, h1 = (rnd(2, N, seed=103 + i) for i in range(4))
+    v = lambda t: t[:, N - C:]
+    F = torch.zeros(3, Lt, C)
+    emu.fusion_combine(mode, cat, Y0, Y1 if mode else None, v(s0), v(h0), v(s1) if mode else None,
+                       v(h1) if mode else None, tl.cpu, F, Lt, C)
+    Fg = torch.zeros(3, Lt, C).cuda()
+    d = lambda t: t.cuda()
+    s0g, h0g, s1g, h1g = d(s0), d(h0), d(s1), d(h1)
+    hip.fusion_combine(mode, d(cat), d(Y0), d(Y1) if mode else None, v(s0g), v(h0g), v(s1g) if mode else None,
+                       v(h1g) if mode else None, tl.gpu, Fg, Lt, C)
+    close(Fg, F, 3e-6, 'fusion_combine mode %d' % mode)
+
+
+@pytest.mark.parametrize('mode', [1, 2, 3, 4])
+def test_softmax_pairs(hip, mode):
+    emu = TorchOps()
+    NM = [(5, 7), (1, 1), (1, 9), (130, 70), (64, 1)]
+    row0 = np.concatenate([[0], np.cumsum([n * m for n, m in NM])]).astype(np.int32)
+    R = int(row0[-1])
+    x = rnd(R, seed=110) * 4
+    r0 = torch.tensor(row0[:-1])
+    gN, gM = torch.tensor([n for n, _ in NM], dtype=torch.int32), torch.tensor([m for _, m in NM], dtype=torch.int32)
+    out = torch.zeros(R)
+    emu.softmax_pairs(x, out, r0, gN, gM, len(NM), 200, mode)
+    outg = torch.zeros(R).cuda()
+    hip.softmax_pairs(x.cuda(), outg, r0.cuda(), gN.cuda(), gM.cuda(), len(NM), 200, mode)
+    close(outg, out, 3e-6, 'softmax mode %d' % mode)
+
+
+def test_cpu_tensors_rejected(hip):
+    with pytest.raises(RuntimeError):
+        hip.selftest_mfma(torch.zeros(32, 8), torch.zeros(32, 8), torch.zeros(32, 32), 8)
