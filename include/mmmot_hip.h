@@ -89,6 +89,26 @@ int mmmot_conv3x3_bn_relu(const float* in, const float* wp, const float* bias,
                           int first, int pool, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * fp16-matrix-core variant of the trunk layer with fp32-class accuracy.
+ * "hl16" split-half format (same bytes as fp32): a row of C channels is C/8
+ * units of 32 bytes, unit u = [fp16 hi of channels 8u..8u+7 | fp16 lo of the
+ * same channels], hi = fp16(x), lo = fp16(x - hi).  Every product is evaluated
+ * as a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on v_mfma_f32_32x32x16_f16 with fp32
+ * accumulation (3 MFMAs per algorithmic product: ceiling 2.5 PF / 3).
+ *   in  : hl16 NHWC [L][H][W][Cin]       wp: hl16 [9][Cout][Cin] (host-scaled by 2^wshift)
+ *   out : hl16 NHWC (pooled when pool=1)  oscale = 2^-wshift, applied before bias
+ * Cin % 64 == 0, Cout % 64 == 0, H and W even.  Same reference lines as above.
+ * mmmot_conv3x3_first_hl16 is the Cin=3 layer (fp32 MFMA on the NCHW crops) that
+ * emits hl16; mmmot_hl16_pack/unpack convert n fp32 values (n % 8 == 0). */
+int mmmot_conv3x3_bn_relu_hl16(const void* in, const void* wp, const float* bias, void* out,
+                               int L, int H, int W, int Cin, int Cout, int pool, float oscale,
+                               void* stream);
+int mmmot_conv3x3_first_hl16(const float* in, const float* wp, const float* bias, void* out,
+                             int L, int H, int W, int Cout, void* stream);
+int mmmot_hl16_pack(const float* x, void* y, long n, void* stream);
+int mmmot_hl16_unpack(const void* x, float* y, long n, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Row GEMM with fused operand generation and statistics epilogue:
  *   v[r][n] = sum_k A(r,k) * W[n][k] + bias[n] + dbias[rowidx[r]][n]
  *   part[t][0][n] = S  = sum_{r in tile t} v[r][n]
@@ -147,7 +167,9 @@ int mmmot_segment_mean(const float* X, int ldx, int C,
                        const int* seg_start, const int* seg_count, const int* seg_stride,
                        const int* seg_group, int nseg,
                        const float* sc, const float* sh, int ldsc, int relu,
-                       float* out, int ldo, void* stream);
+                       float* out, int ldo,
+                       int hl16 /* 1: X rows are in the hl16 split-half format (see below) */,
+                       void* stream);
 
 /* out[omap ? omap[r] : r] = post(act(sum_k f(X[r][k])*w[k] + b)),
  * post(v) = v - (v < thr) when use_thr (reference tracking_net.py:161-162).

@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libmmmot_hip.so')
-SOURCES = ['conv3x3.hip', 'gemm_rows.hip', 'small_kernels.hip']
+SOURCES = ['conv3x3.hip', 'conv3x3_hl16.hip', 'gemm_rows.hip', 'small_kernels.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 HIPFLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
 
@@ -49,7 +49,11 @@ SIGNATURES = {
     'mmmot_conv3x3_bn_relu': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f],
     'mmmot_gemm_rows': [ctypes.POINTER(GemmArgs), c_f],
     'mmmot_gn_finalize': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, ctypes.c_float, c_f, c_f, c_f],
-    'mmmot_segment_mean': [c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_f, c_f, c_i, c_i, c_f, c_i, c_f],
+    'mmmot_segment_mean': [c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_f, c_f, c_i, c_i, c_f, c_i, c_i, c_f],
+    'mmmot_conv3x3_bn_relu_hl16': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, c_f],
+    'mmmot_conv3x3_first_hl16': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
+    'mmmot_hl16_pack': [c_f, c_f, ctypes.c_long, c_f],
+    'mmmot_hl16_unpack': [c_f, c_f, ctypes.c_long, c_f],
     'mmmot_rowdot': [c_f, c_i, c_i, c_f, ctypes.c_float, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i,
                      ctypes.c_float, c_f, c_f, c_f],
     'mmmot_row_layernorm': [c_f, c_i, c_i, c_f, c_f, ctypes.c_float, c_i, c_f, c_i, c_i, c_f],

@@ -13,7 +13,9 @@
 // is an in-register max and the pooled NHWC store index is simply q.
 #include "common.h"
 
-template <int BN, bool FIRST, bool POOL>
+// OUT16: write the output in the hl16 split-half format consumed by conv3x3_hl16.hip
+// (unit u of a pixel = [hi of channels 8u..8u+7 | lo of channels 8u..8u+7], 2-byte stores).
+template <int BN, bool FIRST, bool POOL, bool OUT16 = false>
 __global__ __launch_bounds__(MM_THREADS, 2) void conv3x3_kernel(
     const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
     float* __restrict__ out, int L, int H, int W, int Cin, int Cout, int Mtot, int ntn) {
@@ -148,7 +150,15 @@ __global__ __launch_bounds__(MM_THREADS, 2) void conv3x3_kernel(
             const int rem = q - crop * (Hq * Wq);
             const int yq = rem / Wq, xq = rem - yq * Wq;
             const long pix = ((long)crop * H + 2 * yq + (sub >> 1)) * W + 2 * xq + (sub & 1);
-            out[pix * Cout + n] = fmaxf(acc[tm][tn][e] + bv, 0.f);
+            const float val = fmaxf(acc[tm][tn][e] + bv, 0.f);
+            if constexpr (OUT16) {
+              _Float16* o16 = reinterpret_cast<_Float16*>(out) + pix * Cout * 2 + (n >> 3) * 16 + (n & 7);
+              const _Float16 h = (_Float16)val;
+              o16[0] = h;
+              o16[8] = (_Float16)(val - (float)h);
+            } else {
+              out[pix * Cout + n] = val;
+            }
           }
         }
       }
@@ -156,13 +166,13 @@ __global__ __launch_bounds__(MM_THREADS, 2) void conv3x3_kernel(
   }
 }
 
-template <int BN, bool FIRST, bool POOL>
+template <int BN, bool FIRST, bool POOL, bool OUT16 = false>
 static int launch_conv(const float* in, const float* wp, const float* bias, float* out, int L, int H,
                        int W, int Cin, int Cout, hipStream_t s) {
   const int Mtot = L * H * W;
   const int ntm = (Mtot + MM_BM - 1) / MM_BM;
   const int ntn = Cout / BN;
-  hipLaunchKernelGGL((conv3x3_kernel<BN, FIRST, POOL>), dim3(ntm * ntn), dim3(MM_THREADS), 0, s, in, wp,
+  hipLaunchKernelGGL((conv3x3_kernel<BN, FIRST, POOL, OUT16>), dim3(ntm * ntn), dim3(MM_THREADS), 0, s, in, wp,
                      bias, out, L, H, W, Cin, Cout, Mtot, ntn);
   return mm_check(hipGetLastError());
 }
@@ -189,4 +199,16 @@ extern "C" int mmmot_conv3x3_bn_relu(const float* in, const float* wp, const flo
                 : launch_conv<128, false, false>(in, wp, bias, out, L, H, W, Cin, Cout, s);
   return pool ? launch_conv<64, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, s)
               : launch_conv<64, false, false>(in, wp, bias, out, L, H, W, Cin, Cout, s);
+}
+
+// First trunk layer (NCHW fp32 crops in, K = 27) with hl16 output for the fp16-split trunk.
+extern "C" int mmmot_conv3x3_first_hl16(const float* in, const float* wp, const float* bias, void* out, int L,
+                                        int H, int W, int Cout, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!in || !wp || !bias || !out || L <= 0 || H <= 0 || W <= 0) return MMMOT_EINVAL;
+  if ((H & 1) || (W & 1) || (Cout % 64) != 0) return MMMOT_EINVAL;
+  if (!mm_al16(in) || !mm_al16(wp) || !mm_al16(out)) return MMMOT_EINVAL;
+  if ((long)L * H * W >= (1L << 31) - MM_BM) return MMMOT_EINVAL;
+  if (Cout % 128 == 0) return launch_conv<128, true, false, true>(in, wp, bias, (float*)out, L, H, W, 3, Cout, s);
+  return launch_conv<64, true, false, true>(in, wp, bias, (float*)out, L, H, W, 3, Cout, s);
 }

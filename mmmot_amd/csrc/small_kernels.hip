@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void segment_mean_kernel(
     const float* __restrict__ X, int ldx, int C, const int* __restrict__ seg_start,
     const int* __restrict__ seg_count, const int* __restrict__ seg_stride, const int* __restrict__ seg_group,
     const float* __restrict__ sc, const float* __restrict__ sh, int ldsc, int relu,
-    float* __restrict__ out, int ldo) {
+    float* __restrict__ out, int ldo, int hl16) {
   __shared__ __attribute__((aligned(16))) float red[4][256];
   const int s = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -87,7 +87,18 @@ __global__ __launch_bounds__(256) void segment_mean_kernel(
   }
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
   auto ld = [&](int t) -> f32x4 {
-    f32x4 v = *reinterpret_cast<const f32x4*>(&X[((long)start + (long)t * stride) * ldx + c]);
+    f32x4 v;
+    if (hl16) {
+      // hl16 row (same bytes as fp32): unit u = c>>3 holds [hi8 | lo8] halves; this lane's 4 channels
+      const _Float16* rowp = reinterpret_cast<const _Float16*>(X + ((long)start + (long)t * stride) * ldx);
+      typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+      const f16x4 h = *reinterpret_cast<const f16x4*>(rowp + (c >> 3) * 16 + (c & 7));
+      const f16x4 l = *reinterpret_cast<const f16x4*>(rowp + (c >> 3) * 16 + 8 + (c & 7));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (float)h[e] + (float)l[e];
+    } else {
+      v = *reinterpret_cast<const f32x4*>(&X[((long)start + (long)t * stride) * ldx + c]);
+    }
     if (norm) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], s4[e], h4[e]);
@@ -123,13 +134,15 @@ __global__ __launch_bounds__(256) void segment_mean_kernel(
 
 extern "C" int mmmot_segment_mean(const float* X, int ldx, int C, const int* seg_start, const int* seg_count,
                                   const int* seg_stride, const int* seg_group, int nseg, const float* sc,
-                                  const float* sh, int ldsc, int relu, float* out, int ldo, void* stream) {
+                                  const float* sh, int ldsc, int relu, float* out, int ldo, int hl16,
+                                  void* stream) {
   if (!X || !seg_start || !seg_count || !out || nseg <= 0 || C <= 0) return MMMOT_EINVAL;
+  if (hl16 && (C % 8 != 0 || ldx % 8 != 0)) return MMMOT_EINVAL;
   if (C % 4 != 0 || ldx % 4 != 0 || ldo % 4 != 0 || !mm_al16(X) || !mm_al16(out)) return MMMOT_EINVAL;
   if ((sc == nullptr) != (sh == nullptr)) return MMMOT_EINVAL;
   if (sc && (ldsc % 4 != 0 || !mm_al16(sc) || !mm_al16(sh))) return MMMOT_EINVAL;
   hipLaunchKernelGGL(segment_mean_kernel, dim3(nseg, (C + 255) / 256), dim3(256), 0, (hipStream_t)stream, X,
-                     ldx, C, seg_start, seg_count, seg_stride, seg_group, sc, sh, ldsc, relu, out, ldo);
+                     ldx, C, seg_start, seg_count, seg_stride, seg_group, sc, sh, ldsc, relu, out, ldo, hl16);
   return mm_check(hipGetLastError());
 }
 

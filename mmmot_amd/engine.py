@@ -21,7 +21,10 @@ EPS = 1e-5  # nn.GroupNorm / nn.BatchNorm default used everywhere in the referen
 
 class Engine:
     def __init__(self, packed, ops, fusion='A', affinity_op='multiply', softmax_mode='none',
-                 neg_threshold=0.0, score_arch='branch_cls', end_mode='avg'):
+                 neg_threshold=0.0, score_arch='branch_cls', end_mode='avg', trunk='f16x3'):
+        if trunk not in ('f16x3', 'f32'):
+            raise ValueError("trunk must be 'f16x3' (fp16 matrix cores, 3-term split) or 'f32' (exact fp32 MFMA)")
+        self.trunk = trunk
         if affinity_op not in PAIR_OPS:
             raise ValueError('unknown affinity_op %r' % (affinity_op,))
         if softmax_mode not in SOFTMAX_MODES and softmax_mode != 'none':
@@ -69,26 +72,33 @@ class Engine:
         """crops [Lt,3,S,S] NCHW (reference contract) -> cat[:, 0:512]."""
         ops, Lt, S = self.ops, plan.Lt, plan.S
         x, H, W = crops, S, S
+        f16 = (self.trunk == 'f16x3')  # activations travel in the hl16 split-half format (same bytes)
         for li, cv in enumerate(self.P['vgg']):
             Ho, Wo = (H // 2, W // 2) if cv['pool'] else (H, W)
             out = self.buf('vgg%d' % (li & 1), Lt * Ho * Wo, cv['cout'])
             if self.conv_events is not None:  # bench.py: HIP events around every trunk launch
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            ops.conv3x3(x, cv['wp'], cv['bias'], out, Lt, H, W, cv['cin'], cv['cout'], li == 0, cv['pool'])
+            if not f16:
+                ops.conv3x3(x, cv['wp'], cv['bias'], out, Lt, H, W, cv['cin'], cv['cout'], li == 0, cv['pool'])
+            elif li == 0:
+                ops.conv3x3_first_hl16(x, cv['wp'], cv['bias'], out, Lt, H, W, cv['cout'])
+            else:
+                ops.conv3x3_hl16(x, cv['wp16'], cv['bias'], out, Lt, H, W, cv['cin'], cv['cout'], cv['pool'],
+                                 cv['oscale'])
             if self.conv_events is not None:
                 e1.record()
                 self.conv_events.append((li, Lt * H * W, cv['cin'], cv['cout'], e0, e1))
             x, H, W = out, Ho, Wo
             if cv['last']:
                 self._stash('vgg_stage%d' % cv['stage'], x)
-                self._skippool(plan, cv['stage'], x, H * W, cv['cout'], cat)
+                self._skippool(plan, cv['stage'], x, H * W, cv['cout'], cat, hl16=f16)
 
-    def _skippool(self, plan, s, x, hw, C, cat):
+    def _skippool(self, plan, s, x, hw, C, cat, hl16=False):
         """reference modules/appear_net.py:9-32 for stage s -> cat[:, 128 s : 128 (s+1)]."""
         ops, Lt, hd, T = self.ops, plan.Lt, self.P['skippool'][s], plan.det_tiles
         pooled = self.buf('sp_pool', Lt, C)
-        ops.segment_mean(x, C, plan.crop_segments(hw), pooled, use_group=False)
+        ops.segment_mean(x, C, plan.crop_segments(hw), pooled, use_group=False, hl16=hl16)
         ln0 = self.buf('sp_ln0', Lt, C)
         ops.row_layernorm(pooled, C, hd['g0'], hd['b0'], EPS, False, ln0, Lt)
         C4 = hd['w1'].shape[0]

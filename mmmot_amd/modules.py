@@ -12,6 +12,8 @@ libmmmot_hip.so through ``Engine``; CPU tensors are rejected (no fallback).
 Inference (eval mode) only: the north-star path is the forward; ``train()``
 mode raises.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -296,6 +298,7 @@ class TrackingNet(nn.Module):
         self.w_det = nn.Sequential(nn.Conv1d(c, c, 1, 1), nn.BatchNorm1d(c), nn.ReLU(inplace=True),
                                    nn.Conv1d(c, c // 2, 1, 1), nn.BatchNorm1d(c // 2), nn.ReLU(inplace=True),
                                    nn.Conv1d(c // 2, 1, 1, 1))
+        self.trunk = os.environ.get('MMMOT_TRUNK', 'f16x3')
         self._ops = None       # operator backend (HipOps unless a test injects another)
         self._engine = None
         self._engine_key = None
@@ -319,9 +322,15 @@ class TrackingNet(nn.Module):
             packed = pack_weights(self.state_dict(), self.score_fusion_arch, dev)
             self._engine = Engine(packed, self._ops, fusion=self.score_fusion_arch, affinity_op=self.affinity_op,
                                   softmax_mode=self.softmax_mode, neg_threshold=self.neg_threshold,
-                                  score_arch=self.score_arch, end_mode=self.end_mode)
+                                  score_arch=self.score_arch, end_mode=self.end_mode, trunk=self.trunk)
             self._plans = {}
         return self._engine
+
+    def set_trunk(self, trunk):
+        """'f16x3': VGG trunk on the fp16 matrix cores with the 3-term hi/lo split (default);
+        'f32': exact fp32 MFMA everywhere."""
+        self.trunk = trunk
+        self._engine = None
 
     def invalidate(self):
         self._engine = None

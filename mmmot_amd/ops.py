@@ -61,6 +61,23 @@ class HipOps:
                                             int(first), int(pool), self._stream())
         _lib.check(st, 'mmmot_conv3x3_bn_relu')
 
+    def conv3x3_hl16(self, inp, wp, bias, out, L, H, W, Cin, Cout, pool, oscale):
+        """fp16-split trunk layer: inp/out/wp are fp32-typed buffers holding hl16 data (same bytes)."""
+        st = self.lib.mmmot_conv3x3_bn_relu_hl16(_ptr(inp), _ptr(wp), _ptr(bias), _ptr(out), L, H, W, Cin, Cout,
+                                                 int(pool), float(oscale), self._stream())
+        _lib.check(st, 'mmmot_conv3x3_bn_relu_hl16')
+
+    def conv3x3_first_hl16(self, inp, wp, bias, out, L, H, W, Cout):
+        st = self.lib.mmmot_conv3x3_first_hl16(_ptr(inp), _ptr(wp), _ptr(bias), _ptr(out), L, H, W, Cout,
+                                               self._stream())
+        _lib.check(st, 'mmmot_conv3x3_first_hl16')
+
+    def hl16_pack(self, x, y):
+        _lib.check(self.lib.mmmot_hl16_pack(_ptr(x), _ptr(y), x.numel(), self._stream()), 'mmmot_hl16_pack')
+
+    def hl16_unpack(self, x, y):
+        _lib.check(self.lib.mmmot_hl16_unpack(_ptr(x), _ptr(y), y.numel(), self._stream()), 'mmmot_hl16_unpack')
+
     def gemm(self, W, tiles, N, K, X=None, bias=None, dbias=None, rowidx=None, Y=None, part=None,
              sc=None, sh=None, FA=None, FB=None, pair=None, amode=A_PLAIN, pairop=0, act=ACT_NONE):
         a = _lib.GemmArgs()
@@ -89,11 +106,11 @@ class HipOps:
                                         float(eps), _ptr(sc), _ptr(sh), self._stream())
         _lib.check(st, 'mmmot_gn_finalize')
 
-    def segment_mean(self, X, C, segs, out, sc=None, sh=None, relu=False, use_group=True):
+    def segment_mean(self, X, C, segs, out, sc=None, sh=None, relu=False, use_group=True, hl16=False):
         st = self.lib.mmmot_segment_mean(_ptr(X), _ld(X), C, _iptr(segs.start), _iptr(segs.count),
                                          _iptr(segs.stride), _iptr(segs.group) if use_group else None, segs.n,
                                          _ptr(sc), _ptr(sh), _ld(sc), int(relu), _ptr(out), _ld(out),
-                                         self._stream())
+                                         int(hl16), self._stream())
         _lib.check(st, 'mmmot_segment_mean')
 
     def rowdot(self, X, K, w, b, tiles, out, sc=None, sh=None, act=ACT_NONE, use_thr=False, thr=0.0, omap=None):

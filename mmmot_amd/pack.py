@@ -32,6 +32,34 @@ def fold_bn(w, b, bn_w, bn_b, mean, var, eps=1e-5):
     return wf, bf
 
 
+def to_hl16(x):
+    """[..., C] real tensor -> fp32-typed tensor of the same shape whose BYTES are the hl16 split-half
+    format of include/mmmot_hip.h: per 8 channels [8 x fp16 hi | 8 x fp16 lo], hi = fp16(x),
+    lo = fp16(x - hi) (computed in fp64, so hi + lo carries 22 significand bits of x)."""
+    x = x.detach().to('cpu', torch.float64)
+    C = x.shape[-1]
+    assert C % 8 == 0
+    hi = x.to(torch.float16)
+    lo = (x - hi.to(torch.float64)).to(torch.float16)
+    lead = x.shape[:-1]
+    u = torch.stack([hi.reshape(*lead, C // 8, 8), lo.reshape(*lead, C // 8, 8)], dim=-2).contiguous()
+    return u.view(torch.float32).reshape(*lead, C)
+
+
+def from_hl16(y):
+    """Inverse of to_hl16 (fp32-typed hl16 buffer [..., C] -> fp32 values)."""
+    C = y.shape[-1]
+    u = y.contiguous().view(torch.float16).reshape(*y.shape[:-1], C // 8, 2, 8).to(torch.float32)
+    return (u[..., 0, :] + u[..., 1, :]).reshape(*y.shape[:-1], C)
+
+
+def hl16_weight_shift(w):
+    """Power-of-two pre-scale that puts max|w| near 2^14 so the lo halves stay in fp16's normal range."""
+    import math
+    m = float(w.abs().max())
+    return 0 if m == 0.0 else max(-14, min(24, int(math.floor(math.log2(16384.0 / m)))))
+
+
 def stn_transform(sd, prefix, k):
     """Closed-form STN3d output (k x k), fp64."""
     beta2 = _d(sd[prefix + 'fc_bn2.bias'])
@@ -72,8 +100,14 @@ def pack_weights(sd, fusion, device, eps=1e-5):
                 else:
                     # -> [tap = ky*3+kx][Cout][Cin]
                     wp = w.permute(2, 3, 0, 1).reshape(9, cout, cin)
-                convs.append(dict(wp=f32(wp), bias=f32(b), cin=cin, cout=cout, pool=pool, stage=s,
-                                  last=(idx == stage[-1][0])))
+                cv = dict(wp=f32(wp), bias=f32(b), cin=cin, cout=cout, pool=pool, stage=s,
+                          last=(idx == stage[-1][0]))
+                if cin != 3:
+                    # fp16-split (hl16) copy for the f16 matrix-core trunk: weights scaled by 2^shift
+                    shift = hl16_weight_shift(wp)
+                    cv['wp16'] = to_hl16(wp * (2.0 ** shift)).contiguous().to(device)
+                    cv['oscale'] = 2.0 ** (-shift)
+                convs.append(cv)
         P['vgg'] = convs
         heads = []
         for s in range(4):

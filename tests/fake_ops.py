@@ -50,6 +50,31 @@ class TorchOps:
             y = torch.nn.functional.max_pool2d(y, 2, 2)
         out.view(L, y.shape[2], y.shape[3], Cout).copy_(y.permute(0, 2, 3, 1).to(out.dtype))
 
+    # ---- hl16 (fp16 hi/lo split) trunk: same conv, operands/outputs stored split-half ----------
+    def conv3x3_hl16(self, inp, wp, bias, out, L, H, W, Cin, Cout, pool, oscale):
+        from mmmot_amd.pack import from_hl16, to_hl16
+        x = from_hl16(inp.reshape(-1)[:L * H * W * Cin].view(L * H * W, Cin)).view(L, H, W, Cin).permute(0, 3, 1, 2)
+        w = from_hl16(wp.reshape(9 * Cout, Cin)).view(3, 3, Cout, Cin).permute(2, 3, 0, 1) * oscale
+        y = torch.relu(torch.nn.functional.conv2d(x.to(self.dtype), w.to(self.dtype), bias.to(self.dtype), padding=1))
+        if pool:
+            y = torch.nn.functional.max_pool2d(y, 2, 2)
+        rows = y.permute(0, 2, 3, 1).reshape(-1, Cout)
+        out.reshape(-1)[:rows.numel()].view(-1, Cout).copy_(to_hl16(rows))
+
+    def conv3x3_first_hl16(self, inp, wp, bias, out, L, H, W, Cout):
+        from mmmot_amd.pack import to_hl16
+        tmp = torch.zeros(L * H * W, Cout)
+        self.conv3x3(inp, wp, bias, tmp, L, H, W, 3, Cout, True, False)
+        out.reshape(-1)[:tmp.numel()].view(-1, Cout).copy_(to_hl16(tmp))
+
+    def hl16_pack(self, x, y):
+        from mmmot_amd.pack import to_hl16
+        y.reshape(-1).copy_(to_hl16(x.reshape(-1, 8)).reshape(-1))
+
+    def hl16_unpack(self, x, y):
+        from mmmot_amd.pack import from_hl16
+        y.reshape(-1).copy_(from_hl16(x.reshape(-1, 8)).reshape(-1))
+
     def gemm(self, W, tiles, N, K, X=None, bias=None, dbias=None, rowidx=None, Y=None, part=None,
              sc=None, sh=None, FA=None, FB=None, pair=None, amode=0, pairop=0, act=ACT_NONE):
         R = tiles.R
@@ -94,7 +119,10 @@ class TorchOps:
             sc[g, :C] = scv.float()
             sh[g, :C] = (beta.double() - s1.repeat_interleave(CG) * scv).float()
 
-    def segment_mean(self, X, C, segs, out, sc=None, sh=None, relu=False, use_group=True):
+    def segment_mean(self, X, C, segs, out, sc=None, sh=None, relu=False, use_group=True, hl16=False):
+        if hl16:
+            from mmmot_amd.pack import from_hl16
+            X = from_hl16(X[:, :C].contiguous())
         for s in range(segs.n):
             st, cnt, stride = int(segs.h_start[s]), int(segs.h_count[s]), int(segs.h_stride[s])
             rows = X[st:st + (cnt - 1) * stride + 1:stride, :C]

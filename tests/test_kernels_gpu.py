@@ -307,3 +307,104 @@ def test_softmax_pairs(hip, mode):
 def test_cpu_tensors_rejected(hip):
     with pytest.raises(RuntimeError):
         hip.selftest_mfma(torch.zeros(32, 8), torch.zeros(32, 8), torch.zeros(32, 32), 8)
+
+
+# ---- fp16-split (hl16) trunk ---------------------------------------------------------------
+def test_hl16_pack_unpack_matches_host_format(hip):
+    from mmmot_amd.pack import from_hl16, to_hl16
+    x = torch.cat([rnd(4096, seed=120) * 30, rnd(4096, seed=121) * 1e-3, rnd(64, seed=122) * 1e-6])
+    y = torch.zeros_like(x).cuda()
+    hip.hl16_pack(x.cuda(), y)
+    assert torch.equal(y.cpu().view(torch.int32), to_hl16(x.view(-1, 8)).reshape(-1).view(torch.int32))
+    z = torch.zeros_like(x).cuda()
+    hip.hl16_unpack(y, z)
+    close(z, from_hl16(to_hl16(x.view(-1, 8))).reshape(-1), 1e-7, 'hl16 unpack')
+    # 22 significand bits: relative error <= 2^-21 for normal-range values
+    big = x[:4096].double()
+    assert ((z.cpu()[:4096].double() - big).abs() <= big.abs() * 2.0 ** -21 + 1e-7).all()
+
+
+HL_CASES = [
+    # pool L  H   W  Cin Cout
+    (1, 2, 8, 8, 64, 64),
+    (0, 2, 8, 12, 64, 128),
+    (1, 3, 4, 4, 128, 256),
+    (0, 5, 6, 10, 64, 64),
+    (1, 7, 2, 2, 256, 512),
+    (0, 1, 16, 16, 512, 512),
+    (1, 9, 4, 4, 512, 512),     # 36 pooled pixels: partial tile + channel-tile-major order
+]
+
+
+@pytest.mark.parametrize('pool,L,H,W,Cin,Cout', HL_CASES)
+def test_conv3x3_hl16(hip, pool, L, H, W, Cin, Cout):
+    from mmmot_amd.pack import from_hl16, hl16_weight_shift, to_hl16
+    x = torch.relu(rnd(L * H * W, Cin, seed=130)) * 3.0
+    w = rnd(9, Cout, Cin, seed=131, scale=(2.0 / (9 * Cin)) ** 0.5)
+    bias = rnd(Cout, seed=132, scale=0.1)
+    shift = hl16_weight_shift(w)
+    x16, w16 = to_hl16(x), to_hl16(w.double() * 2.0 ** shift)
+    # reference: fp64 conv on the values the kernel actually sees (hi + lo), then the output split rounding
+    emu = TorchOps(torch.float64)
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    ref = torch.zeros(L * Ho * Wo, Cout)
+    emu.conv3x3(from_hl16(x16).view(L, H, W, Cin), (from_hl16(w16) * 2.0 ** -shift), bias, ref, L, H, W, Cin, Cout,
+                False, bool(pool))
+    out16 = torch.zeros(L * Ho * Wo, Cout).cuda()
+    hip.conv3x3_hl16(x16.cuda(), w16.cuda(), bias.cuda(), out16, L, H, W, Cin, Cout, bool(pool), 2.0 ** -shift)
+    out = torch.zeros_like(out16)
+    hip.hl16_unpack(out16, out)
+    close(out, ref, 2e-6, 'conv3x3 hl16 (3-term fp16 split) vs fp64')
+
+
+def test_conv3x3_first_hl16(hip):
+    emu = TorchOps(torch.float64)
+    L, H, W, Cout = 3, 8, 12, 64
+    x = rnd(L, 3, H, W, seed=140)
+    wp = rnd(Cout, 32, seed=141, scale=0.2)
+    wp[:, 27:] = 0
+    bias = rnd(Cout, seed=142, scale=0.1)
+    ref = torch.zeros(L * H * W, Cout)
+    emu.conv3x3(x, wp, bias, ref, L, H, W, 3, Cout, True, False)
+    out16 = torch.zeros(L * H * W, Cout).cuda()
+    hip.conv3x3_first_hl16(x.cuda(), wp.cuda(), bias.cuda(), out16, L, H, W, Cout)
+    out = torch.zeros_like(out16)
+    hip.hl16_unpack(out16, out)
+    close(out, ref, 3e-6, 'first conv -> hl16')
+
+
+def test_hl16_small_magnitudes_keep_absolute_accuracy(hip):
+    """Small activations put their lo halves into fp16's subnormal range; the result must stay
+    accurate in ABSOLUTE terms (the MFMA must not flush fp16 subnormal inputs to zero)."""
+    from mmmot_amd.pack import from_hl16, hl16_weight_shift, to_hl16
+    L, H, W, Cin, Cout = 1, 8, 8, 64, 64
+    x = torch.relu(rnd(L * H * W, Cin, seed=150)) * 0.02          # lo halves ~1e-6: fp16 subnormals
+    w = rnd(9, Cout, Cin, seed=151, scale=0.05)
+    bias = torch.zeros(Cout)
+    shift = hl16_weight_shift(w)
+    x16, w16 = to_hl16(x), to_hl16(w.double() * 2.0 ** shift)
+    emu = TorchOps(torch.float64)
+    ref = torch.zeros(L * H * W, Cout)
+    emu.conv3x3(x.view(L, H, W, Cin), w, bias, ref, L, H, W, Cin, Cout, False, False)   # exact fp32 inputs
+    out16 = torch.zeros(L * H * W, Cout).cuda()
+    hip.conv3x3_hl16(x16.cuda(), w16.cuda(), bias.cuda(), out16, L, H, W, Cin, Cout, False, 2.0 ** -shift)
+    out = torch.zeros_like(out16)
+    hip.hl16_unpack(out16, out)
+    err = (out.cpu().double() - ref.double()).abs().max().item()
+    print('hl16 small-magnitude abs err %.3e (ref max %.3e)' % (err, ref.abs().max().item()))
+    assert err < 2e-6, err   # a flushed lo half would cost ~2^-11 relative = 1e-4 here
+
+
+def test_segment_mean_hl16_input(hip):
+    from mmmot_amd.pack import from_hl16, to_hl16
+    emu = TorchOps()
+    C, hw, Lt = 256, 16, 5
+    x = torch.relu(rnd(Lt * hw, C, seed=160)) * 4
+    x16 = to_hl16(x)
+    sg_c = Segments(np.arange(Lt) * hw, np.full(Lt, hw), np.ones(Lt), np.zeros(Lt), 'cpu')
+    sg_g = Segments(np.arange(Lt) * hw, np.full(Lt, hw), np.ones(Lt), np.zeros(Lt), 'cuda')
+    out = torch.zeros(Lt, C)
+    emu.segment_mean(from_hl16(x16), C, sg_c, out, use_group=False)
+    outg = torch.zeros(Lt, C).cuda()
+    hip.segment_mean(x16.cuda(), C, sg_g, outg, use_group=False, hl16=True)
+    close(outg, out, 2e-6, 'segment_mean on hl16 rows')

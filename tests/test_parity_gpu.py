@@ -18,11 +18,15 @@ def to_dev(ins):
     return (None if dets is None else dets.to(DEV)), {k: v.to(DEV) for k, v in info.items()}, ds
 
 
+@pytest.mark.parametrize('trunk', ['f16x3', 'f32'])
 @pytest.mark.parametrize('name', case_names())
-def test_hip_forward_matches_reference_golden(name):
+def test_hip_forward_matches_reference_golden(name, trunk):
+    """trunk='f16x3': VGG on the fp16 matrix cores (3-term hi/lo split, the default);
+    trunk='f32': exact fp32 MFMA everywhere."""
     c, base = get_case(name)
     m = build_model(c, base, device=DEV)
-    assert m.engine().ops.name == 'hip'
+    m.set_trunk(trunk)
+    assert m.engine().ops.name == 'hip' and m.engine().trunk == trunk
     with torch.no_grad():
         out = m(*to_dev(case_inputs(c)))
     errs = compare_outputs(out, golden(name), tol=TOL)
