@@ -22,11 +22,15 @@
 #include "common.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+__device__ u32x4 mm_zero_page[2];  // zero-initialised: source of out-of-image (padding) taps
 
 #define HL_BK 64   // channels per LDS stage
 #define HL_LDT 72  // halves per LDS row: 144 B
 
-__device__ __forceinline__ void hl_split8(const float* v, uint4& hi, uint4& lo) {
+__device__ __forceinline__ void hl_split8(f32x8 v, u32x4& hi, u32x4& lo) {
   f16x8 h, l;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -34,14 +38,14 @@ __device__ __forceinline__ void hl_split8(const float* v, uint4& hi, uint4& lo) 
     h[e] = (_Float16)x;
     l[e] = (_Float16)(x - (float)h[e]);
   }
-  hi = *reinterpret_cast<uint4*>(&h);
-  lo = *reinterpret_cast<uint4*>(&l);
+  hi = __builtin_bit_cast(u32x4, h);
+  lo = __builtin_bit_cast(u32x4, l);
 }
 
 template <int BN, bool POOL>
 __global__ __launch_bounds__(MM_THREADS, 2) void conv3x3_hl16_kernel(
-    const uint4* __restrict__ in, const uint4* __restrict__ wp, const float* __restrict__ bias,
-    uint4* __restrict__ out, int L, int H, int W, int Cin, int Cout, int Mtot, int ntm, int ntn, float oscale) {
+    const u32x4* __restrict__ in, const u32x4* __restrict__ wp, const float* __restrict__ bias,
+    u32x4* __restrict__ out, int L, int H, int W, int Cin, int Cout, int Mtot, int ntm, int ntn, float oscale) {
   constexpr int WM = (BN == 128) ? 2 : 4;
   constexpr int WN = 4 / WM;
   constexpr int TM = MM_BM / (WM * 32);
@@ -115,8 +119,8 @@ __global__ __launch_bounds__(MM_THREADS, 2) void conv3x3_hl16_kernel(
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[tm][tn][e] = 0.f;
 
-  uint4 ra[4][2], rb[BLD][2];
-  const uint4 z4 = {0u, 0u, 0u, 0u};
+  u32x4 ra[4][2], rb[BLD][2];
+  const u32x4 z4 = {0u, 0u, 0u, 0u};
   const int cpt = Cin / HL_BK;  // slabs per tap
 
   auto load_stage = [&](int it) {
@@ -125,18 +129,18 @@ __global__ __launch_bounds__(MM_THREADS, 2) void conv3x3_hl16_kernel(
     const int dy = tap / 3 - 1, dx = tap % 3 - 1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      // branch-free and select-free: out-of-image taps read a 32-byte zero page, so the loaded
+      // registers are consumed only by the ds_write of the NEXT iteration (the wait sits there).
+      // (A conditional load made hipcc keep ra[] in scratch; a select made it wait for the data here.)
       const int yy = py[i] + dy, xx = px[i] + dx;
-      ra[i][0] = z4;
-      ra[i][1] = z4;
-      if (pval[i] && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
-        const uint4* p = in + ((pbase[i] + dy * W + dx) * cin8 + u0) * 2;
-        ra[i][0] = p[0];
-        ra[i][1] = p[1];
-      }
+      const bool ok = pval[i] && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+      const u32x4* p = ok ? in + ((pbase[i] + dy * W + dx) * cin8 + u0) * 2 : mm_zero_page;
+      ra[i][0] = p[0];
+      ra[i][1] = p[1];
     }
 #pragma unroll
     for (int i = 0; i < BLD; ++i) {
-      const uint4* p = wp + (((long)tap * Cout + n0 + lrow + 32 * i) * cin8 + u0) * 2;
+      const u32x4* p = wp + (((long)tap * Cout + n0 + lrow + 32 * i) * cin8 + u0) * 2;
       rb[i][0] = p[0];
       rb[i][1] = p[1];
     }
@@ -149,13 +153,13 @@ __global__ __launch_bounds__(MM_THREADS, 2) void conv3x3_hl16_kernel(
   for (int it = 0; it < nk; ++it) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<uint4*>(&As_hi[(lrow + 32 * i) * HL_LDT + ku * 8]) = ra[i][0];
-      *reinterpret_cast<uint4*>(&As_lo[(lrow + 32 * i) * HL_LDT + ku * 8]) = ra[i][1];
+      *reinterpret_cast<u32x4*>(&As_hi[(lrow + 32 * i) * HL_LDT + ku * 8]) = ra[i][0];
+      *reinterpret_cast<u32x4*>(&As_lo[(lrow + 32 * i) * HL_LDT + ku * 8]) = ra[i][1];
     }
 #pragma unroll
     for (int i = 0; i < BLD; ++i) {
-      *reinterpret_cast<uint4*>(&Bs_hi[(lrow + 32 * i) * HL_LDT + ku * 8]) = rb[i][0];
-      *reinterpret_cast<uint4*>(&Bs_lo[(lrow + 32 * i) * HL_LDT + ku * 8]) = rb[i][1];
+      *reinterpret_cast<u32x4*>(&Bs_hi[(lrow + 32 * i) * HL_LDT + ku * 8]) = rb[i][0];
+      *reinterpret_cast<u32x4*>(&Bs_lo[(lrow + 32 * i) * HL_LDT + ku * 8]) = rb[i][1];
     }
     __syncthreads();
     if (it + 1 < nk) load_stage(it + 1);
@@ -205,17 +209,20 @@ __global__ __launch_bounds__(MM_THREADS, 2) void conv3x3_hl16_kernel(
       const int qd = w / UN, u = w - qd * UN;
       const int m = mt * MM_BM + qd * 4;
       if (m < Mtot) {
-        float v[8];
+        const float* c = &Cs[(qd * 4) * CLD + u * 8];
+        f32x8 v = *reinterpret_cast<const f32x8*>(c);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float* c = &Cs[(qd * 4) * CLD + u * 8 + e];
-          v[e] = fmaxf(fmaxf(c[0], c[CLD]), fmaxf(c[2 * CLD], c[3 * CLD]));
+        for (int r = 1; r < 4; ++r) {
+          const f32x8 w2 = *reinterpret_cast<const f32x8*>(c + r * CLD);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], w2[e]);
         }
+        const f32x8 bv = *reinterpret_cast<const f32x8*>(&bias[n0 + u * 8]);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], oscale, bias[n0 + u * 8 + e]), 0.f);
-        uint4 hi, lo;
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], oscale, bv[e]), 0.f);
+        u32x4 hi, lo;
         hl_split8(v, hi, lo);
-        uint4* o = out + ((long)(m >> 2) * cout8 + (n0 >> 3) + u) * 2;
+        u32x4* o = out + ((long)(m >> 2) * cout8 + (n0 >> 3) + u) * 2;
         o[0] = hi;
         o[1] = lo;
       }
@@ -225,17 +232,18 @@ __global__ __launch_bounds__(MM_THREADS, 2) void conv3x3_hl16_kernel(
       const int r = w / UN, u = w - r * UN;
       const int m = mt * MM_BM + r;
       if (m < Mtot) {
-        float v[8];
+        f32x8 v = *reinterpret_cast<const f32x8*>(&Cs[r * CLD + u * 8]);
+        const f32x8 bv = *reinterpret_cast<const f32x8*>(&bias[n0 + u * 8]);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(Cs[r * CLD + u * 8 + e], oscale, bias[n0 + u * 8 + e]), 0.f);
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], oscale, bv[e]), 0.f);
         const int q = m >> 2, sub = m & 3;
         const int crop = q / (Hq * Wq);
         const int rem = q - crop * (Hq * Wq);
         const int yq = rem / Wq, xqq = rem - yq * Wq;
         const long pix = ((long)crop * H + 2 * yq + (sub >> 1)) * W + 2 * xqq + (sub & 1);
-        uint4 hi, lo;
+        u32x4 hi, lo;
         hl_split8(v, hi, lo);
-        uint4* o = out + (pix * cout8 + (n0 >> 3) + u) * 2;
+        u32x4* o = out + (pix * cout8 + (n0 >> 3) + u) * 2;
         o[0] = hi;
         o[1] = lo;
       }
@@ -249,8 +257,8 @@ static int launch_hl(const void* in, const void* wp, const float* bias, void* ou
   const int Mtot = L * H * W;
   const int ntm = (Mtot + MM_BM - 1) / MM_BM;
   const int ntn = Cout / BN;
-  hipLaunchKernelGGL((conv3x3_hl16_kernel<BN, POOL>), dim3(ntm * ntn), dim3(MM_THREADS), 0, s, (const uint4*)in,
-                     (const uint4*)wp, bias, (uint4*)out, L, H, W, Cin, Cout, Mtot, ntm, ntn, oscale);
+  hipLaunchKernelGGL((conv3x3_hl16_kernel<BN, POOL>), dim3(ntm * ntn), dim3(MM_THREADS), 0, s, (const u32x4*)in,
+                     (const u32x4*)wp, bias, (u32x4*)out, L, H, W, Cin, Cout, Mtot, ntm, ntn, oscale);
   return mm_check(hipGetLastError());
 }
 
@@ -271,25 +279,20 @@ extern "C" int mmmot_conv3x3_bn_relu_hl16(const void* in, const void* wp, const 
 // ---------------------------------------------------------------------------
 // fp32 rows <-> hl16 rows (used for the first layer's output handoff in tests and by the host
 // weight packer's device-side check; C % 8 == 0).
-__global__ void hl16_pack_kernel(const float* __restrict__ x, uint4* __restrict__ y, long nunits) {
+__global__ void hl16_pack_kernel(const float* __restrict__ x, u32x4* __restrict__ y, long nunits) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nunits) return;
-  float v[8];
-  const f32x4 a = *reinterpret_cast<const f32x4*>(x + i * 8);
-  const f32x4 b = *reinterpret_cast<const f32x4*>(x + i * 8 + 4);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
-  uint4 hi, lo;
+  const f32x8 v = *reinterpret_cast<const f32x8*>(x + i * 8);
+  u32x4 hi, lo;
   hl_split8(v, hi, lo);
   y[i * 2] = hi;
   y[i * 2 + 1] = lo;
 }
 
-__global__ void hl16_unpack_kernel(const uint4* __restrict__ x, float* __restrict__ y, long nunits) {
+__global__ void hl16_unpack_kernel(const u32x4* __restrict__ x, float* __restrict__ y, long nunits) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nunits) return;
-  uint4 hi = x[i * 2], lo = x[i * 2 + 1];
-  const f16x8 h = *reinterpret_cast<f16x8*>(&hi), l = *reinterpret_cast<f16x8*>(&lo);
+  const f16x8 h = __builtin_bit_cast(f16x8, x[i * 2]), l = __builtin_bit_cast(f16x8, x[i * 2 + 1]);
 #pragma unroll
   for (int e = 0; e < 8; ++e) y[i * 8 + e] = (float)h[e] + (float)l[e];
 }
@@ -298,7 +301,7 @@ extern "C" int mmmot_hl16_pack(const float* x, void* y, long n, void* stream) {
   if (!x || !y || n <= 0 || n % 8 != 0 || !mm_al16(x) || !mm_al16(y)) return MMMOT_EINVAL;
   const long nu = n / 8;
   hipLaunchKernelGGL(hl16_pack_kernel, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
-                     (uint4*)y, nu);
+                     (u32x4*)y, nu);
   return mm_check(hipGetLastError());
 }
 
@@ -306,6 +309,6 @@ extern "C" int mmmot_hl16_unpack(const void* x, float* y, long n, void* stream) 
   if (!x || !y || n <= 0 || n % 8 != 0 || !mm_al16(x) || !mm_al16(y)) return MMMOT_EINVAL;
   const long nu = n / 8;
   hipLaunchKernelGGL(hl16_unpack_kernel, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const uint4*)x, y, nu);
+                     (const u32x4*)x, y, nu);
   return mm_check(hipGetLastError());
 }
