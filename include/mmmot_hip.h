@@ -138,6 +138,12 @@ typedef struct mmmot_gemm_args {
   const int* grp_row0; const int* grp_M; const int* grp_aoff; const int* grp_boff; /* [G] PAIR */
   int T; int N; int K;
   int amode; int pairop; int act;
+  /* w_hl16 = 1: W is in the hl16 split-half format ([N][K/8] units of [hi8|lo8] halves, values
+   * pre-scaled by 1/oscale) and the contraction runs on the fp16 matrix cores with the 3-term
+   * hi/lo split (fp32-class accuracy, see mmmot_conv3x3_bn_relu_hl16); requires K % 64 == 0.
+   * The A operand stays fp32 in memory and is split while staged.  oscale multiplies the
+   * accumulator before bias. */
+  int w_hl16; float oscale;
 } mmmot_gemm_args;
 int mmmot_gemm_rows(const mmmot_gemm_args* a, void* stream);
 

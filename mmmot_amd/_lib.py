@@ -39,6 +39,7 @@ class GemmArgs(ctypes.Structure):
         ('grp_row0', c_f), ('grp_M', c_f), ('grp_aoff', c_f), ('grp_boff', c_f),
         ('T', c_i), ('N', c_i), ('K', c_i),
         ('amode', c_i), ('pairop', c_i), ('act', c_i),
+        ('w_hl16', c_i), ('oscale', ctypes.c_float),
     ]
 
 

@@ -1,26 +1,50 @@
-// Row GEMM on the exact fp32 MFMA with fused operand generation and a
-// GroupNorm-statistics epilogue (see include/mmmot_hip.h: mmmot_gemm_rows).
+// Row GEMM with fused operand generation and a GroupNorm-statistics epilogue
+// (see include/mmmot_hip.h: mmmot_gemm_rows).
 //
 //   v[r][n] = sum_k A(r,k) W[n][k] + bias[n] + dbias[rowidx[r]][n]
 //
 // A modes: PLAIN (X), NORM_RELU (relu(X*sc+sh): the previous layer's GroupNorm
 // + ReLU applied while staging the tile), PAIR (op(FA[i], FB[j]) generated on
 // the fly - the 3x512xNxM tensor of reference modules/gcn.py:6-41 never reaches
-// HBM).  Epilogue: per-tile per-channel sum / sum-of-squares of v (input of
+// HBM).  Epilogue: per-tile per-channel sum / tile-centred M2 of v (input of
 // mmmot_gn_finalize), activation, store.
+//
+// Two arithmetic paths behind one template:
+//   F16 = false : exact fp32 MFMA (v_mfma_f32_32x32x2_f32), BK = 32;
+//   F16 = true  : fp16 matrix cores with the 3-term hi/lo split of conv3x3_hl16.hip
+//                 (a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on v_mfma_f32_32x32x16_f16, fp32 accumulate),
+//                 BK = 64.  W arrives pre-split (hl16 format, host-scaled by 1/oscale); the fp32
+//                 A operand is produced by the prologue and split while it is staged to LDS.
 #include "common.h"
 
-template <int BN, int AMODE>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define G16_BK 64
+#define G16_LDT 72  // halves per LDS row (144 B): conflict-free ds_read_b128
+
+template <int BN, int AMODE, bool F16>
 __global__ __launch_bounds__(MM_THREADS, 2) void gemm_rows_kernel(mmmot_gemm_args a, int ntn) {
   constexpr int WM = (BN == 128) ? 2 : 4;
   constexpr int WN = 4 / WM;
   constexpr int TM = MM_BM / (WM * 32);
   constexpr int TN = BN / (WN * 32);
   constexpr int BLD = BN / 32;
+  constexpr int BK = F16 ? G16_BK : MM_BK;
+  constexpr int KV = BK / 32;  // f32x4 loads per thread-row per stage (8 lanes cover a row's BK floats)
+  constexpr int SMEM_BYTES = F16 ? (MM_BM + BN) * G16_LDT * 2 * 2 : (MM_BM + BN) * MM_LDT * 4;
 
-  __shared__ __attribute__((aligned(16))) float smem[(MM_BM + BN) * MM_LDT];
+  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
+  float* smem = reinterpret_cast<float*>(smem_raw);
+  // fp32 path
   float* As = smem;
   float* Bs = smem + MM_BM * MM_LDT;
+  // f16 path: [A hi][A lo][B hi][B lo] planes of halves
+  _Float16* hs = reinterpret_cast<_Float16*>(smem_raw);
+  _Float16* As_hi = hs;
+  _Float16* As_lo = hs + MM_BM * G16_LDT;
+  _Float16* Bs_hi = hs + 2 * MM_BM * G16_LDT;
+  _Float16* Bs_lo = hs + 2 * MM_BM * G16_LDT + BN * G16_LDT;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -36,8 +60,10 @@ __global__ __launch_bounds__(MM_THREADS, 2) void gemm_rows_kernel(mmmot_gemm_arg
 
   const int lrow = tid >> 3;
   const int kq = tid & 7;
+  const int koff = kq * (BK / 8);  // first k (floats) of this thread inside the slab
 
-  // per-thread source rows of its 4 staging rows
+  // per-thread source rows of its 4 staging rows (invalid rows read row 0 of the tile: always mapped,
+  // and are zeroed when staged - keeps the loads branch-free)
   const float* pa[4];
   const float* pb[4];
   bool rval[4];
@@ -45,27 +71,24 @@ __global__ __launch_bounds__(MM_THREADS, 2) void gemm_rows_kernel(mmmot_gemm_arg
   for (int i = 0; i < 4; ++i) {
     const int r = lrow + 32 * i;
     rval[i] = r < nrows;
-    pa[i] = nullptr;
+    const int rr = rval[i] ? r : 0;
     pb[i] = nullptr;
-    if (rval[i]) {
-      if constexpr (AMODE == MMMOT_A_PAIR) {
-        const int q = row0 + r - a.grp_row0[grp];
-        const int M = a.grp_M[grp];
-        const int ii = q / M, jj = q - ii * M;
-        pa[i] = a.FA + (long)(a.grp_aoff[grp] + ii) * a.ldf + kq * 4;
-        pb[i] = a.FB + (long)(a.grp_boff[grp] + jj) * a.ldf + kq * 4;
-      } else {
-        pa[i] = a.X + (long)(row0 + r) * a.ldx + kq * 4;
-      }
+    if constexpr (AMODE == MMMOT_A_PAIR) {
+      const int q = row0 + rr - a.grp_row0[grp];
+      const int M = a.grp_M[grp];
+      const int ii = q / M, jj = q - ii * M;
+      pa[i] = a.FA + (long)(a.grp_aoff[grp] + ii) * a.ldf + koff;
+      pb[i] = a.FB + (long)(a.grp_boff[grp] + jj) * a.ldf + koff;
+    } else {
+      pa[i] = a.X + (long)(row0 + rr) * a.ldx + koff;
     }
   }
   const float* psc = nullptr;
   const float* psh = nullptr;
   if constexpr (AMODE == MMMOT_A_NORM_RELU) {
-    psc = a.sc + (long)grp * a.ldsc + kq * 4;
-    psh = a.sh + (long)grp * a.ldsc + kq * 4;
+    psc = a.sc + (long)grp * a.ldsc + koff;
+    psh = a.sh + (long)grp * a.ldsc + koff;
   }
-  const float* pw = a.W + (long)(n0 + lrow) * a.K + kq * 4;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -75,55 +98,131 @@ __global__ __launch_bounds__(MM_THREADS, 2) void gemm_rows_kernel(mmmot_gemm_arg
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[tm][tn][e] = 0.f;
 
-  f32x4 ra[4], rb[BLD];
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 ra[4][KV];      // raw A (and FB for PAIR in rb2) of the next stage
+  f32x4 rb2[4][KV];
+  f32x4 rs[KV], rh[KV];  // scale / shift of the next stage (NORM_RELU)
+  f32x4 rw32[BLD];       // fp32 weights (F16 = false)
+  u32x4 rw16[BLD][2];    // hl16 weights (F16 = true): hi8, lo8
 
   auto load_stage = [&](int it) {
-    const int k0 = it * MM_BK;
-    f32x4 s4 = zero4, h4 = zero4;
+    const int k0 = it * BK;
     if constexpr (AMODE == MMMOT_A_NORM_RELU) {
-      s4 = *reinterpret_cast<const f32x4*>(psc + k0);
-      h4 = *reinterpret_cast<const f32x4*>(psh + k0);
-    }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      f32x4 v = zero4;
-      if (rval[i]) {
-        v = *reinterpret_cast<const f32x4*>(pa[i] + k0);
-        if constexpr (AMODE == MMMOT_A_NORM_RELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], s4[e], h4[e]), 0.f);
-        } else if constexpr (AMODE == MMMOT_A_PAIR) {
-          const f32x4 u = *reinterpret_cast<const f32x4*>(pb[i] + k0);
-          if (a.pairop == MMMOT_PAIR_MULTIPLY) {
-            v = v * u;
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float d = (v[e] - u[e]) * 0.5f;
-              v[e] = (a.pairop == MMMOT_PAIR_MINUS_ABS) ? fabsf(d) : d;
-            }
-          }
-        }
+      for (int v = 0; v < KV; ++v) {
+        rs[v] = *reinterpret_cast<const f32x4*>(psc + k0 + 4 * v);
+        rh[v] = *reinterpret_cast<const f32x4*>(psh + k0 + 4 * v);
       }
-      ra[i] = v;
     }
-#pragma unroll
-    for (int i = 0; i < BLD; ++i) rb[i] = *reinterpret_cast<const f32x4*>(pw + (long)(32 * i) * a.K + k0);
-  };
-
-  const int nk = a.K / MM_BK;
-  load_stage(0);
-  for (int it = 0; it < nk; ++it) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<f32x4*>(&As[(lrow + 32 * i) * MM_LDT + kq * 4]) = ra[i];
 #pragma unroll
-    for (int i = 0; i < BLD; ++i)
-      *reinterpret_cast<f32x4*>(&Bs[(lrow + 32 * i) * MM_LDT + kq * 4]) = rb[i];
+      for (int v = 0; v < KV; ++v) {
+        ra[i][v] = *reinterpret_cast<const f32x4*>(pa[i] + k0 + 4 * v);
+        if constexpr (AMODE == MMMOT_A_PAIR) rb2[i][v] = *reinterpret_cast<const f32x4*>(pb[i] + k0 + 4 * v);
+      }
+    if constexpr (F16) {
+      // hl16 weight row n: K/8 units of [hi8 | lo8]; this thread's unit = (k0 + koff) / 8
+      const u32x4* wp = reinterpret_cast<const u32x4*>(a.W);
+      const long ku = (long)(a.K >> 3);
+#pragma unroll
+      for (int i = 0; i < BLD; ++i) {
+        const u32x4* p = wp + ((long)(n0 + lrow + 32 * i) * ku + ((k0 + koff) >> 3)) * 2;
+        rw16[i][0] = p[0];
+        rw16[i][1] = p[1];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < BLD; ++i)
+        rw32[i] = *reinterpret_cast<const f32x4*>(a.W + (long)(n0 + lrow + 32 * i) * a.K + k0 + koff);
+    }
+  };
+
+  // A(r, k) of the staged registers -> fp32 values (prologue), zero for rows beyond the tile
+  auto a_value = [&](int i, int v) -> f32x4 {
+    f32x4 x = ra[i][v];
+    if constexpr (AMODE == MMMOT_A_NORM_RELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = fmaxf(fmaf(x[e], rs[v][e], rh[v][e]), 0.f);
+    } else if constexpr (AMODE == MMMOT_A_PAIR) {
+      const f32x4 u = rb2[i][v];
+      if (a.pairop == MMMOT_PAIR_MULTIPLY) {
+        x = x * u;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = (x[e] - u[e]) * 0.5f;
+          x[e] = (a.pairop == MMMOT_PAIR_MINUS_ABS) ? fabsf(d) : d;
+        }
+      }
+    }
+    if (!rval[i]) x = f32x4{0.f, 0.f, 0.f, 0.f};
+    return x;
+  };
+
+  const int nk = a.K / BK;
+  const int lr = lane & 31;
+  load_stage(0);
+  for (int it = 0; it < nk; ++it) {
+    if constexpr (F16) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x4 x0 = a_value(i, 0), x1 = a_value(i, 1);
+        f16x8 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float y0 = fminf(fmaxf(x0[e], -65000.f), 65000.f), y1 = fminf(fmaxf(x1[e], -65000.f), 65000.f);
+          h[e] = (_Float16)y0;
+          l[e] = (_Float16)(y0 - (float)h[e]);
+          h[4 + e] = (_Float16)y1;
+          l[4 + e] = (_Float16)(y1 - (float)h[4 + e]);
+        }
+        *reinterpret_cast<f16x8*>(&As_hi[(lrow + 32 * i) * G16_LDT + kq * 8]) = h;
+        *reinterpret_cast<f16x8*>(&As_lo[(lrow + 32 * i) * G16_LDT + kq * 8]) = l;
+      }
+#pragma unroll
+      for (int i = 0; i < BLD; ++i) {
+        *reinterpret_cast<u32x4*>(&Bs_hi[(lrow + 32 * i) * G16_LDT + kq * 8]) = rw16[i][0];
+        *reinterpret_cast<u32x4*>(&Bs_lo[(lrow + 32 * i) * G16_LDT + kq * 8]) = rw16[i][1];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<f32x4*>(&As[(lrow + 32 * i) * MM_LDT + kq * 4]) = a_value(i, 0);
+#pragma unroll
+      for (int i = 0; i < BLD; ++i)
+        *reinterpret_cast<f32x4*>(&Bs[(lrow + 32 * i) * MM_LDT + kq * 4]) = rw32[i];
+    }
     __syncthreads();
     if (it + 1 < nk) load_stage(it + 1);
-    mm_stage<TM, TN>(As, Bs, acc, wm * TM * 32, wn * TN * 32, lane);
+    if constexpr (F16) {
+      const int kh = (lane >> 5) * 8;
+#pragma unroll
+      for (int k16 = 0; k16 < G16_BK / 16; ++k16) {
+        f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          const int off = (wm * TM * 32 + tm * 32 + lr) * G16_LDT + k16 * 16 + kh;
+          ah[tm] = *reinterpret_cast<const f16x8*>(&As_hi[off]);
+          al[tm] = *reinterpret_cast<const f16x8*>(&As_lo[off]);
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const int off = (wn * TN * 32 + tn * 32 + lr) * G16_LDT + k16 * 16 + kh;
+          bh[tn] = *reinterpret_cast<const f16x8*>(&Bs_hi[off]);
+          bl[tn] = *reinterpret_cast<const f16x8*>(&Bs_lo[off]);
+        }
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+          }
+      }
+    } else {
+      mm_stage<TM, TN>(As, Bs, acc, wm * TM * 32, wn * TN * 32, lane);
+    }
     __syncthreads();
   }
 
@@ -132,6 +231,7 @@ __global__ __launch_bounds__(MM_THREADS, 2) void gemm_rows_kernel(mmmot_gemm_arg
   //   part[t][0][n] = S  = sum_r v[r][n]            over the tile's valid rows
   //   part[t][1][n] = M2 = sum_r (v[r][n] - S/nrows)^2
   // mmmot_gn_finalize merges the tiles with the parallel-variance formula of Chan et al. in fp64.
+  const float oscale = F16 ? a.oscale : 1.f;
   float* red = smem;                 // [WM][BN] per-wave column partials (LDS reuse: all waves are past the last stage)
   float* colmean = smem + WM * BN;   // [BN]
 #pragma unroll
@@ -146,7 +246,7 @@ __global__ __launch_bounds__(MM_THREADS, 2) void gemm_rows_kernel(mmmot_gemm_arg
       for (int e = 0; e < 16; ++e) {
         const int r = wm * TM * 32 + tm * 32 + mm_acc_row(e, lane);
         if (r < nrows) {
-          float v = acc[tm][tn][e] + bv;
+          float v = fmaf(acc[tm][tn][e], oscale, bv);
           if (a.dbias) v += a.dbias[(long)a.rowidx[row0 + r] * a.lddb + n];
           acc[tm][tn][e] = v;
           s1 += v;
@@ -198,17 +298,32 @@ __global__ __launch_bounds__(MM_THREADS, 2) void gemm_rows_kernel(mmmot_gemm_arg
   }
 }
 
-template <int BN, int AMODE>
+template <int BN, int AMODE, bool F16>
 static int launch_gemm(const mmmot_gemm_args* a, hipStream_t s) {
   const int ntn = a->N / BN;
-  hipLaunchKernelGGL((gemm_rows_kernel<BN, AMODE>), dim3(a->T * ntn), dim3(MM_THREADS), 0, s, *a, ntn);
+  hipLaunchKernelGGL((gemm_rows_kernel<BN, AMODE, F16>), dim3(a->T * ntn), dim3(MM_THREADS), 0, s, *a, ntn);
   return mm_check(hipGetLastError());
+}
+
+template <bool F16>
+static int dispatch_gemm(const mmmot_gemm_args* a, hipStream_t s) {
+  const bool wide = (a->N % 128 == 0);
+  switch (a->amode) {
+    case MMMOT_A_PLAIN:
+      return wide ? launch_gemm<128, MMMOT_A_PLAIN, F16>(a, s) : launch_gemm<64, MMMOT_A_PLAIN, F16>(a, s);
+    case MMMOT_A_NORM_RELU:
+      return wide ? launch_gemm<128, MMMOT_A_NORM_RELU, F16>(a, s) : launch_gemm<64, MMMOT_A_NORM_RELU, F16>(a, s);
+    case MMMOT_A_PAIR:
+      return wide ? launch_gemm<128, MMMOT_A_PAIR, F16>(a, s) : launch_gemm<64, MMMOT_A_PAIR, F16>(a, s);
+  }
+  return MMMOT_EINVAL;
 }
 
 extern "C" int mmmot_gemm_rows(const mmmot_gemm_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!a || !a->W || a->T <= 0 || !a->tile_row0 || !a->tile_nrows) return MMMOT_EINVAL;
-  if (a->K <= 0 || a->K % MM_BK != 0 || a->N <= 0 || a->N % 64 != 0) return MMMOT_EINVAL;
+  const int bk = a->w_hl16 ? G16_BK : MM_BK;
+  if (a->K <= 0 || a->K % bk != 0 || a->N <= 0 || a->N % 64 != 0) return MMMOT_EINVAL;
   if (!mm_al16(a->W)) return MMMOT_EINVAL;
   if (a->amode == MMMOT_A_PAIR) {
     if (!a->FA || !a->FB || !a->grp_row0 || !a->grp_M || !a->grp_aoff || !a->grp_boff || !a->tile_group)
@@ -221,16 +336,7 @@ extern "C" int mmmot_gemm_rows(const mmmot_gemm_args* a, void* stream) {
       return MMMOT_EINVAL;
   }
   if (a->dbias && !a->rowidx) return MMMOT_EINVAL;
-  const bool wide = (a->N % 128 == 0);
-  switch (a->amode) {
-    case MMMOT_A_PLAIN:
-      return wide ? launch_gemm<128, MMMOT_A_PLAIN>(a, s) : launch_gemm<64, MMMOT_A_PLAIN>(a, s);
-    case MMMOT_A_NORM_RELU:
-      return wide ? launch_gemm<128, MMMOT_A_NORM_RELU>(a, s) : launch_gemm<64, MMMOT_A_NORM_RELU>(a, s);
-    case MMMOT_A_PAIR:
-      return wide ? launch_gemm<128, MMMOT_A_PAIR>(a, s) : launch_gemm<64, MMMOT_A_PAIR>(a, s);
-  }
-  return MMMOT_EINVAL;
+  return a->w_hl16 ? dispatch_gemm<true>(a, s) : dispatch_gemm<false>(a, s);
 }
 
 // ---------------------------------------------------------------------------

@@ -25,6 +25,7 @@ class Engine:
         if trunk not in ('f16x3', 'f32'):
             raise ValueError("trunk must be 'f16x3' (fp16 matrix cores, 3-term split) or 'f32' (exact fp32 MFMA)")
         self.trunk = trunk
+        self.mlp = trunk  # the 1x1-conv / linear GEMMs follow the same arithmetic choice
         if affinity_op not in PAIR_OPS:
             raise ValueError('unknown affinity_op %r' % (affinity_op,))
         if softmax_mode not in SOFTMAX_MODES and softmax_mode != 'none':
@@ -59,6 +60,14 @@ class Engine:
         sh = self.buf(name + '_sh', tiles.G, C)
         self.ops.gn_finalize(part, tiles, C, NG, gamma, beta, EPS, sc, sh)
         return sc, sh
+
+    def _gemm(self, d, name, tiles, N, K, **kw):
+        """Row GEMM with weight d[name]: on the fp16 matrix cores (3-term hi/lo split, hl16 weight copy
+        made by pack._add_hl16_copies) when mlp == 'f16x3', else on the exact fp32 MFMA."""
+        if self.mlp == 'f16x3' and (name + '_h16') in d:
+            self.ops.gemm(d[name + '_h16'], tiles, N, K, w_hl16=True, oscale=d[name + '_os'], **kw)
+        else:
+            self.ops.gemm(d[name], tiles, N, K, **kw)
 
     def _part(self, tiles, N):
         return self.buf('part', tiles.T, 2, N)
@@ -103,11 +112,11 @@ class Engine:
         ops.row_layernorm(pooled, C, hd['g0'], hd['b0'], EPS, False, ln0, Lt)
         C4 = hd['w1'].shape[0]
         h1 = self.buf('sp_h1', Lt, C4)
-        ops.gemm(hd['w1'], T, C4, C, X=ln0, bias=hd['c1'], Y=h1)
+        self._gemm(hd, 'w1', T, C4, C, X=ln0, bias=hd['c1'], Y=h1)
         ln1 = self.buf('sp_ln1', Lt, C4)
         ops.row_layernorm(h1, C4, hd['g2'], hd['b2'], EPS, True, ln1, Lt)
         h2 = self.buf('sp_h2', Lt, 128)
-        ops.gemm(hd['w4'], T, 128, C4, X=ln1, bias=hd['c4'], Y=h2)
+        self._gemm(hd, 'w4', T, 128, C4, X=ln1, bias=hd['c4'], Y=h2)
         ops.row_layernorm(h2, 128, hd['g5'], hd['b5'], EPS, True, cat[:, 128 * s:128 * (s + 1)], Lt)
 
     # ---- LiDAR branch: PointNet with folded transforms ----------------------
@@ -123,7 +132,7 @@ class Engine:
         for i, (N, K) in zip((2, 3, 4, 5), ((64, 64), (64, 64), (128, 64), (1024, 128))):
             y = self.buf('pn_y%d' % i, Pn, N)
             part = self._part(T, N)
-            ops.gemm(pn['w%d' % i], T, N, K, X=x, bias=pn['b%d' % i], Y=y, part=part, sc=sc, sh=sh,
+            self._gemm(pn, 'w%d' % i, T, N, K, X=x, bias=pn['b%d' % i], Y=y, part=part, sc=sc, sh=sh,
                      amode=A_NORM_RELU)
             sc, sh = self._finalize('pn%d' % i, part, T, N, N, pn['g%d' % i], pn['be%d' % i])
             x = y
@@ -133,17 +142,17 @@ class Engine:
         self._stash('pn_seg1024', seg1024)
         # PointNet_v1.conv1 split: per-detection 1024-channel part becomes a gathered bias
         dbias = self.buf('pn_dbias', Lt, 512)
-        ops.gemm(pn['wc1b'], D, 512, 1024, X=seg1024, bias=pn['bc1'], Y=dbias)
+        self._gemm(pn, 'wc1b', D, 512, 1024, X=seg1024, bias=pn['bc1'], Y=dbias)
         yc1 = self.buf('pn_yc1', Pn, 512)
         part = self._part(T, 512)
-        ops.gemm(pn['wc1a'], T, 512, 64, X=y1, Y=yc1, part=part, sc=sc1, sh=sh1, amode=A_NORM_RELU,
+        self._gemm(pn, 'wc1a', T, 512, 64, X=y1, Y=yc1, part=part, sc=sc1, sh=sh1, amode=A_NORM_RELU,
                  dbias=dbias, rowidx=plan.row_det)
         scc, shc = self._finalize('pnc1', part, T, 512, 512, pn['gc1'], pn['bec1'])
         seg512 = self.buf('pn_seg512', Lt, 512)
         ops.segment_mean(yc1, 512, plan.det_segs, seg512, sc=scc, sh=shc, relu=True)
         yc2 = self.buf('pn_yc2', Lt, 512)
         part = self._part(D, 512)
-        ops.gemm(pn['wc2'], D, 512, 512, X=seg512, bias=pn['bc2'], Y=yc2, part=part)
+        self._gemm(pn, 'wc2', D, 512, 512, X=seg512, bias=pn['bc2'], Y=yc2, part=part)
         sc2, sh2 = self._finalize('pnc2', part, D, 512, 16, pn['gc2'], pn['bec2'])
         ops.affine_act(yc2, 512, sc2, sh2, D, ACT_RELU, cat[:, 512:1024])
 
@@ -156,7 +165,7 @@ class Engine:
         if self.fusion == 'A':
             y0 = self.buf('fu_y0', Lt, 512)
             part = self._part(D, 512)
-            ops.gemm(fu['w0'], D, 512, 1024, X=cat, bias=fu['b0'], Y=y0, part=part)
+            self._gemm(fu, 'w0', D, 512, 1024, X=cat, bias=fu['b0'], Y=y0, part=part)
             sc0, sh0 = self._finalize('fu0', part, D, 512, 512, fu['g0'], fu['be0'])
             ops.fusion_combine(mode, cat, y0, None, sc0, sh0, None, None, D, F, Lt, 512)
             return
@@ -165,7 +174,7 @@ class Engine:
         for j, x in enumerate((img, pts)):  # NB: *_p weights consume the IMAGE features
             y = self.buf('fu_y%d' % j, Lt, N)
             part = self._part(D, N)
-            ops.gemm(fu['w%d' % j], D, N, 512, X=x, bias=fu['b%d' % j], Y=y, part=part)
+            self._gemm(fu, 'w%d' % j, D, N, 512, X=x, bias=fu['b%d' % j], Y=y, part=part)
             sc, sh = self._finalize('fu%d' % j, part, D, N, N, fu['g%d' % j], fu['be%d' % j])
             ys.append(y)
             scs.append(sc[:, N - 512:])
@@ -179,9 +188,9 @@ class Engine:
         R = plan.nR * plan.Lt
         X = F.view(R, 512)
         h0 = self.buf('det_h0', R, 512)
-        ops.gemm(wd['w0'], T, 512, 512, X=X, bias=wd['b0'], Y=h0, act=ACT_RELU)
+        self._gemm(wd, 'w0', T, 512, 512, X=X, bias=wd['b0'], Y=h0, act=ACT_RELU)
         h1 = self.buf('det_h1', R, 256)
-        ops.gemm(wd['w3'], T, 256, 512, X=h0, bias=wd['b3'], Y=h1, act=ACT_RELU)
+        self._gemm(wd, 'w3', T, 256, 512, X=h0, bias=wd['b3'], Y=h1, act=ACT_RELU)
         out = torch.empty(plan.nR, plan.Lt, dtype=torch.float32, device=F.device)
         act = ACT_SIGMOID if 'cls' in self.score_arch else ACT_NONE
         ops.rowdot(h1, 256, wd['w6'], wd['b6'], T, out.view(-1), act=act, use_thr=True, thr=self.neg_threshold)
@@ -197,7 +206,7 @@ class Engine:
         # stacked [new_end.conv0 ; conv1.0] over the on-the-fly pairwise tensor
         ya = self.buf('aff_ya', R, 1024)
         part = self._part(PT, 1024)
-        ops.gemm(lk['wa'], PT, 1024, 512, FA=Ff, FB=Ff, pair=pair, amode=A_PAIR,
+        self._gemm(lk, 'wa', PT, 1024, 512, FA=Ff, FB=Ff, pair=pair, amode=A_PAIR,
                  pairop=PAIR_OPS[self.affinity_op], bias=lk['ba'], Y=ya, part=part)
         sc_ne, sh_ne = self._finalize('aff_ne0', part[:, :, 0:512], PT, 512, 1, lk['g_ne0'], lk['be_ne0'])
         sc1, sh1 = self._finalize('aff_1', part[:, :, 512:1024], PT, 512, 512, lk['g1'], lk['be1'])
@@ -207,11 +216,11 @@ class Engine:
         self._stash('aff_v', V)
         vh0 = self.buf('aff_vh0', VT.R, 512)
         part = self._part(VT, 512)
-        ops.gemm(lk['nw0'], VT, 512, 512, X=V, bias=lk['nb0'], Y=vh0, part=part)
+        self._gemm(lk, 'nw0', VT, 512, 512, X=V, bias=lk['nb0'], Y=vh0, part=part)
         scv, shv = self._finalize('aff_v1', part, VT, 512, 1, lk['ng1'], lk['nbe1'])
         vh1 = self.buf('aff_vh1', VT.R, 128)
         part = self._part(VT, 128)
-        ops.gemm(lk['nw3'], VT, 128, 512, X=vh0, bias=lk['nb3'], Y=vh1, part=part, sc=scv, sh=shv,
+        self._gemm(lk, 'nw3', VT, 128, 512, X=vh0, bias=lk['nb3'], Y=vh1, part=part, sc=scv, sh=shv,
                  amode=A_NORM_RELU)
         scv2, shv2 = self._finalize('aff_v4', part, VT, 128, 1, lk['ng4'], lk['nbe4'])
         ne = torch.zeros(2, nR, Lt, dtype=torch.float32, device=F.device)  # eval-mode zero padding (tracking_net.py:183-189)
@@ -220,12 +229,12 @@ class Engine:
         # link branch
         y3 = self.buf('aff_y3', R, 512)
         part = self._part(PT, 512)
-        ops.gemm(lk['w3'], PT, 512, 512, X=ya[:, 512:1024], bias=lk['b3'], Y=y3, part=part, sc=sc1, sh=sh1,
+        self._gemm(lk, 'w3', PT, 512, 512, X=ya[:, 512:1024], bias=lk['b3'], Y=y3, part=part, sc=sc1, sh=sh1,
                  amode=A_NORM_RELU)
         sc4, sh4 = self._finalize('aff_4', part, PT, 512, 512, lk['g4'], lk['be4'])
         y6 = self.buf('aff_y6', R, 128)
         part = self._part(PT, 128)
-        ops.gemm(lk['w6'], PT, 128, 512, X=y3, bias=lk['b6'], Y=y6, part=part, sc=sc4, sh=sh4,
+        self._gemm(lk, 'w6', PT, 128, 512, X=y3, bias=lk['b6'], Y=y6, part=part, sc=sc4, sh=sh4,
                  amode=A_NORM_RELU)
         sc7, sh7 = self._finalize('aff_7', part, PT, 128, 128, lk['g7'], lk['be7'])
         logits = torch.empty(R, dtype=torch.float32, device=F.device)

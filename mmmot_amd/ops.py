@@ -79,7 +79,9 @@ class HipOps:
         _lib.check(self.lib.mmmot_hl16_unpack(_ptr(x), _ptr(y), y.numel(), self._stream()), 'mmmot_hl16_unpack')
 
     def gemm(self, W, tiles, N, K, X=None, bias=None, dbias=None, rowidx=None, Y=None, part=None,
-             sc=None, sh=None, FA=None, FB=None, pair=None, amode=A_PLAIN, pairop=0, act=ACT_NONE):
+             sc=None, sh=None, FA=None, FB=None, pair=None, amode=A_PLAIN, pairop=0, act=ACT_NONE,
+             w_hl16=False, oscale=1.0):
+        """W: [N][K] fp32 weights, or (w_hl16=True) the hl16 split-half copy scaled by 1/oscale."""
         a = _lib.GemmArgs()
         a.X, a.ldx = _ptr(X), _ld(X)
         a.W = _ptr(W)
@@ -95,6 +97,7 @@ class HipOps:
             a.grp_aoff, a.grp_boff = _iptr(pair['aoff']), _iptr(pair['boff'])
         a.T, a.N, a.K = tiles.T, N, K
         a.amode, a.pairop, a.act = amode, pairop, act
+        a.w_hl16, a.oscale = int(w_hl16), float(oscale)
         _lib.check(self.lib.mmmot_gemm_rows(ctypes.byref(a), self._stream()), 'mmmot_gemm_rows')
 
     def gn_finalize(self, part, tiles, C, NG, gamma, beta, eps, sc, sh):

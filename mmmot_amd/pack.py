@@ -60,6 +60,25 @@ def hl16_weight_shift(w):
     return 0 if m == 0.0 else max(-14, min(24, int(math.floor(math.log2(16384.0 / m)))))
 
 
+def _add_hl16_copies(P, device):
+    """For every row-GEMM weight ([N][K] fp32, K % 64 == 0) add ``<name>_h16`` (hl16 split-half copy
+    scaled by 2^shift) and ``<name>_os`` (= 2^-shift) so the engine can run the GEMM on the fp16
+    matrix cores (mmmot_gemm_args.w_hl16)."""
+    def visit(d):
+        for k in list(d.keys()):
+            v = d[k]
+            if torch.is_tensor(v) and v.dim() == 2 and v.dtype == torch.float32 and v.shape[1] % 64 == 0 \
+                    and v.shape[0] % 64 == 0 and not k.startswith('trans'):
+                shift = hl16_weight_shift(v)
+                d[k + '_h16'] = to_hl16(v.detach().cpu().double() * (2.0 ** shift)).contiguous().to(device)
+                d[k + '_os'] = 2.0 ** (-shift)
+    for key in ('pointnet', 'fusion', 'w_det', 'w_link'):
+        if key in P:
+            visit(P[key])
+    for hd in P.get('skippool', []):
+        visit(hd)
+
+
 def stn_transform(sd, prefix, k):
     """Closed-form STN3d output (k x k), fp64."""
     beta2 = _d(sd[prefix + 'fc_bn2.bias'])
@@ -205,4 +224,5 @@ def pack_weights(sd, fusion, device, eps=1e-5):
         lk['ng4'] = f32(_d(sd[ne + 'conv1.4.weight'])); lk['nbe4'] = f32(_d(sd[ne + 'conv1.4.bias']))
         lk['nw6'] = f32(_d(sd[ne + 'conv1.6.weight']).reshape(-1)); lk['nb6'] = float(sd[ne + 'conv1.6.bias'].item())
         P['w_link'] = lk
+    _add_hl16_copies(P, device)
     return P

@@ -76,7 +76,11 @@ class TorchOps:
         y.reshape(-1).copy_(from_hl16(x.reshape(-1, 8)).reshape(-1))
 
     def gemm(self, W, tiles, N, K, X=None, bias=None, dbias=None, rowidx=None, Y=None, part=None,
-             sc=None, sh=None, FA=None, FB=None, pair=None, amode=0, pairop=0, act=ACT_NONE):
+             sc=None, sh=None, FA=None, FB=None, pair=None, amode=0, pairop=0, act=ACT_NONE,
+             w_hl16=False, oscale=1.0):
+        if w_hl16:  # hl16 split-half weights, pre-scaled by 1/oscale
+            from mmmot_amd.pack import from_hl16
+            W = from_hl16(W[:N, :K].contiguous()).double() * oscale
         R = tiles.R
         grp = _rows_groups(tiles)
         if amode == 2:

@@ -35,6 +35,18 @@ def test_abi_version_and_argument_checks_without_gpu():
     assert lib.mmmot_softmax_pairs(None, None, None, None, None, 1, 4, 3, None) == -1
 
 
-def test_gemm_args_struct_layout_matches_header():
-    # 23 pointers/ints in declaration order; size must equal the C struct's (LP64: 8-byte pointers, 4-byte ints)
-    assert ctypes.sizeof(_lib.GemmArgs) == 208
+def test_gemm_args_struct_layout_matches_header(tmp_path):
+    """The ctypes mirror must have the C struct's size and field offsets: compile the header with gcc
+    (which also proves include/mmmot_hip.h is plain C) and compare."""
+    import subprocess
+    fields = [f[0] for f in _lib.GemmArgs._fields_]
+    src = tmp_path / 'layout.c'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mmmot_hip.h"\nint main(void){\n'
+                   'printf("%zu\\n", sizeof(mmmot_gemm_args));\n' +
+                   ''.join('printf("%%zu\\n", offsetof(mmmot_gemm_args, %s));\n' % f for f in fields) +
+                   'return 0;}\n')
+    exe = tmp_path / 'layout'
+    subprocess.check_call(['gcc', '-std=c99', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
+    nums = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert nums[0] == ctypes.sizeof(_lib.GemmArgs)
+    assert nums[1:] == [getattr(_lib.GemmArgs, f).offset for f in fields]
