@@ -105,6 +105,11 @@ int mmmot_conv3x3_bn_relu_hl16(const void* in, const void* wp, const float* bias
                                void* stream);
 int mmmot_conv3x3_first_hl16(const float* in, const float* wp, const float* bias, void* out,
                              int L, int H, int W, int Cout, void* stream);
+/* tuning knob: inner-loop schedule of the hl16 trunk kernel (0..3; results are identical) */
+int mmmot_set_conv_variant(int v);
+/* variant 3 is instrumented: accumulated shader-clock cycles per phase of the K loop (see
+ * conv3x3_hl16.hip); out8 is a HOST array of 8 counters, reset != 0 clears them. Synchronous. */
+int mmmot_debug_read_phase_timers(unsigned long long* out8, int reset);
 int mmmot_hl16_pack(const float* x, void* y, long n, void* stream);
 int mmmot_hl16_unpack(const void* x, float* y, long n, void* stream);
 

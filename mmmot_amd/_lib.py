@@ -53,6 +53,8 @@ SIGNATURES = {
     'mmmot_segment_mean': [c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_f, c_f, c_i, c_i, c_f, c_i, c_i, c_f],
     'mmmot_conv3x3_bn_relu_hl16': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, c_f],
     'mmmot_conv3x3_first_hl16': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
+    'mmmot_set_conv_variant': [c_i],
+    'mmmot_debug_read_phase_timers': [ctypes.POINTER(ctypes.c_ulonglong), c_i],
     'mmmot_hl16_pack': [c_f, c_f, ctypes.c_long, c_f],
     'mmmot_hl16_unpack': [c_f, c_f, ctypes.c_long, c_f],
     'mmmot_rowdot': [c_f, c_i, c_i, c_f, ctypes.c_float, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i,

@@ -1,0 +1,100 @@
+#!/usr/bin/env python
+"""A/B timing of the hl16 trunk kernel's inner-loop schedule variants on the cfg3 layer shapes.
+
+    python tools/bench_conv_variants.py [--rounds 5]
+
+Interleaved rounds in one process (variants x layers), median ms and TFLOP/s-equivalent per variant.
+Runs on the GPU box only."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mmmot_amd import _lib  # noqa: E402
+from mmmot_amd.ops import HipOps  # noqa: E402
+from mmmot_amd.pack import hl16_weight_shift, to_hl16  # noqa: E402
+
+LAYERS = [  # (L, H, W, Cin, Cout, pool) at cfg3 (128 crops of 128x128)
+    (128, 128, 128, 64, 64, 1), (128, 64, 64, 128, 128, 1), (128, 32, 32, 256, 256, 0), (128, 16, 16, 512, 512, 0),
+    (128, 8, 8, 512, 512, 1),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--rounds', type=int, default=5)
+    ap.add_argument('--variants', default='1,2', help='1 = 128-row tiles, 2 = 256-row tiles, 0 = automatic')
+    args = ap.parse_args()
+    ops = HipOps()
+    lib = _lib.load()
+    variants = [int(v) for v in args.variants.split(',')]
+    g = torch.Generator().manual_seed(0)
+    res = {}
+    for (L, H, W, Cin, Cout, pool) in LAYERS:
+        x = torch.relu(torch.randn(L * H * W, Cin, generator=g)).cuda()
+        x16 = torch.empty_like(x)
+        ops.hl16_pack(x, x16)
+        w = torch.randn(9, Cout, Cin, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+        shift = hl16_weight_shift(w)
+        w16 = to_hl16(w.double() * 2.0 ** shift).cuda()
+        bias = torch.zeros(Cout).cuda()
+        Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+        out = torch.empty(L * Ho * Wo, Cout).cuda()
+        flops = 2.0 * L * H * W * 9 * Cin * Cout
+        ref = None
+        for r in range(args.rounds + 1):
+            for v in variants:
+                lib.mmmot_set_conv_variant(v)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                ops.conv3x3_hl16(x16, w16, bias, out, L, H, W, Cin, Cout, bool(pool), 2.0 ** -shift)
+                e1.record()
+                torch.cuda.synchronize()
+                if r == 0:  # warm-up round doubles as an identity check between variants
+                    if ref is None:
+                        ref = out.clone()
+                    else:
+                        assert torch.equal(ref, out), 'variant %d differs' % v
+                else:
+                    res.setdefault((v, (L, H, W, Cin, Cout, pool)), []).append((e0.elapsed_time(e1), flops))
+    # phase timers of the instrumented variant (3) on the 32x32 256->256 layer
+    import ctypes
+    buf = (ctypes.c_ulonglong * 8)()
+    lib.mmmot_debug_read_phase_timers(buf, 1)
+    lib.mmmot_set_conv_variant(3)
+    L, H, W, Cin, Cout, pool = LAYERS[2]
+    x16 = torch.zeros(L * H * W, Cin).cuda()
+    w16 = torch.zeros(9, Cout, Cin).cuda()
+    out = torch.empty(L * H * W, Cout).cuda()
+    ops.conv3x3_hl16(x16, w16, torch.zeros(Cout).cuda(), out, L, H, W, Cin, Cout, False, 1.0)
+    torch.cuda.synchronize()
+    lib.mmmot_debug_read_phase_timers(buf, 1)
+    n = max(buf[5], 1)
+    names = ['vmcnt-wait + ds_write', 'barrier 1', 'issue next loads', 'ds_read + MFMA', 'barrier 2']
+    tot = sum(buf[i] for i in range(5))
+    print('phase cycles per (wave, stage) on 32x32 256->256 (48 MFMA = 1536 cycles of matrix pipe):')
+    for i in range(5):
+        print('  %-24s %8.0f  %5.1f%%' % (names[i], buf[i] / n, 100.0 * buf[i] / tot))
+    lib.mmmot_set_conv_variant(5)
+    ops.conv3x3_hl16(x16, w16, torch.zeros(Cout).cuda(), out, L, H, W, Cin, Cout, False, 1.0)
+    torch.cuda.synchronize()
+    lib.mmmot_debug_read_phase_timers(buf, 1)
+    npd, ncs = max(buf[5], 1), max(buf[6], 1)
+    print('wave-specialised kernel, cycles per (wave, stage):')
+    print('  producer: wait+ds_write %.0f | issue loads %.0f | barrier wait %.0f' % (buf[0] / npd, buf[1] / npd, buf[2] / npd))
+    print('  consumer: ds_read+MFMA %.0f | barrier wait %.0f' % (buf[3] / ncs, buf[4] / ncs))
+    lib.mmmot_set_conv_variant(0)
+    print('%-8s' % 'variant' + ''.join('%22s' % ('%dx%d %d->%d%s' % (l[1], l[2], l[3], l[4], ' P' if l[5] else '')) for l in LAYERS))
+    for v in variants:
+        row = '%-8d' % v
+        for l in LAYERS:
+            ts = sorted(t for t, _ in res[(v, l)])
+            med = ts[len(ts) // 2]
+            row += '%12.3f ms %6.1f' % (med, res[(v, l)][0][1] / (med * 1e-3) / 1e12)
+        print(row)
+
+
+if __name__ == '__main__':
+    main()
