@@ -103,6 +103,11 @@ int mmmot_conv3x3_bn_relu(const float* in, const float* wp, const float* bias,
 int mmmot_conv3x3_bn_relu_hl16(const void* in, const void* wp, const float* bias, void* out,
                                int L, int H, int W, int Cin, int Cout, int pool, float oscale,
                                void* stream);
+/* same contract, LDS-DMA + producer/consumer-wave kernel on 256-row tiles (conv3x3_hl16_dma.hip) */
+int mmmot_conv3x3_bn_relu_hl16_dma(const void* in, const void* wp, const float* bias, void* out,
+                                   int L, int H, int W, int Cin, int Cout, int pool, float oscale,
+                                   void* stream);
+int mmmot_set_dma_variant(int v); /* tuning / experiment knob of the LDS-DMA kernel (0 = default) */
 int mmmot_conv3x3_first_hl16(const float* in, const float* wp, const float* bias, void* out,
                              int L, int H, int W, int Cout, void* stream);
 /* tuning knob: inner-loop schedule of the hl16 trunk kernel (0..3; results are identical) */

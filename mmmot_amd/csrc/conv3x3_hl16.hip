@@ -303,319 +303,6 @@ __global__ __launch_bounds__(2 * BM, 2) void conv3x3_hl16_kernel(
   }
 }
 
-// ---------------------------------------------------------------------------
-// Wave-specialised variant: 128 x BN tile, 8 waves = 4 consumer waves (one per SIMD: ds_read + MFMA
-// only) + 4 producer waves (global loads -> ds_write only), LDS double-buffered, ONE barrier per stage.
-// The phase timers of the single-role kernel show the vector-memory pipe (64 KB per stage through the
-// CU's L1/TA) and the matrix pipe strictly alternating; here the producers keep the memory pipe busy
-// for stage it+2 / it+1 while the consumers' MFMAs run on stage it.
-// TIMED: mm_dbg[0] producer wait+ds_write, [1] producer load issue, [2] producer barrier wait,
-//        [3] consumer ds_read+MFMA, [4] consumer barrier wait, [5] producer samples, [6] consumer samples
-// NPW producer waves (4 or 8): the L2 -> CU load path delivers ~3.5 B/clk per loading wave
-// (tools/l2bw_probe.hip: 15 B/clk/CU with 4 waves, 28 with 8, 35-48 with 16), so the number of producer
-// waves - not the depth of their prefetch - sets the staging bandwidth.
-template <int BN, bool POOL, bool TIMED, int NPW>
-__global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void conv3x3_hl16_ws_kernel(
-    const u32x4* __restrict__ in, const u32x4* __restrict__ wp, const float* __restrict__ bias,
-    u32x4* __restrict__ out, int L, int H, int W, int Cin, int Cout, int Mtot, int ntm, int ntn, float oscale) {
-  constexpr int BM = 128;
-  constexpr int WN = (BN == 128) ? 2 : 1;  // consumer waves along channels
-  constexpr int WM = 4 / WN;
-  constexpr int TM = BM / (WM * 32);
-  constexpr int TN = BN / (WN * 32);
-  constexpr int RPP = 8 * NPW;    // rows staged per pass by the producer waves
-  constexpr int APASS = BM / RPP;
-  constexpr int BLD = BN / RPP;
-  constexpr int NTHR = 256 + 64 * NPW;
-  static_assert(BM % RPP == 0 && BN % RPP == 0, "producer staging geometry");
-  constexpr int PLANE_A = BM * HL_LDT;
-  constexpr int PLANE_B = BN * HL_LDT;
-  constexpr int SKEW = 32;
-  constexpr int BUF = 2 * PLANE_A + 2 * PLANE_B + 4 * SKEW;  // halves per stage buffer (multiple of 64 halves)
-  static_assert((BUF * 2) % 128 == 0, "stage buffers must stay 128-byte aligned");
-  __shared__ __attribute__((aligned(128))) _Float16 smem[2 * BUF];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const bool producer = wave >= 4;
-
-  const int nwg = gridDim.x;
-  const int lid = mm_xcd_remap(blockIdx.x, nwg);
-  const int xq = nwg >> 3, xr = nwg & 7;
-  const int xcd = blockIdx.x & 7;
-  const int cbase = (xcd < xr) ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
-  const int clen = (xcd < xr) ? xq + 1 : xq;
-  int mt, nt;
-  if (clen % ntn == 0 && cbase % ntn == 0) {
-    const int mcount = clen / ntn;
-    const int s = lid - cbase;
-    nt = s / mcount;
-    mt = cbase / ntn + s % mcount;
-  } else {
-    mt = lid / ntn;
-    nt = lid % ntn;
-  }
-  const int n0 = nt * BN;
-  const int Hq = H >> 1, Wq = W >> 1;
-  const int cin8 = Cin >> 3;
-  const int nk = 9 * (Cin / HL_BK);
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[tm][tn][e] = 0.f;
-  const int cw = wave & 3;  // consumer wave index
-  const int wm = cw / WN, wn = cw % WN;
-  const int lr = lane & 31;
-
-  if (producer) {
-    // ---------------- producer waves: global -> registers -> LDS, two stages ahead -----------------
-    const int ptid = tid - 256;
-    const int lrow = ptid >> 3;  // 0..RPP-1 (+RPP i)
-    const int ku = ptid & 7;
-    const int plane_off = (ku & 1);
-    // Everything row-dependent is hoisted: a per-row base pointer and a 9-bit mask of the taps that
-    // fall inside the image; per stage only a wave-uniform offset (tap shift + channel slab) is added.
-    const u32x4* arow[APASS];
-    unsigned okmask[APASS];
-#pragma unroll
-    for (int i = 0; i < APASS; ++i) {
-      const int m = mt * BM + lrow + RPP * i;
-      const bool pv = m < Mtot;
-      const int q = m >> 2, sub = m & 3;
-      const int crop = q / (Hq * Wq);
-      const int rem = q - crop * (Hq * Wq);
-      const int yq = rem / Wq, xqq = rem - yq * Wq;
-      const int y = 2 * yq + (sub >> 1), x = 2 * xqq + (sub & 1);
-      unsigned mk = 0;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-        if (pv && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) mk |= 1u << t;
-      }
-      okmask[i] = mk;
-      arow[i] = in + (pv ? (((long)crop * H + y) * W + x) : 0L) * (cin8 * 2) + ku;
-    }
-    const u32x4* brow[BLD];
-#pragma unroll
-    for (int i = 0; i < BLD; ++i) brow[i] = wp + (long)(n0 + lrow + RPP * i) * (cin8 * 2) + ku;
-    const long tapstride_w = (long)Cout * cin8 * 2;  // weight rows of one tap
-    // two register sets: TWO stages of loads stay in flight (a stage's first tap misses L2 and comes
-    // from HBM / Infinity Cache; with a single set every batch was drained with vmcnt(0) before the next
-    // one was issued, so the producers ran at one memory latency per stage)
-    u32x4 ra0[APASS][2], rb0[BLD][2], ra1[APASS][2], rb1[BLD][2];
-    auto load_stage = [&](int it, u32x4 (&ra)[APASS][2], u32x4 (&rb)[BLD][2]) {
-      const int slab = it / 9;
-      const int tap = it - slab * 9;
-      const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-      const long aoff = (long)(dy * W + dx) * (cin8 * 2) + slab * 16;  // wave-uniform
-      const long boff = (long)tap * tapstride_w + slab * 16;            // wave-uniform
-#pragma unroll
-      for (int i = 0; i < APASS; ++i) {
-        const u32x4* p = ((okmask[i] >> tap) & 1u) ? arow[i] + aoff : mm_zero_page;
-        ra[i][0] = p[0];
-        ra[i][1] = p[8];
-      }
-#pragma unroll
-      for (int i = 0; i < BLD; ++i) {
-        const u32x4* p = brow[i] + boff;
-        rb[i][0] = p[0];
-        rb[i][1] = p[8];
-      }
-    };
-    auto store_stage = [&](int buf, const u32x4 (&ra)[APASS][2], const u32x4 (&rb)[BLD][2]) {
-      _Float16* base = smem + buf * BUF;
-      _Float16* A_pl = base + (plane_off ? PLANE_A + SKEW : 0);
-      _Float16* B_pl = base + 2 * PLANE_A + 2 * SKEW + (plane_off ? PLANE_B + SKEW : 0);
-#pragma unroll
-      for (int i = 0; i < APASS; ++i) {
-        *reinterpret_cast<u32x4*>(&A_pl[(lrow + RPP * i) * HL_LDT + (ku >> 1) * 8]) = ra[i][0];
-        *reinterpret_cast<u32x4*>(&A_pl[(lrow + RPP * i) * HL_LDT + (4 + (ku >> 1)) * 8]) = ra[i][1];
-      }
-#pragma unroll
-      for (int i = 0; i < BLD; ++i) {
-        *reinterpret_cast<u32x4*>(&B_pl[(lrow + RPP * i) * HL_LDT + (ku >> 1) * 8]) = rb[i][0];
-        *reinterpret_cast<u32x4*>(&B_pl[(lrow + RPP * i) * HL_LDT + (4 + (ku >> 1)) * 8]) = rb[i][1];
-      }
-    };
-    // stage s lives in register set s & 1 and in LDS buffer s & 1
-    load_stage(0, ra0, rb0);
-    if (nk > 1) load_stage(1, ra1, rb1);
-    store_stage(0, ra0, rb0);
-    if (nk > 2) load_stage(2, ra0, rb0);
-    __syncthreads();  // stage 0 visible
-    // iteration it: consumers read buffer it&1; store stage it+1 (loaded two iterations ago), then
-    // refill its register set with stage it+3.  nk is a multiple of 9; unrolled by two so the register
-    // sets are compile-time names (runtime-indexed vector arrays would go to scratch).
-    unsigned long long tp[3] = {0, 0, 0}, t0 = 0;
-    auto tk = [&](int ph) {
-      if constexpr (TIMED) {
-        const unsigned long long now = __builtin_readcyclecounter();
-        tp[ph] += now - t0;
-        t0 = now;
-      }
-    };
-    if constexpr (TIMED) t0 = __builtin_readcyclecounter();
-    for (int it = 0; it < nk; it += 2) {
-      if (it + 1 < nk) store_stage(1, ra1, rb1);
-      if constexpr (TIMED) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-      tk(0);
-      if (it + 3 < nk) load_stage(it + 3, ra1, rb1);
-      tk(1);
-      __syncthreads();
-      tk(2);
-      if (it + 1 < nk) {
-        if (it + 2 < nk) store_stage(0, ra0, rb0);
-        if constexpr (TIMED) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-        tk(0);
-        if (it + 4 < nk) load_stage(it + 4, ra0, rb0);
-        tk(1);
-        __syncthreads();
-        tk(2);
-      }
-    }
-    if constexpr (TIMED) {
-      if (lane == 0) {
-        for (int i = 0; i < 3; ++i) atomicAdd(&mm_dbg[i], tp[i]);
-        atomicAdd(&mm_dbg[5], (unsigned long long)nk);
-      }
-    }
-  } else {
-    // ---------------- consumer waves: LDS -> fragments -> MFMA ------------------------------------
-    const int kh = (lane >> 5) * 8;
-    __syncthreads();  // stage 0 visible
-    unsigned long long tc[2] = {0, 0}, t0 = 0;
-    if constexpr (TIMED) t0 = __builtin_readcyclecounter();
-    for (int it = 0; it < nk; ++it) {
-      const _Float16* base = smem + (it & 1) * BUF;
-      const _Float16* As_hi = base;
-      const _Float16* As_lo = base + PLANE_A + SKEW;
-      const _Float16* Bs_hi = base + 2 * PLANE_A + 2 * SKEW;
-      const _Float16* Bs_lo = base + 2 * PLANE_A + PLANE_B + 3 * SKEW;
-#pragma unroll
-      for (int k16 = 0; k16 < HL_BK / 16; ++k16) {
-        f16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-          const int off = (wm * TM * 32 + tm * 32 + lr) * HL_LDT + k16 * 16 + kh;
-          ah[tm] = *reinterpret_cast<const f16x8*>(&As_hi[off]);
-          al[tm] = *reinterpret_cast<const f16x8*>(&As_lo[off]);
-        }
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          const int off = (wn * TN * 32 + tn * 32 + lr) * HL_LDT + k16 * 16 + kh;
-          bh[tn] = *reinterpret_cast<const f16x8*>(&Bs_hi[off]);
-          bl[tn] = *reinterpret_cast<const f16x8*>(&Bs_lo[off]);
-        }
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn) {
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-          }
-      }
-      if constexpr (TIMED) {
-        const unsigned long long now = __builtin_readcyclecounter();
-        tc[0] += now - t0;
-        t0 = now;
-      }
-      __syncthreads();
-      if constexpr (TIMED) {
-        const unsigned long long now = __builtin_readcyclecounter();
-        tc[1] += now - t0;
-        t0 = now;
-      }
-    }
-    if constexpr (TIMED) {
-      if (lane == 0) {
-        atomicAdd(&mm_dbg[3], tc[0]);
-        atomicAdd(&mm_dbg[4], tc[1]);
-        atomicAdd(&mm_dbg[6], (unsigned long long)nk);
-      }
-    }
-  }
-
-  // ---- epilogue (all 8 waves): consumer accumulators -> LDS fp32 [128][BN+4] -> output units ----
-  constexpr int CLD = BN + 4;
-  static_assert(128 * CLD * 4 <= (int)sizeof(smem), "epilogue staging must fit the LDS");
-  float* Cs = reinterpret_cast<float*>(smem);
-  constexpr int UN = BN / 8;
-  const int cout8 = Cout >> 3;
-  if (!producer) {
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-          Cs[(wm * TM * 32 + tm * 32 + mm_acc_row(e, lane)) * CLD + wn * TN * 32 + tn * 32 + lr] = acc[tm][tn][e];
-  }
-  __syncthreads();
-  const int mbase = mt * BM;
-  if constexpr (POOL) {
-    for (int w = tid; w < 32 * UN; w += NTHR) {
-      const int qd = w / UN, u = w - qd * UN;
-      const int m = mbase + qd * 4;
-      if (m < Mtot) {
-        const float* c = &Cs[(qd * 4) * CLD + u * 8];
-        f32x8 v = *reinterpret_cast<const f32x8*>(c);
-#pragma unroll
-        for (int r = 1; r < 4; ++r) {
-          const f32x8 w2 = *reinterpret_cast<const f32x8*>(c + r * CLD);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], w2[e]);
-        }
-        const f32x8 bv = *reinterpret_cast<const f32x8*>(&bias[n0 + u * 8]);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], oscale, bv[e]), 0.f);
-        u32x4 hi, lo;
-        hl_split8(v, hi, lo);
-        u32x4* o = out + ((long)(m >> 2) * cout8 + (n0 >> 3) + u) * 2;
-        o[0] = hi;
-        o[1] = lo;
-      }
-    }
-  } else {
-    for (int w = tid; w < 128 * UN; w += NTHR) {
-      const int r = w / UN, u = w - r * UN;
-      const int m = mbase + r;
-      if (m < Mtot) {
-        f32x8 v = *reinterpret_cast<const f32x8*>(&Cs[r * CLD + u * 8]);
-        const f32x8 bv = *reinterpret_cast<const f32x8*>(&bias[n0 + u * 8]);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], oscale, bv[e]), 0.f);
-        const int q = m >> 2, sub = m & 3;
-        const int crop = q / (Hq * Wq);
-        const int rem = q - crop * (Hq * Wq);
-        const int yq = rem / Wq, xqq = rem - yq * Wq;
-        const long pix = ((long)crop * H + 2 * yq + (sub >> 1)) * W + 2 * xqq + (sub & 1);
-        u32x4 hi, lo;
-        hl_split8(v, hi, lo);
-        u32x4* o = out + (pix * cout8 + (n0 >> 3) + u) * 2;
-        o[0] = hi;
-        o[1] = lo;
-      }
-    }
-  }
-}
-
-template <int BN, bool POOL, bool TIMED, int NPW>
-static int launch_hl_ws(const void* in, const void* wp, const float* bias, void* out, int L, int H, int W, int Cin,
-                        int Cout, float oscale, hipStream_t s) {
-  const int Mtot = L * H * W;
-  const int ntm = (Mtot + 127) / 128;
-  const int ntn = Cout / BN;
-  hipLaunchKernelGGL((conv3x3_hl16_ws_kernel<BN, POOL, TIMED, NPW>), dim3(ntm * ntn), dim3(256 + 64 * NPW), 0, s, (const u32x4*)in,
-                     (const u32x4*)wp, bias, (u32x4*)out, L, H, W, Cin, Cout, Mtot, ntm, ntn, oscale);
-  return mm_check(hipGetLastError());
-}
-
 extern "C" int mmmot_debug_read_phase_timers(unsigned long long* out8, int reset) {
   hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(mm_dbg), 8 * sizeof(unsigned long long));
   if (e != hipSuccess) return (int)e;
@@ -626,12 +313,13 @@ extern "C" int mmmot_debug_read_phase_timers(unsigned long long* out8, int reset
   return mm_check(e);
 }
 
-// Tuning knob (tools/bench_conv_variants.py): 0 = default, 1 = 128-row tiles / single-role waves,
-// 2 = wave-specialised (producer / consumer waves, double-buffered LDS), 3 = variant 1 with phase-timing
-// instrumentation, 4 = 256-row tiles / single-role waves.  Results are identical.
+// Tuning knob (tools/bench_conv_variants.py): 0 / 1 = 128-row tiles (default), 3 = the same with
+// phase-timing instrumentation, 4 = 256-row tiles.  Results are identical.  (A producer/consumer-wave
+// variant of this register-staged kernel was measured too and was not faster: the LDS-DMA kernel in
+// conv3x3_hl16_dma.hip supersedes it; numbers in profiles/README.md.)
 static int g_hl16_variant = 0;
 extern "C" int mmmot_set_conv_variant(int v) {
-  if (v < 0 || v > 6) return MMMOT_EINVAL;
+  if (v < 0 || v > 4) return MMMOT_EINVAL;
   g_hl16_variant = v;
   return MMMOT_OK;
 }
@@ -655,9 +343,6 @@ static int launch_hl(const void* in, const void* wp, const float* bias, void* ou
   // pixel tiles to fill 256 CUs, otherwise the 128-row tile (two workgroups per CU) balances better.
   switch (g_hl16_variant) {
     case 1: return launch_hl_v<128, BN, POOL, false>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
-    case 2: return launch_hl_ws<BN, POOL, false, 4>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
-    case 5: return launch_hl_ws<BN, POOL, true, 8>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
-    case 6: return launch_hl_ws<BN, POOL, false, 8>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
     case 3: return launch_hl_v<128, BN, POOL, true>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
     case 4: return launch_hl_v<256, BN, POOL, false>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
     default: return launch_hl_v<128, BN, POOL, false>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);

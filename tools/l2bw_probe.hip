@@ -22,7 +22,10 @@ __global__ __launch_bounds__(256) void probe(const u32x4* __restrict__ buf, size
     for (int u = 0; u < UNROLL; ++u) {
       size_t idx;
       if (pattern == 0) idx = base + (size_t)u * 256 + tid;
-      else idx = base + ((size_t)(u * 32 + lane_row)) * row_stride_vec + piece;
+      else if (pattern == 1) idx = base + ((size_t)(u * 32 + lane_row)) * row_stride_vec + piece;
+      // pattern 2: like 1 but every access of every wave falls into the first 128 bytes of a 1-KiB-aligned
+      // row (the trunk kernel at Cin = 256: all workgroups read the same 32-channel slab offset at once)
+      else idx = (base / row_stride_vec) * row_stride_vec + ((size_t)(u * 32 + lane_row)) * row_stride_vec + piece;
       v[u] = buf[idx % region_vec];
     }
 #pragma unroll
@@ -33,7 +36,7 @@ __global__ __launch_bounds__(256) void probe(const u32x4* __restrict__ buf, size
 }
 
 int main() {
-  const size_t region_bytes = 2u << 20;  // 2 MiB: L2 resident in every XCD
+  const size_t region_bytes = 3u << 20;  // 3 MiB: L2 resident in every XCD
   u32x4* buf;
   unsigned* sink;
   hipMalloc(&buf, region_bytes + (1 << 20));
@@ -43,7 +46,7 @@ int main() {
   hipEventCreate(&e0);
   hipEventCreate(&e1);
   const int iters = 2000;
-  for (int pattern = 0; pattern < 2; ++pattern)
+  for (int pattern = 0; pattern < 3; ++pattern)
     for (int blocks_per_cu = 1; blocks_per_cu <= 4; blocks_per_cu *= 2) {
       const int grid = 256 * blocks_per_cu;
       auto run = [&](auto kern, int unroll) {
