@@ -25,7 +25,10 @@ __global__ __launch_bounds__(MM_THREADS, 2) void conv3x3_kernel(
   constexpr int TN = BN / (WN * 32);
   constexpr int BLD = BN / 32;             // float4 weight loads per thread per stage
 
-  __shared__ __attribute__((aligned(16))) float smem[(MM_BM + BN) * MM_LDT];
+  // OUT16 stages the output tile through LDS (fp32 [128][BN+4]) for 16-byte hl16 stores
+  constexpr int SMEM_FLOATS =
+      (OUT16 && MM_BM * (BN + 4) > (MM_BM + BN) * MM_LDT) ? MM_BM * (BN + 4) : (MM_BM + BN) * MM_LDT;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
   float* As = smem;
   float* Bs = smem + MM_BM * MM_LDT;
 
@@ -123,6 +126,47 @@ __global__ __launch_bounds__(MM_THREADS, 2) void conv3x3_kernel(
     __syncthreads();
   }
 
+  if constexpr (OUT16 && !POOL) {
+    // hl16 output: accumulators -> LDS -> bias + ReLU -> hi/lo split -> two 16-byte stores per 8 channels
+    // (per-lane 2-byte stores made this layer store-issue bound: 0.67 ms per 2 frame pairs at cfg3)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    constexpr int CLD = BN + 4;
+    float* Cs = smem;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          Cs[(wm * TM * 32 + tm * 32 + mm_acc_row(e, lane)) * CLD + wn * TN * 32 + tn * 32 + (lane & 31)] =
+              acc[tm][tn][e];
+    __syncthreads();
+    constexpr int UN = BN / 8;
+    u32x4* out16 = reinterpret_cast<u32x4*>(out);
+    for (int w = tid; w < MM_BM * UN; w += MM_THREADS) {
+      const int r = w / UN, u = w - r * UN;
+      const int m = mt * MM_BM + r;
+      if (m < Mtot) {
+        const int q = m >> 2, sub = m & 3;
+        const int crop = q / (Hq * Wq);
+        const int rem = q - crop * (Hq * Wq);
+        const int yq = rem / Wq, xq = rem - yq * Wq;
+        const long pix = ((long)crop * H + 2 * yq + (sub >> 1)) * W + 2 * xq + (sub & 1);
+        f16x8 hh, ll;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float val = fminf(fmaxf(Cs[r * CLD + u * 8 + e] + bias[n0 + u * 8 + e], 0.f), 65000.f);
+          hh[e] = (_Float16)val;
+          ll[e] = (_Float16)(val - (float)hh[e]);
+        }
+        u32x4* o = out16 + (pix * (Cout >> 3) + (n0 >> 3) + u) * 2;
+        o[0] = __builtin_bit_cast(u32x4, hh);
+        o[1] = __builtin_bit_cast(u32x4, ll);
+      }
+    }
+    return;
+  }
   // epilogue: bias + ReLU (+ 2x2 max-pool), NHWC store
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {

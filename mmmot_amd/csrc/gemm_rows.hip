@@ -33,6 +33,9 @@ __global__ __launch_bounds__(MM_THREADS, 2) void gemm_rows_kernel(mmmot_gemm_arg
   constexpr int BK = F16 ? G16_BK : MM_BK;
   constexpr int KV = BK / 32;  // f32x4 loads per thread-row per stage (8 lanes cover a row's BK floats)
   constexpr int SMEM_BYTES = F16 ? (MM_BM + BN) * G16_LDT * 2 * 2 : (MM_BM + BN) * MM_LDT * 4;
+  // wide tiles of the f16 path leave through LDS as 16-byte stores (the narrow 64-column instantiation
+  // keeps the direct per-lane stores: hipcc spilled the staged version, and those layers are tiny)
+  constexpr bool STAGED_OUT = F16 && BN == 128;
 
   __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
   float* smem = reinterpret_cast<float*>(smem_raw);
@@ -250,7 +253,9 @@ __global__ __launch_bounds__(MM_THREADS, 2) void gemm_rows_kernel(mmmot_gemm_arg
           if (a.dbias) v += a.dbias[(long)a.rowidx[row0 + r] * a.lddb + n];
           acc[tm][tn][e] = v;
           s1 += v;
-          if (a.Y) a.Y[(long)(row0 + r) * a.ldy + n] = mm_act(v, a.act);
+          if constexpr (!STAGED_OUT) {
+            if (a.Y) a.Y[(long)(row0 + r) * a.ldy + n] = mm_act(v, a.act);
+          }
         }
       }
     }
@@ -296,6 +301,36 @@ __global__ __launch_bounds__(MM_THREADS, 2) void gemm_rows_kernel(mmmot_gemm_arg
       a.part[((long)t * 2 + 1) * a.N + n0 + cl] = s;
     }
   }
+  // F16 path: the output tile goes through LDS (fp32 [128][BN+4]) and leaves as 16-byte stores, 512
+  // contiguous bytes per row.  The per-lane 4-byte stores of the fp32 path above made the short-K
+  // PointNet layers (K = 64 / 128, N = 512 / 1024) store-issue bound: 1.5 TB/s of output.
+  if constexpr (STAGED_OUT) {
+    if (a.Y) {
+      constexpr int CLD = BN + 4;
+      static_assert(MM_BM * CLD * 4 <= SMEM_BYTES, "output staging must fit the K-loop LDS");
+      __syncthreads();  // statistics scratch (red / colmean) and the last stage are dead
+      float* Cs = smem;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            Cs[(wm * TM * 32 + tm * 32 + mm_acc_row(e, lane)) * CLD + wn * TN * 32 + tn * 32 + (lane & 31)] =
+                acc[tm][tn][e];  // acc[] holds v = scaled accumulator + biases for valid rows
+      __syncthreads();
+      constexpr int C4 = BN / 4;
+      for (int w = tid; w < MM_BM * C4; w += MM_THREADS) {
+        const int r = w / C4, c = (w - r * C4) * 4;
+        if (r < nrows) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[r * CLD + c]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = mm_act(v[e], a.act);
+          *reinterpret_cast<f32x4*>(&a.Y[(long)(row0 + r) * a.ldy + n0 + c]) = v;
+        }
+      }
+    }
+  }
 }
 
 template <int BN, int AMODE, bool F16>
@@ -336,6 +371,7 @@ extern "C" int mmmot_gemm_rows(const mmmot_gemm_args* a, void* stream) {
       return MMMOT_EINVAL;
   }
   if (a->dbias && !a->rowidx) return MMMOT_EINVAL;
+  if (a->w_hl16 && a->Y && (a->ldy % 4 != 0 || !mm_al16(a->Y))) return MMMOT_EINVAL;
   return a->w_hl16 ? dispatch_gemm<true>(a, s) : dispatch_gemm<false>(a, s);
 }
 
