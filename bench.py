@@ -13,8 +13,9 @@ samples sharded, no data-path collective, one flat result gather per step
 (weak scaling: per-GPU work is fixed).
 
 Prints ONE JSON line on rank 0 with the contract fields plus
-  roofline     - the dominant kernel (conv3x3 implicit GEMM, fp32 MFMA), measured
-                 with HIP events around every trunk launch inside the timed region
+  roofline     - the dominant kernel (conv3x3 implicit GEMM; f16 MFMA with the 3-term hi/lo split by
+                 default, fp32 MFMA with --trunk f32), measured with HIP events around every trunk
+                 launch inside the timed region; traffic from the committed PMC passes
   cpu_baseline - the oracle (CPU restatement of the reference) on the host cores
 """
 import argparse
@@ -154,6 +155,21 @@ def main():
     n_launch = sum(a[2] for a in dom.values())
     achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
 
+    # HBM/fabric bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process,
+    # so the figure comes from the committed rocprofv3 --pmc passes of this same command (profiles/traffic.json).
+    traffic, traffic_src = None, None
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
+            tr = json.load(f).get('%s/%s' % (args.workload, args.trunk))
+        if tr:
+            traffic = round((tr['fetch_bytes_per_pair'] + tr['write_bytes_per_pair']) * B / tr['launches_per_step'])
+            traffic_src = tr['source']
+    except (OSError, ValueError, KeyError):
+        pass
+    # algorithmic bytes per launch: every layer reads its input and weights once and writes its output once (4 B/value)
+    alg_bytes = sum((a[3] * a[4] + (a[3] // (4 if li in (1, 3, 6, 9, 12) else 1)) * a[5] + 9 * a[4] * a[5]) * 4.0
+                    for li, a in dom.items()) / max(len(dom), 1)
+
     pairs_total = args.steps * B * world
     value = pairs_total / dt
     out = {
@@ -165,7 +181,9 @@ def main():
             'parallelism': 'sample-sharded x%d, flat all_gather of scores' % world},
         'roofline': {'bound': 'mfma', 'kernel': kname,
                      'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
-                     'frac': round(achieved / peak, 4), 'traffic': None, 'peak_basis': peak_basis,
+                     'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_unit': 'bytes/launch (mean)',
+                     'traffic_source': traffic_src, 'algorithmic_bytes_per_launch': round(alg_bytes),
+                     'peak_basis': peak_basis,
                      'avg_launch_ms': round(conv_ms / max(n_launch, 1), 4),
                      'trunk_share_of_step': round(trunk_ms / (dt * 1e3), 4),
                      'flops_basis': 'algorithmic 2*9*Cin*Cout per output pixel (conv1_1 counted at Cin=3)'},
