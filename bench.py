@@ -139,9 +139,10 @@ def main():
         a[2] += 1
     trunk_ms = sum(a[0] for a in per_layer.values())
     if args.trunk == 'f16x3':
-        # dominant kernel = conv3x3_hl16_kernel (layers 1..12); layer 0 (Cin=3) runs the fp32-MFMA kernel
+        # dominant kernel = the hl16 trunk kernel (layers 1..12); layer 0 (Cin=3) runs the fp32-MFMA kernel
         dom = {li: a for li, a in per_layer.items() if li != 0}
-        kname = 'conv3x3_hl16_kernel (VGG16-BN trunk layers 2-13, 12 launches/step)'
+        kname = '%s (VGG16-BN trunk layers 2-13, 12 launches/step)' % {
+            'patch': 'conv3x3_hl16_patch_kernel', 'tile': 'conv3x3_hl16_kernel', 'dma': 'conv3x3_hl16_dma_kernel'}[eng.conv_impl]
         peak = PEAK_F16_MFMA_TFLOPS / 3.0
         peak_basis = ('%.0f TFLOP/s dense f16 MFMA / 3 MFMAs per algorithmic product (a_hi*w_hi + a_hi*w_lo + '
                       'a_lo*w_hi, fp32 accumulate)' % PEAK_F16_MFMA_TFLOPS)

@@ -107,6 +107,11 @@ int mmmot_conv3x3_bn_relu_hl16(const void* in, const void* wp, const float* bias
 int mmmot_conv3x3_bn_relu_hl16_dma(const void* in, const void* wp, const float* bias, void* out,
                                    int L, int H, int W, int Cin, int Cout, int pool, float oscale,
                                    void* stream);
+/* same contract (Cin % 32 == 0 suffices), LDS-resident haloed activation patch + streamed weight ring,
+ * 256 pixels (16x16 or 4 x 8x8 blocks) x 64/128 channels per workgroup (conv3x3_hl16_patch.hip) */
+int mmmot_conv3x3_bn_relu_hl16_patch(const void* in, const void* wp, const float* bias, void* out,
+                                     int L, int H, int W, int Cin, int Cout, int pool, float oscale,
+                                     void* stream);
 int mmmot_set_dma_variant(int v); /* tuning / experiment knob of the LDS-DMA kernel (0 = default) */
 int mmmot_conv3x3_first_hl16(const float* in, const float* wp, const float* bias, void* out,
                              int L, int H, int W, int Cout, void* stream);

@@ -1,0 +1,458 @@
+// hl16 trunk layer with an LDS-resident haloed activation patch ("patch" kernel).
+//
+// Same arithmetic and storage format as conv3x3_hl16.hip (3-term fp16 hi/lo split on
+// v_mfma_f32_32x32x16_f16, fp32 accumulate, hl16 activations and weights).  Different data movement,
+// driven by the measurements of round 1 (profiles/README.md): the tile kernels re-read the activation tile
+// once per tap through L2 (9x) and are bound by the ~3.5 B/clk/wave L2->CU path.  Here
+//   * a workgroup owns 256 output pixels as NB blocks of BS x BS pixels (16x16x1 or 8x8x4) and BN output
+//     channels; per 32-channel slab it holds the (BS+2)^2 haloed activation patch of every block in LDS
+//     (128 B per pixel: 4 hl16 units) and all 9 taps read their shifted A fragments from it: activation
+//     loads per slab drop from 9 x 32 KB to 41 KB (x 0.14), total L2->CU bytes per MFMA by 2.6x;
+//   * weights stream through a 3-slot ring of (tap, slab) tiles (BN rows x 128 B), three stages ahead;
+//   * everything arrives by LDS-DMA (global_load_lds, no VGPR staging, no ds_write): the unpadded
+//     lane-linear LDS image is made conflict-free for ds_read_b128 by XOR swizzles applied on the SOURCE
+//     side and on the fragment read - weight row r: piece ^ ((r >> 1) & 7); patch pixel (py, px):
+//     piece ^ (((px >> 1) + 4 * (py & 1)) & 7), which is conflict-free for every tap shift because the
+//     16 lanes of a ds_read_b128 group are 4 pooling quads = 2 pixel rows x 8 distinct px (mod 16);
+//   * 8 waves, each wave loads AND computes; fragments are double-buffered in registers (the second
+//     16-channel step of a stage is read under the MFMAs of the first, the first step of the next stage
+//     under the MFMAs of the second), ONE s_barrier per stage with counted vmcnt.
+// Rows of the implicit GEMM are in quad order (4 consecutive rows = one 2x2 pooling window), so max-pool
+// stays an in-register/LDS-local max in the epilogue.
+#include <type_traits>
+
+#include "common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+static __device__ u32x4 pt_zero_page[16];  // zero-initialised: source of out-of-image patch pixels
+
+#define P_BM 256
+#define P_ROWB 128  // bytes per LDS record (pixel or weight row): 32 channels hi+lo
+
+__device__ __forceinline__ void pt_split8(f32x8 v, u32x4& hi, u32x4& lo) {
+  f16x8 h, l;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float x = fminf(fmaxf(v[e], -65000.f), 65000.f);
+    h[e] = (_Float16)x;
+    l[e] = (_Float16)(x - (float)h[e]);
+  }
+  hi = __builtin_bit_cast(u32x4, h);
+  lo = __builtin_bit_cast(u32x4, l);
+}
+
+__device__ __forceinline__ int pt_swz_b(int r) { return (r >> 1) & 7; }
+__device__ __forceinline__ int pt_swz_a(int py, int px) { return ((px >> 1) + 4 * (py & 1)) & 7; }
+
+template <int N>
+__device__ __forceinline__ void pt_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ void pt_dma16(const u32x4* src, unsigned char* dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+}
+
+template <int BS>
+struct PatchGeom {
+  static constexpr int NB = P_BM / (BS * BS);     // blocks per workgroup tile: 1 / 4
+  static constexpr int PW = BS + 2;               // patch row length (pixels)
+  static constexpr int PP = PW * PW;              // patch pixels per block
+  static constexpr int NCH = NB * PP * 8;         // 16-byte pieces per slab patch: 2592 / 3200
+  static constexpr int FULL = NCH / 512;          // rounds in which all 8 waves move 1 KB each: 5 / 6
+  static constexpr int REM = NCH - FULL * 512;    // pieces of the last, partial round: 32 / 128
+  static constexpr int RL = REM / 8;              // active lanes per wave in the partial round: 4 / 16
+  static constexpr int PA = FULL + (REM ? 1 : 0); // DMA rounds per slab patch: 6 / 7
+  static constexpr int BYTES = NCH * 16;          // 41 472 / 51 200
+  static_assert(REM % 8 == 0 && PA <= 7, "patch rounds must fit taps 0..6 of the previous slab");
+};
+
+// decode row i (0..31) of M-tile g (0..7) of the workgroup tile -> block, pixel inside the block
+template <int BS>
+__device__ __forceinline__ void pt_row_to_pixel(int g, int i, int& blk, int& y, int& x) {
+  const int q = i >> 2;
+  if constexpr (BS == 16) {
+    blk = 0;
+    y = 2 * g + ((i >> 1) & 1);
+    x = 2 * q + (i & 1);
+  } else {
+    blk = g >> 1;
+    y = 2 * (2 * (g & 1) + (q >> 2)) + ((i >> 1) & 1);
+    x = 2 * (q & 3) + (i & 1);
+  }
+}
+
+template <int BN, int BS, bool POOL>
+__global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
+    const u32x4* __restrict__ in, const u32x4* __restrict__ wp, const float* __restrict__ bias,
+    u32x4* __restrict__ out, int L, int H, int W, int Cin, int Cout, int nby, int nbx, int nblk, int ntm, int ntn,
+    float oscale) {
+  using G = PatchGeom<BS>;
+  constexpr int WN = (BN == 128) ? 2 : 1;  // waves along channels
+  constexpr int WM = 8 / WN;               // waves along pixels
+  constexpr int TM = P_BM / (WM * 32);     // 2 / 1
+  constexpr int TN = BN / (WN * 32);       // 2
+  constexpr int B_BYTES = BN * P_ROWB;     // 16 / 8 KB per (tap, slab) weight tile
+  constexpr int NBL = BN / 64;             // weight DMA instructions per wave per stage: 2 / 1
+  constexpr int CLD = BN + 4;
+  constexpr int RING0 = 2 * G::BYTES;
+  constexpr int LOOP_BYTES = RING0 + 3 * B_BYTES;
+  constexpr int EPI_BYTES = P_BM * CLD * 4;
+  constexpr int SMEM = LOOP_BYTES > EPI_BYTES ? LOOP_BYTES : EPI_BYTES;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA destinations stay in SGPRs
+
+  // XCD-aware, channel-tile-major order (see conv3x3_hl16.hip)
+  const int nwg = gridDim.x;
+  const int lid = mm_xcd_remap(blockIdx.x, nwg);
+  const int xq = nwg >> 3, xr = nwg & 7;
+  const int xcd = blockIdx.x & 7;
+  const int cbase = (xcd < xr) ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
+  const int clen = (xcd < xr) ? xq + 1 : xq;
+  int mt, nt;
+  if (clen % ntn == 0 && cbase % ntn == 0) {
+    const int mcount = clen / ntn;
+    const int s = lid - cbase;
+    nt = s / mcount;
+    mt = cbase / ntn + s % mcount;
+  } else {
+    mt = lid / ntn;
+    nt = lid % ntn;
+  }
+  const int n0 = nt * BN;
+  const int cin8 = Cin >> 3;
+  const int nslab = Cin >> 5;
+  const int nbpc = nby * nbx;  // blocks per crop
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[tm][tn][e] = 0.f;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lr = lane & 31;
+  const int h = lane >> 5;
+
+  // ---------------- loader state ---------------------------------------------------------------------
+  // patch: round k moves pieces [k*512 + wave*64, +64) (k < FULL) or, in the partial round,
+  // [FULL*512 + wave*RL, +RL); piece p = (patch pixel n = p >> 3, LDS slot c' = p & 7) holds the
+  // logical piece c' ^ swz_a(py, px) of that pixel's 128-byte slab record.
+  unsigned poff[G::PA];  // source offset in 16-byte units (without the slab term); ~0u = zero page
+#pragma unroll
+  for (int k = 0; k < G::PA; ++k) {
+    const int p = (k < G::FULL) ? (k * 8 + wave) * 64 + lane : G::FULL * 512 + wave * G::RL + lane;
+    unsigned off = ~0u;
+    if (k < G::FULL || lane < G::RL) {
+      const int n = p >> 3, c = p & 7;
+      const int blk = n / G::PP;
+      const int rem = n - blk * G::PP;
+      const int py = rem / G::PW, px = rem - py * G::PW;
+      const int b = mt * G::NB + blk;
+      const int crop = b / nbpc;
+      const int br = b - crop * nbpc;
+      const int by = br / nbx, bx = br - by * nbx;
+      const int gy = by * BS + py - 1, gx = bx * BS + px - 1;
+      if (b < nblk && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+        off = (unsigned)(((crop * H + gy) * W + gx) * (cin8 * 2) + (c ^ pt_swz_a(py, px)));
+    }
+    poff[k] = off;
+  }
+  const u32x4* zsrc = pt_zero_page + (lane & 15);
+  // weights: instruction (wave * NBL + b) covers 8 rows of the tile; lane = (row in 8, slot in row)
+  const int rsub = lane >> 3, slot8 = lane & 7;
+  unsigned boffl[NBL];  // lane part of the weight source offset (16-byte units); the rest is wave-uniform
+#pragma unroll
+  for (int b = 0; b < NBL; ++b) {
+    const int brw = (wave * NBL + b) * 8 + rsub;
+    boffl[b] = (unsigned)(brw * (cin8 * 2) + (slot8 ^ pt_swz_b(brw)));
+  }
+  const long tapstride_w = (long)Cout * cin8 * 2;
+  const u32x4* wbase = wp + (long)n0 * (cin8 * 2);
+
+  auto issue_patch_round = [&](auto KC, int slab, int pbuf) {  // pbuf: byte offset of the patch buffer in smem
+    constexpr int k = decltype(KC)::value;
+    const u32x4* src = (poff[k] != ~0u) ? in + (poff[k] + (unsigned)(slab * 8)) : zsrc;
+    if constexpr (k < G::FULL) {
+      pt_dma16(src, smem + pbuf + (k * 8 + wave) * 1024);
+    } else {
+      if (lane < G::RL) pt_dma16(src, smem + pbuf + G::FULL * 8192 + wave * (G::RL * 16));
+    }
+  };
+  auto issue_b = [&](int tap, int slab, int ringslot) {
+    // wave-uniform base, laundered through readfirstlane so that it stays in scalar registers and is
+    // not re-associated with the lane offsets into nine hoisted 64-bit lane values
+    const unsigned long ubl = (unsigned long)(wbase + ((long)tap * tapstride_w + slab * 8));
+    const unsigned ub_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(ubl >> 32));
+    const unsigned ub_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ubl);
+    const u32x4* ub = (const u32x4*)(((unsigned long)ub_hi << 32) | (unsigned long)ub_lo);
+#pragma unroll
+    for (int b = 0; b < NBL; ++b)
+      pt_dma16(ub + boffl[b], smem + RING0 + ringslot * B_BYTES + (wave * NBL + b) * 1024);
+  };
+
+  // ---------------- fragment read state --------------------------------------------------------------
+  // A (patch) read of tap (ty, tx), k-step j, lane half h: pixel n = n0 + ty*PW + tx, piece
+  // (4j + 2h) ^ swz(py + ty, px + tx).  swz(.., ty odd) = swz(.., ty even) ^ 4, so per row three lane
+  // values a_sx[tx] = ((swz(py, px + tx) ^ 2h) << 4) cover every tap: byte offset inside the record =
+  // a_sx[tx] ^ (64 * (j ^ (ty & 1))); the tap's pixel offset is an immediate.
+  int a_base[TM], a_sx[TM][3];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    int blk, y, x;
+    pt_row_to_pixel<BS>(wm * TM + tm, lr, blk, y, x);
+    a_base[tm] = (blk * G::PP + y * G::PW + x) * P_ROWB;
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx) a_sx[tm][tx] = (pt_swz_a(y, x + tx) ^ (2 * h)) << 4;
+  }
+  int b_off[TN];  // weight row record + swizzled piece of k-step 0 (k-step 1: ^ 64)
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int r = wn * TN * 32 + tn * 32 + lr;
+    b_off[tn] = r * P_ROWB + (((2 * h) ^ pt_swz_b(r)) << 4);
+  }
+
+  struct Frags {
+    f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+  };
+  auto read_frags = [&](Frags& f, auto TAPC, auto JC, int pb) {
+    constexpr int tap = decltype(TAPC)::value;
+    constexpr int j = decltype(JC)::value;
+    constexpr int ty = tap / 3, tx = tap % 3;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      // record offsets are multiples of 128 and the swizzled piece offset is < 128: xor 16 flips hi <-> lo
+      const int rec = pb + a_base[tm];
+      const int sxo = a_sx[tm][tx] ^ (64 * (j ^ (ty & 1)));
+      constexpr int imm = (ty * G::PW + tx) * P_ROWB;
+      f.ah[tm] = *reinterpret_cast<const f16x8*>(smem + (rec + sxo) + imm);
+      f.al[tm] = *reinterpret_cast<const f16x8*>(smem + (rec + (sxo ^ 16)) + imm);
+    }
+    constexpr int sb = RING0 + (tap % 3) * B_BYTES;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int xo = b_off[tn] ^ (64 * j);
+      f.bh[tn] = *reinterpret_cast<const f16x8*>(smem + xo + sb);
+      f.bl[tn] = *reinterpret_cast<const f16x8*>(smem + (xo ^ 16) + sb);
+    }
+  };
+  // products (tm, tn) [P0, P1) of one 16-channel step: 3 MFMAs each
+  auto mma = [&](const Frags& f, auto P0C, auto P1C) {
+    constexpr int P0 = decltype(P0C)::value, P1 = decltype(P1C)::value;
+#pragma unroll
+    for (int p = P0; p < P1; ++p) {
+      const int tm = p / TN, tn = p % TN;
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[tm], f.bh[tn], acc[tm][tn], 0, 0, 0);
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[tm], f.bl[tn], acc[tm][tn], 0, 0, 0);
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[tm], f.bh[tn], acc[tm][tn], 0, 0, 0);
+    }
+  };
+  constexpr int NPROD = TM * TN;   // 4 / 2
+  constexpr int PC1 = NPROD / 4;   // split points of the load-issuing half stage: 1 / 0
+  constexpr int PC2 = NPROD / 2;   // 2 / 1
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, PC1>;
+  using I2 = std::integral_constant<int, PC2>;
+  using IN = std::integral_constant<int, NPROD>;
+
+  // ---------------- prologue: patch(slab 0), weight stages 0..2 --------------------------------------
+  int pcur = 0;          // patch buffer of the current slab (byte offset in smem)
+  int pnext = G::BYTES;  // patch buffer being filled for the next slab
+  static_assert(G::BYTES % 256 == 0 && RING0 % 256 == 0 && B_BYTES % 256 == 0, "hi/lo xor addressing");
+  {
+    issue_patch_round(std::integral_constant<int, 0>{}, 0, pcur);
+    issue_patch_round(std::integral_constant<int, 1>{}, 0, pcur);
+    issue_patch_round(std::integral_constant<int, 2>{}, 0, pcur);
+    issue_patch_round(std::integral_constant<int, 3>{}, 0, pcur);
+    issue_patch_round(std::integral_constant<int, 4>{}, 0, pcur);
+    issue_patch_round(std::integral_constant<int, 5>{}, 0, pcur);
+    if constexpr (G::PA > 6) issue_patch_round(std::integral_constant<int, 6>{}, 0, pcur);
+    issue_b(0, 0, 0);
+    issue_b(1, 0, 1);
+    issue_b(2, 0, 2);
+    pt_wait_vm<2 * NBL>();  // patch + weight stage 0 landed (this wave's part)
+    __builtin_amdgcn_s_barrier();
+  }
+  Frags f0, f1;
+  read_frags(f0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, pcur);
+
+  // One stage = one (slab, tap): 2 k-steps of 16 channels.  Weight stage t+3 is issued after the
+  // barrier of stage t (its ring slot was last read by stage t); the patch of the next slab is issued
+  // round by round in taps 0..PA-1, BEFORE the weights of the same stage so that the counted vmcnt of
+  // a later barrier retires it as well.
+  auto stage = [&](auto TAPC, auto LASTC, int slab) {
+    constexpr int tap = decltype(TAPC)::value;
+    constexpr bool last = decltype(LASTC)::value;
+    // loads this wave issued one stage earlier (they may stay in flight across this stage's barrier)
+    constexpr int ptap = (tap + 8) % 9;  // tap of the previous stage
+    constexpr int prev_issued =
+        (tap == 0) ? NBL  // previous stage = tap 8 of a non-last slab (or the prologue's stage-2 weights)
+                   : ((last ? 0 : (ptap < G::PA ? 1 : 0)) + ((last && ptap + 3 > 8) ? 0 : NBL));
+    // first half: the second 16-channel step is read under the MFMAs of the first
+    // (the first product goes ahead of the reads: its operand wait must not cover the reads just issued)
+    mma(f0, I0{}, std::integral_constant<int, 1>{});
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(f1, TAPC, std::integral_constant<int, 1>{}, pcur);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(f0, std::integral_constant<int, 1>{}, IN{});
+    __builtin_amdgcn_sched_barrier(0);
+    pt_wait_vm<prev_issued>();  // weights of stage t+1 (and every older load) landed
+    // lgkmcnt(0) as a compiler-visible s_waitcnt (vmcnt 63 / expcnt 7 / lgkmcnt 0): the waitcnt pass then
+    // knows the second step's fragments have landed and does not re-wait after the next reads are issued
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    // second half: first step of the next stage is read, then this stage's loads are issued between MFMAs
+    if constexpr (tap < 8) {
+      read_frags(f0, std::integral_constant<int, tap + 1>{}, std::integral_constant<int, 0>{}, pcur);
+    } else if constexpr (!last) {
+      read_frags(f0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, pnext);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mma(f1, I0{}, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!last && tap < G::PA) issue_patch_round(TAPC, slab + 1, pnext);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(f1, I1{}, I2{});
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!last) {
+      issue_b((tap + 3) % 9, slab + (tap + 3) / 9, tap % 3);
+    } else if constexpr (tap + 3 <= 8) {
+      issue_b(tap + 3, slab, tap % 3);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mma(f1, I2{}, IN{});
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto slab_body = [&](auto LASTC, int slab) {
+    stage(std::integral_constant<int, 0>{}, LASTC, slab);
+    stage(std::integral_constant<int, 1>{}, LASTC, slab);
+    stage(std::integral_constant<int, 2>{}, LASTC, slab);
+    stage(std::integral_constant<int, 3>{}, LASTC, slab);
+    stage(std::integral_constant<int, 4>{}, LASTC, slab);
+    stage(std::integral_constant<int, 5>{}, LASTC, slab);
+    stage(std::integral_constant<int, 6>{}, LASTC, slab);
+    stage(std::integral_constant<int, 7>{}, LASTC, slab);
+    stage(std::integral_constant<int, 8>{}, LASTC, slab);
+  };
+  for (int slab = 0; slab < nslab - 1; ++slab) {
+    slab_body(std::false_type{}, slab);
+    const int t = pcur;
+    pcur = pnext;
+    pnext = t;
+  }
+  slab_body(std::true_type{}, nslab - 1);
+
+  // ---- epilogue: accumulators -> LDS fp32 [256][BN+4] -> pool/bias/relu/split -> hl16 -------------
+  __syncthreads();  // every wave is past its last LDS read; no DMA in flight (the last stages drained)
+  float* Cs = reinterpret_cast<float*>(smem);
+  constexpr int UN = BN / 8;
+  const int cout8 = Cout >> 3;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        Cs[((wm * TM + tm) * 32 + mm_acc_row(e, lane)) * CLD + wn * TN * 32 + tn * 32 + lr] = acc[tm][tn][e];
+  __syncthreads();
+  if constexpr (POOL) {
+    const int Hq = H >> 1, Wq = W >> 1;
+    for (int w = tid; w < (P_BM / 4) * UN; w += 512) {
+      const int qd = w / UN, u = w - qd * UN;
+      int blk, y, x;
+      pt_row_to_pixel<BS>(qd >> 3, (qd & 7) * 4, blk, y, x);
+      const int b = mt * G::NB + blk;
+      const int crop = b / nbpc;
+      const int br = b - crop * nbpc;
+      const int by = br / nbx, bx = br - by * nbx;
+      const int gy = by * BS + y, gx = bx * BS + x;
+      if (b < nblk && gy < H && gx < W) {
+        const float* c = &Cs[(qd * 4) * CLD + u * 8];
+        f32x8 v = *reinterpret_cast<const f32x8*>(c);
+#pragma unroll
+        for (int r = 1; r < 4; ++r) {
+          const f32x8 w2 = *reinterpret_cast<const f32x8*>(c + r * CLD);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], w2[e]);
+        }
+        const f32x8 bv = *reinterpret_cast<const f32x8*>(&bias[n0 + u * 8]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], oscale, bv[e]), 0.f);
+        u32x4 hi, lo;
+        pt_split8(v, hi, lo);
+        const long pix = ((long)crop * Hq + (gy >> 1)) * Wq + (gx >> 1);
+        u32x4* o = out + (pix * cout8 + (n0 >> 3) + u) * 2;
+        o[0] = hi;
+        o[1] = lo;
+      }
+    }
+  } else {
+    for (int w = tid; w < P_BM * UN; w += 512) {
+      const int r = w / UN, u = w - r * UN;
+      int blk, y, x;
+      pt_row_to_pixel<BS>(r >> 5, r & 31, blk, y, x);
+      const int b = mt * G::NB + blk;
+      const int crop = b / nbpc;
+      const int br = b - crop * nbpc;
+      const int by = br / nbx, bx = br - by * nbx;
+      const int gy = by * BS + y, gx = bx * BS + x;
+      if (b < nblk && gy < H && gx < W) {
+        f32x8 v = *reinterpret_cast<const f32x8*>(&Cs[r * CLD + u * 8]);
+        const f32x8 bv = *reinterpret_cast<const f32x8*>(&bias[n0 + u * 8]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], oscale, bv[e]), 0.f);
+        u32x4 hi, lo;
+        pt_split8(v, hi, lo);
+        const long pix = ((long)crop * H + gy) * W + gx;
+        u32x4* o = out + (pix * cout8 + (n0 >> 3) + u) * 2;
+        o[0] = hi;
+        o[1] = lo;
+      }
+    }
+  }
+}
+
+template <int BN, int BS, bool POOL>
+static int launch_patch(const void* in, const void* wp, const float* bias, void* out, int L, int H, int W, int Cin,
+                        int Cout, float oscale, hipStream_t s) {
+  const int nby = (H + BS - 1) / BS, nbx = (W + BS - 1) / BS;
+  const int nblk = L * nby * nbx;
+  constexpr int NB = PatchGeom<BS>::NB;
+  const int ntm = (nblk + NB - 1) / NB;
+  const int ntn = Cout / BN;
+  hipLaunchKernelGGL((conv3x3_hl16_patch_kernel<BN, BS, POOL>), dim3(ntm * ntn), dim3(512), 0, s, (const u32x4*)in,
+                     (const u32x4*)wp, bias, (u32x4*)out, L, H, W, Cin, Cout, nby, nbx, nblk, ntm, ntn, oscale);
+  return mm_check(hipGetLastError());
+}
+
+template <int BN, int BS>
+static int launch_patch_p(int pool, const void* in, const void* wp, const float* bias, void* out, int L, int H, int W,
+                          int Cin, int Cout, float oscale, hipStream_t s) {
+  return pool ? launch_patch<BN, BS, true>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s)
+              : launch_patch<BN, BS, false>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
+}
+
+// Same contract as mmmot_conv3x3_bn_relu_hl16 (Cin % 32 == 0, Cout % 64 == 0, H and W even).
+extern "C" int mmmot_conv3x3_bn_relu_hl16_patch(const void* in, const void* wp, const float* bias, void* out, int L,
+                                                int H, int W, int Cin, int Cout, int pool, float oscale,
+                                                void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!in || !wp || !bias || !out || L <= 0 || H <= 0 || W <= 0) return MMMOT_EINVAL;
+  if ((H & 1) || (W & 1) || Cin % 32 != 0 || Cout % 64 != 0) return MMMOT_EINVAL;
+  if (!mm_al16(in) || !mm_al16(wp) || !mm_al16(out)) return MMMOT_EINVAL;
+  if ((long)L * H * W * (Cin / 4) >= (1L << 31) - 64) return MMMOT_EINVAL;  // 32-bit piece offsets
+  const bool big = (H > 8 || W > 8);  // 16x16 blocks unless the whole map fits an 8x8 block
+  if (Cout % 128 == 0)
+    return big ? launch_patch_p<128, 16>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s)
+               : launch_patch_p<128, 8>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
+  return big ? launch_patch_p<64, 16>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s)
+             : launch_patch_p<64, 8>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
+}

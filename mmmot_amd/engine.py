@@ -11,6 +11,8 @@ chain of  GEMM(+stats epilogue) -> finalize -> next GEMM(normalise prologue).
 ``ops`` is the operator backend: ``mmmot_amd.ops.HipOps`` in the product.  The
 engine itself only allocates memory and orders launches.
 """
+import os
+
 import torch
 
 from .ops import (ACT_NONE, ACT_RELU, ACT_SIGMOID, A_NORM_RELU, A_PAIR, A_PLAIN, FUSION_MODES, PAIR_OPS,
@@ -25,6 +27,11 @@ class Engine:
         if trunk not in ('f16x3', 'f32'):
             raise ValueError("trunk must be 'f16x3' (fp16 matrix cores, 3-term split) or 'f32' (exact fp32 MFMA)")
         self.trunk = trunk
+        # machine mapping of the hl16 trunk layers (same arithmetic): 'patch' = LDS-resident haloed patch
+        # (conv3x3_hl16_patch.hip, fastest), 'tile' = register-staged 128-row tiles, 'dma' = LDS-DMA ring
+        self.conv_impl = os.environ.get('MMMOT_CONV', 'patch')
+        if self.conv_impl not in ('patch', 'tile', 'dma'):
+            raise ValueError("MMMOT_CONV must be 'patch', 'tile' or 'dma'")
         self.mlp = trunk  # the 1x1-conv / linear GEMMs follow the same arithmetic choice
         if affinity_op not in PAIR_OPS:
             raise ValueError('unknown affinity_op %r' % (affinity_op,))
@@ -93,8 +100,9 @@ class Engine:
             elif li == 0:
                 ops.conv3x3_first_hl16(x, cv['wp'], cv['bias'], out, Lt, H, W, cv['cout'])
             else:
-                ops.conv3x3_hl16(x, cv['wp16'], cv['bias'], out, Lt, H, W, cv['cin'], cv['cout'], cv['pool'],
-                                 cv['oscale'])
+                conv = {'patch': ops.conv3x3_hl16_patch, 'tile': ops.conv3x3_hl16,
+                        'dma': ops.conv3x3_hl16_dma}[self.conv_impl]
+                conv(x, cv['wp16'], cv['bias'], out, Lt, H, W, cv['cin'], cv['cout'], cv['pool'], cv['oscale'])
             if self.conv_events is not None:
                 e1.record()
                 self.conv_events.append((li, Lt * H * W, cv['cin'], cv['cout'], e0, e1))

@@ -73,6 +73,12 @@ class HipOps:
                                                      Cout, int(pool), float(oscale), self._stream())
         _lib.check(st, 'mmmot_conv3x3_bn_relu_hl16_dma')
 
+    def conv3x3_hl16_patch(self, inp, wp, bias, out, L, H, W, Cin, Cout, pool, oscale):
+        """Same contract as conv3x3_hl16; LDS-resident haloed patch kernel (256 pixels per workgroup)."""
+        st = self.lib.mmmot_conv3x3_bn_relu_hl16_patch(_ptr(inp), _ptr(wp), _ptr(bias), _ptr(out), L, H, W, Cin,
+                                                       Cout, int(pool), float(oscale), self._stream())
+        _lib.check(st, 'mmmot_conv3x3_bn_relu_hl16_patch')
+
     def conv3x3_first_hl16(self, inp, wp, bias, out, L, H, W, Cout):
         st = self.lib.mmmot_conv3x3_first_hl16(_ptr(inp), _ptr(wp), _ptr(bias), _ptr(out), L, H, W, Cout,
                                                self._stream())

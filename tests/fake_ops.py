@@ -51,6 +51,12 @@ class TorchOps:
         out.view(L, y.shape[2], y.shape[3], Cout).copy_(y.permute(0, 2, 3, 1).to(out.dtype))
 
     # ---- hl16 (fp16 hi/lo split) trunk: same conv, operands/outputs stored split-half ----------
+    def conv3x3_hl16_patch(self, *a):
+        return self.conv3x3_hl16(*a)
+
+    def conv3x3_hl16_dma(self, *a):
+        return self.conv3x3_hl16(*a)
+
     def conv3x3_hl16(self, inp, wp, bias, out, L, H, W, Cin, Cout, pool, oscale):
         from mmmot_amd.pack import from_hl16, to_hl16
         x = from_hl16(inp.reshape(-1)[:L * H * W * Cin].view(L * H * W, Cin)).view(L, H, W, Cin).permute(0, 3, 1, 2)

@@ -1,0 +1,73 @@
+"""The LDS-resident-patch trunk kernel (conv3x3_hl16_patch.hip) must agree with the fp64 convolution like the
+register-staged kernel does (same arithmetic, different machine mapping).  Geometry cases exercise both block
+shapes (16x16x1, 8x8x4), partial blocks (maps that are not multiples of the block), maps smaller than a block,
+tiles that straddle crops, partial last tiles and 2..16 channel slabs."""
+import pytest
+import torch
+
+from fake_ops import TorchOps
+from mmmot_amd.pack import from_hl16, hl16_weight_shift, to_hl16
+from test_kernels_gpu import close, hip, rnd  # noqa: F401  (hip is a fixture)
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # pool L  H   W  Cin Cout
+    (1, 2, 8, 8, 64, 64),        # 8x8 blocks, half-filled tile (2 of 4 blocks)
+    (0, 5, 8, 8, 32, 128),       # 8x8 blocks, tile straddles crops, partial last tile, single slab
+    (1, 3, 4, 4, 128, 256),      # map smaller than a block
+    (0, 3, 2, 2, 64, 64),        # 2x2 maps (S=32 crops at conv5)
+    (0, 5, 6, 10, 64, 64),       # 16x16 blocks, partial block
+    (1, 2, 14, 14, 64, 128),     # 14x14 (S=224 crops at conv5)
+    (0, 1, 16, 16, 256, 512),    # exactly one block per crop, 4 channel tiles
+    (1, 2, 32, 32, 128, 128),    # 2x2 blocks per crop
+    (0, 2, 28, 20, 64, 64),      # partial blocks on both axes
+    (1, 9, 4, 4, 512, 512),      # 16 slabs
+    (1, 1, 64, 64, 64, 64),      # conv1_2-like
+]
+
+
+def run_case(hip, pool, L, H, W, Cin, Cout, seed=430):
+    x = torch.relu(rnd(L * H * W, Cin, seed=seed)) * 3.0
+    w = rnd(9, Cout, Cin, seed=seed + 1, scale=(2.0 / (9 * Cin)) ** 0.5)
+    bias = rnd(Cout, seed=seed + 2, scale=0.1)
+    shift = hl16_weight_shift(w)
+    x16, w16 = to_hl16(x), to_hl16(w.double() * 2.0 ** shift)
+    emu = TorchOps(torch.float64)
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    ref = torch.zeros(L * Ho * Wo, Cout)
+    emu.conv3x3(from_hl16(x16).view(L, H, W, Cin), (from_hl16(w16) * 2.0 ** -shift), bias, ref, L, H, W, Cin, Cout,
+                False, bool(pool))
+    out16 = torch.full((L * Ho * Wo, Cout), float('nan')).cuda()
+    hip.conv3x3_hl16_patch(x16.cuda(), w16.cuda(), bias.cuda(), out16, L, H, W, Cin, Cout, bool(pool), 2.0 ** -shift)
+    out = torch.zeros_like(out16)
+    hip.hl16_unpack(out16, out)
+    return out, ref, (x16, w16, bias, shift)
+
+
+@pytest.mark.parametrize('pool,L,H,W,Cin,Cout', CASES)
+def test_conv3x3_hl16_patch(hip, pool, L, H, W, Cin, Cout):
+    out, ref, _ = run_case(hip, pool, L, H, W, Cin, Cout)
+    close(out, ref, 2e-6, 'conv3x3 hl16 patch kernel vs fp64')
+
+
+def test_patch_matches_tile_kernel_and_is_deterministic(hip):
+    """Same inputs through the register-staged tile kernel: fp32 accumulation order differs (32- vs 64-channel
+    slabs), values must agree to fp32 rounding; repeated launches of the patch kernel are bitwise identical
+    (no race in the DMA ring / counted-vmcnt pipeline)."""
+    pool, L, H, W, Cin, Cout = 0, 6, 16, 16, 256, 256
+    out, ref, (x16, w16, bias, shift) = run_case(hip, pool, L, H, W, Cin, Cout, seed=440)
+    o_tile = torch.zeros(L * H * W, Cout).cuda()
+    hip.conv3x3_hl16(x16.cuda(), w16.cuda(), bias.cuda(), o_tile, L, H, W, Cin, Cout, False, 2.0 ** -shift)
+    t = torch.zeros_like(o_tile)
+    hip.hl16_unpack(o_tile, t)
+    close(out, t, 2e-6, 'patch kernel vs tile kernel')
+    xs, ws, bs = x16.cuda(), w16.cuda(), bias.cuda()
+    first = None
+    for _ in range(20):
+        o = torch.zeros(L * H * W, Cout).cuda()
+        hip.conv3x3_hl16_patch(xs, ws, bs, o, L, H, W, Cin, Cout, False, 2.0 ** -shift)
+        if first is None:
+            first = o.clone()
+        else:
+            assert torch.equal(first, o), 'patch kernel is not deterministic across launches'

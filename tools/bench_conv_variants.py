@@ -25,14 +25,15 @@ LAYERS = [  # (L, H, W, Cin, Cout, pool) at cfg3 (128 crops of 128x128)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--rounds', type=int, default=5)
-    ap.add_argument('--variants', default='1,4,7', help='1 = 128-row tiles, 4 = 256-row tiles, 7..10 = LDS-DMA kernel variants 0..3')
+    ap.add_argument('--crops', type=int, default=128, help='crops per launch (128 = one cfg3 pair)')
+    ap.add_argument('--variants', default='1,11', help='1 = 128-row tiles, 4 = 256-row tiles, 7..10 = LDS-DMA kernel variants 0..3, 11 = LDS-patch kernel')
     args = ap.parse_args()
     ops = HipOps()
     lib = _lib.load()
     variants = [int(v) for v in args.variants.split(',')]
     g = torch.Generator().manual_seed(0)
     res = {}
-    for (L, H, W, Cin, Cout, pool) in LAYERS:
+    for (L, H, W, Cin, Cout, pool) in [(args.crops,) + l[1:] for l in LAYERS]:
         x = torch.relu(torch.randn(L * H * W, Cin, generator=g)).cuda()
         x16 = torch.empty_like(x)
         ops.hl16_pack(x, x16)
@@ -47,11 +48,13 @@ def main():
         for r in range(args.rounds + 1):
             for v in variants:
                 lib.mmmot_set_conv_variant(v if v < 7 else 0)
-                lib.mmmot_set_dma_variant(v - 7 if v >= 7 else 0)  # 7..10 = DMA kernel variants 0..3
+                lib.mmmot_set_dma_variant(v - 7 if 7 <= v <= 10 else 0)  # 7..10 = DMA kernel variants 0..3
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 out.fill_(float('nan'))
                 e0.record()
-                if v >= 7:  # LDS-DMA producer/consumer kernel (its own entry point)
+                if v == 11:  # LDS-resident patch kernel
+                    ops.conv3x3_hl16_patch(x16, w16, bias, out, L, H, W, Cin, Cout, bool(pool), 2.0 ** -shift)
+                elif v >= 7:  # LDS-DMA producer/consumer kernel (its own entry point)
                     ops.conv3x3_hl16_dma(x16, w16, bias, out, L, H, W, Cin, Cout, bool(pool), 2.0 ** -shift)
                 else:
                     ops.conv3x3_hl16(x16, w16, bias, out, L, H, W, Cin, Cout, bool(pool), 2.0 ** -shift)
@@ -79,6 +82,7 @@ def main():
     lib.mmmot_debug_read_phase_timers(buf, 1)
     lib.mmmot_set_conv_variant(3)
     L, H, W, Cin, Cout, pool = LAYERS[2]
+    L = args.crops
     x16 = torch.zeros(L * H * W, Cin).cuda()
     w16 = torch.zeros(9, Cout, Cin).cuda()
     out = torch.empty(L * H * W, Cout).cuda()
@@ -95,7 +99,7 @@ def main():
     print('%-8s' % 'variant' + ''.join('%22s' % ('%dx%d %d->%d%s' % (l[1], l[2], l[3], l[4], ' P' if l[5] else '')) for l in LAYERS))
     for v in variants:
         row = '%-8d' % v
-        for l in LAYERS:
+        for l in [(args.crops,) + l[1:] for l in LAYERS]:
             ts = sorted(t for t, _ in res[(v, l)])
             med = ts[len(ts) // 2]
             row += '%12.3f ms %6.1f' % (med, res[(v, l)][0][1] / (med * 1e-3) / 1e12)
