@@ -112,6 +112,7 @@ int mmmot_conv3x3_bn_relu_hl16_dma(const void* in, const void* wp, const float* 
 int mmmot_conv3x3_bn_relu_hl16_patch(const void* in, const void* wp, const float* bias, void* out,
                                      int L, int H, int W, int Cin, int Cout, int pool, float oscale,
                                      void* stream);
+int mmmot_set_patch_variant(int v); /* timing experiments of the patch kernel (0 = product; 1..4 give WRONG results) */
 int mmmot_set_dma_variant(int v); /* tuning / experiment knob of the LDS-DMA kernel (0 = default) */
 int mmmot_conv3x3_first_hl16(const float* in, const float* wp, const float* bias, void* out,
                              int L, int H, int W, int Cout, void* stream);

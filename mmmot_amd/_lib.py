@@ -57,6 +57,7 @@ SIGNATURES = {
     'mmmot_conv3x3_first_hl16': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
     'mmmot_set_conv_variant': [c_i],
     'mmmot_set_dma_variant': [c_i],
+    'mmmot_set_patch_variant': [c_i],
     'mmmot_debug_read_phase_timers': [ctypes.POINTER(ctypes.c_ulonglong), c_i],
     'mmmot_hl16_pack': [c_f, c_f, ctypes.c_long, c_f],
     'mmmot_hl16_unpack': [c_f, c_f, ctypes.c_long, c_f],

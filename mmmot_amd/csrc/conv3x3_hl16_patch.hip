@@ -86,7 +86,9 @@ __device__ __forceinline__ void pt_row_to_pixel(int g, int i, int& blk, int& y, 
   }
 }
 
-template <int BN, int BS, bool POOL>
+// EXP: timing experiments only (WRONG results unless 0): 1 = no loads in the K loop, 2 = no barriers in
+// the K loop, 3 = no fragment reads in the K loop, 4 = no MFMAs
+template <int BN, int BS, bool POOL, int EXP>
 __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     const u32x4* __restrict__ in, const u32x4* __restrict__ wp, const float* __restrict__ bias,
     u32x4* __restrict__ out, int L, int H, int W, int Cin, int Cout, int nby, int nbx, int nblk, int ntm, int ntn,
@@ -187,16 +189,22 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
       if (lane < G::RL) pt_dma16(src, smem + pbuf + G::FULL * 8192 + wave * (G::RL * 16));
     }
   };
-  auto issue_b = [&](int tap, int slab, int ringslot) {
-    // wave-uniform base, laundered through readfirstlane so that it stays in scalar registers and is
-    // not re-associated with the lane offsets into nine hoisted 64-bit lane values
-    const unsigned long ubl = (unsigned long)(wbase + ((long)tap * tapstride_w + slab * 8));
-    const unsigned ub_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(ubl >> 32));
-    const unsigned ub_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ubl);
-    const u32x4* ub = (const u32x4*)(((unsigned long)ub_hi << 32) | (unsigned long)ub_lo);
-#pragma unroll
-    for (int b = 0; b < NBL; ++b)
+  // weight DMA instruction b (0..NBL-1) of stage (tap, slab) into ring slot `ringslot`
+  auto issue_b1 = [&](auto BC, int tap, int slab, int ringslot) {
+    constexpr int b = decltype(BC)::value;
+    if constexpr (b < NBL) {
+      // wave-uniform base, laundered through readfirstlane so that it stays in scalar registers and is
+      // not re-associated with the lane offsets into nine hoisted 64-bit lane values
+      const unsigned long ubl = (unsigned long)(wbase + ((long)tap * tapstride_w + slab * 8));
+      const unsigned ub_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(ubl >> 32));
+      const unsigned ub_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ubl);
+      const u32x4* ub = (const u32x4*)(((unsigned long)ub_hi << 32) | (unsigned long)ub_lo);
       pt_dma16(ub + boffl[b], smem + RING0 + ringslot * B_BYTES + (wave * NBL + b) * 1024);
+    }
+  };
+  auto issue_b = [&](int tap, int slab, int ringslot) {
+    issue_b1(std::integral_constant<int, 0>{}, tap, slab, ringslot);
+    issue_b1(std::integral_constant<int, 1>{}, tap, slab, ringslot);
   };
 
   // ---------------- fragment read state --------------------------------------------------------------
@@ -220,48 +228,64 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     b_off[tn] = r * P_ROWB + (((2 * h) ^ pt_swz_b(r)) << 4);
   }
 
+  using I0 = std::integral_constant<int, 0>;
   struct Frags {
     f16x8 ah[TM], al[TM], bh[TN], bl[TN];
   };
-  auto read_frags = [&](Frags& f, auto TAPC, auto JC, int pb) {
+  constexpr int NPROD = TM * TN;          // products per 16-channel step: 4 / 2
+  constexpr int NMMA = 3 * NPROD;         // MFMAs per half stage: 12 / 6
+  constexpr int NRD = 2 * TM + 2 * TN;    // ds_read_b128 per half stage: 8 / 6
+  // one fragment read: r < 2*TM -> activation row block r/2 (hi, lo); else weight row block (hi, lo)
+  auto read_one = [&](Frags& f, auto RC, auto TAPC, auto JC, int pb) {
+    constexpr int r = decltype(RC)::value;
     constexpr int tap = decltype(TAPC)::value;
     constexpr int j = decltype(JC)::value;
     constexpr int ty = tap / 3, tx = tap % 3;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
+    if constexpr (EXP == 3) {
+      if (pb != 0) return;  // only the prologue read (pb == 0) fills the fragments
+    }
+    if constexpr (r < 2 * TM) {
+      constexpr int tm = r / 2;
       // record offsets are multiples of 128 and the swizzled piece offset is < 128: xor 16 flips hi <-> lo
       const int rec = pb + a_base[tm];
       const int sxo = a_sx[tm][tx] ^ (64 * (j ^ (ty & 1)));
       constexpr int imm = (ty * G::PW + tx) * P_ROWB;
-      f.ah[tm] = *reinterpret_cast<const f16x8*>(smem + (rec + sxo) + imm);
-      f.al[tm] = *reinterpret_cast<const f16x8*>(smem + (rec + (sxo ^ 16)) + imm);
-    }
-    constexpr int sb = RING0 + (tap % 3) * B_BYTES;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
+      if constexpr (r % 2 == 0) f.ah[tm] = *reinterpret_cast<const f16x8*>(smem + (rec + sxo) + imm);
+      else f.al[tm] = *reinterpret_cast<const f16x8*>(smem + (rec + (sxo ^ 16)) + imm);
+    } else {
+      constexpr int tn = (r - 2 * TM) / 2;
+      constexpr int sb = RING0 + (tap % 3) * B_BYTES;
       const int xo = b_off[tn] ^ (64 * j);
-      f.bh[tn] = *reinterpret_cast<const f16x8*>(smem + xo + sb);
-      f.bl[tn] = *reinterpret_cast<const f16x8*>(smem + (xo ^ 16) + sb);
+      if constexpr (r % 2 == 0) f.bh[tn] = *reinterpret_cast<const f16x8*>(smem + xo + sb);
+      else f.bl[tn] = *reinterpret_cast<const f16x8*>(smem + (xo ^ 16) + sb);
     }
   };
-  // products (tm, tn) [P0, P1) of one 16-channel step: 3 MFMAs each
-  auto mma = [&](const Frags& f, auto P0C, auto P1C) {
-    constexpr int P0 = decltype(P0C)::value, P1 = decltype(P1C)::value;
-#pragma unroll
-    for (int p = P0; p < P1; ++p) {
-      const int tm = p / TN, tn = p % TN;
+  // one MFMA of a half stage, term-major so that consecutive MFMAs hit different accumulators:
+  // i -> term i / NPROD (lo*hi, hi*lo, hi*hi), product i % NPROD
+  auto mma_one = [&](const Frags& f, auto IC) {
+    constexpr int i = decltype(IC)::value;
+    if constexpr (EXP == 4) return;
+    constexpr int term = i / NPROD, p = i % NPROD;
+    constexpr int tm = p / TN, tn = p % TN;
+    if constexpr (term == 0)
       acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[tm], f.bh[tn], acc[tm][tn], 0, 0, 0);
+    else if constexpr (term == 1)
       acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[tm], f.bl[tn], acc[tm][tn], 0, 0, 0);
+    else
       acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[tm], f.bh[tn], acc[tm][tn], 0, 0, 0);
+  };
+  auto read_frags = [&](Frags& f, auto TAPC, auto JC, int pb) {  // all reads of a half stage (prologue)
+    read_one(f, std::integral_constant<int, 0>{}, TAPC, JC, pb);
+    read_one(f, std::integral_constant<int, 1>{}, TAPC, JC, pb);
+    read_one(f, std::integral_constant<int, 2>{}, TAPC, JC, pb);
+    read_one(f, std::integral_constant<int, 3>{}, TAPC, JC, pb);
+    read_one(f, std::integral_constant<int, 4>{}, TAPC, JC, pb);
+    read_one(f, std::integral_constant<int, 5>{}, TAPC, JC, pb);
+    if constexpr (NRD > 6) {
+      read_one(f, std::integral_constant<int, 6>{}, TAPC, JC, pb);
+      read_one(f, std::integral_constant<int, 7>{}, TAPC, JC, pb);
     }
   };
-  constexpr int NPROD = TM * TN;   // 4 / 2
-  constexpr int PC1 = NPROD / 4;   // split points of the load-issuing half stage: 1 / 0
-  constexpr int PC2 = NPROD / 2;   // 2 / 1
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, PC1>;
-  using I2 = std::integral_constant<int, PC2>;
-  using IN = std::integral_constant<int, NPROD>;
 
   // ---------------- prologue: patch(slab 0), weight stages 0..2 --------------------------------------
   int pcur = 0;          // patch buffer of the current slab (byte offset in smem)
@@ -296,40 +320,77 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     constexpr int prev_issued =
         (tap == 0) ? NBL  // previous stage = tap 8 of a non-last slab (or the prologue's stage-2 weights)
                    : ((last ? 0 : (ptap < G::PA ? 1 : 0)) + ((last && ptap + 3 > 8) ? 0 : NBL));
-    // first half: the second 16-channel step is read under the MFMAs of the first
-    // (the first product goes ahead of the reads: its operand wait must not cover the reads just issued)
-    mma(f0, I0{}, std::integral_constant<int, 1>{});
-    __builtin_amdgcn_sched_barrier(0);
-    read_frags(f1, TAPC, std::integral_constant<int, 1>{}, pcur);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(f0, std::integral_constant<int, 1>{}, IN{});
-    __builtin_amdgcn_sched_barrier(0);
-    pt_wait_vm<prev_issued>();  // weights of stage t+1 (and every older load) landed
+    // Half stages are written as ONE MFMA + ONE other instruction at a time (sched_barrier pins the order):
+    // the two waves of a SIMD run in lockstep after every barrier, so any run of non-MFMA issue (8 ds_reads,
+    // an LDS-DMA with its address math) leaves the matrix pipe idle unless it is cut into MFMA-sized gaps.
+    // first half: MFMAs of the first 16-channel step, fragments of the second step read underneath
+    auto half1 = [&](auto IC) {
+      constexpr int i = decltype(IC)::value;
+      if constexpr (i < NMMA) {
+        mma_one(f0, IC);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (i < NRD) {
+        read_one(f1, IC, TAPC, std::integral_constant<int, 1>{}, pcur);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    half1(std::integral_constant<int, 0>{});
+    half1(std::integral_constant<int, 1>{});
+    half1(std::integral_constant<int, 2>{});
+    half1(std::integral_constant<int, 3>{});
+    half1(std::integral_constant<int, 4>{});
+    half1(std::integral_constant<int, 5>{});
+    half1(std::integral_constant<int, 6>{});
+    half1(std::integral_constant<int, 7>{});
+    half1(std::integral_constant<int, 8>{});
+    half1(std::integral_constant<int, 9>{});
+    half1(std::integral_constant<int, 10>{});
+    half1(std::integral_constant<int, 11>{});
+    if constexpr (EXP != 1) pt_wait_vm<prev_issued>();  // weights of stage t+1 (and every older load) landed
     // lgkmcnt(0) as a compiler-visible s_waitcnt (vmcnt 63 / expcnt 7 / lgkmcnt 0): the waitcnt pass then
     // knows the second step's fragments have landed and does not re-wait after the next reads are issued
     __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_s_barrier();
-    // second half: first step of the next stage is read, then this stage's loads are issued between MFMAs
-    if constexpr (tap < 8) {
-      read_frags(f0, std::integral_constant<int, tap + 1>{}, std::integral_constant<int, 0>{}, pcur);
-    } else if constexpr (!last) {
-      read_frags(f0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, pnext);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    mma(f1, I0{}, I1{});
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!last && tap < G::PA) issue_patch_round(TAPC, slab + 1, pnext);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(f1, I1{}, I2{});
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!last) {
-      issue_b((tap + 3) % 9, slab + (tap + 3) / 9, tap % 3);
-    } else if constexpr (tap + 3 <= 8) {
-      issue_b(tap + 3, slab, tap % 3);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    mma(f1, I2{}, IN{});
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (EXP != 2) __builtin_amdgcn_s_barrier();
+    // second half: MFMAs of the second step; first step of the next stage read underneath; this stage's
+    // loads (patch round first, then the weights of stage t+3) issued at three spread-out points
+    auto half2 = [&](auto IC) {
+      constexpr int i = decltype(IC)::value;
+      if constexpr (i < NMMA) {
+        mma_one(f1, IC);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (i < NRD) {
+        if constexpr (tap < 8) read_one(f0, IC, std::integral_constant<int, (tap + 1) % 9>{}, I0{}, pcur);
+        else if constexpr (!last) read_one(f0, IC, I0{}, I0{}, pnext);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (EXP != 1) {
+        constexpr int at_patch = (NMMA >= 12) ? 2 : 1, at_b0 = (NMMA >= 12) ? 6 : 4, at_b1 = 10;
+        if constexpr (i == at_patch) {
+          if constexpr (!last && tap < G::PA) issue_patch_round(TAPC, slab + 1, pnext);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (i == at_b0 || (i == at_b1 && NBL > 1)) {
+          using BI = std::integral_constant<int, (i == at_b0) ? 0 : 1>;
+          if constexpr (!last) issue_b1(BI{}, (tap + 3) % 9, slab + (tap + 3) / 9, tap % 3);
+          else if constexpr (tap + 3 <= 8) issue_b1(BI{}, tap + 3, slab, tap % 3);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
+    half2(std::integral_constant<int, 0>{});
+    half2(std::integral_constant<int, 1>{});
+    half2(std::integral_constant<int, 2>{});
+    half2(std::integral_constant<int, 3>{});
+    half2(std::integral_constant<int, 4>{});
+    half2(std::integral_constant<int, 5>{});
+    half2(std::integral_constant<int, 6>{});
+    half2(std::integral_constant<int, 7>{});
+    half2(std::integral_constant<int, 8>{});
+    half2(std::integral_constant<int, 9>{});
+    half2(std::integral_constant<int, 10>{});
+    half2(std::integral_constant<int, 11>{});
   };
   auto slab_body = [&](auto LASTC, int slab) {
     stage(std::integral_constant<int, 0>{}, LASTC, slab);
@@ -420,17 +481,39 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   }
 }
 
-template <int BN, int BS, bool POOL>
-static int launch_patch(const void* in, const void* wp, const float* bias, void* out, int L, int H, int W, int Cin,
+static int g_patch_exp = 0;
+extern "C" int mmmot_set_patch_variant(int v) {
+  if (v < 0 || v > 4) return MMMOT_EINVAL;
+  g_patch_exp = v;
+  return MMMOT_OK;
+}
+
+template <int BN, int BS, bool POOL, int EXP>
+static int launch_patch_e(const void* in, const void* wp, const float* bias, void* out, int L, int H, int W, int Cin,
                         int Cout, float oscale, hipStream_t s) {
   const int nby = (H + BS - 1) / BS, nbx = (W + BS - 1) / BS;
   const int nblk = L * nby * nbx;
   constexpr int NB = PatchGeom<BS>::NB;
   const int ntm = (nblk + NB - 1) / NB;
   const int ntn = Cout / BN;
-  hipLaunchKernelGGL((conv3x3_hl16_patch_kernel<BN, BS, POOL>), dim3(ntm * ntn), dim3(512), 0, s, (const u32x4*)in,
+  hipLaunchKernelGGL((conv3x3_hl16_patch_kernel<BN, BS, POOL, EXP>), dim3(ntm * ntn), dim3(512), 0, s, (const u32x4*)in,
                      (const u32x4*)wp, bias, (u32x4*)out, L, H, W, Cin, Cout, nby, nbx, nblk, ntm, ntn, oscale);
   return mm_check(hipGetLastError());
+}
+
+template <int BN, int BS, bool POOL>
+static int launch_patch(const void* in, const void* wp, const float* bias, void* out, int L, int H, int W, int Cin,
+                        int Cout, float oscale, hipStream_t s) {
+  if constexpr (BN == 128 && BS == 16 && !POOL) {  // the experiments exist for one instantiation only
+    switch (g_patch_exp) {
+      case 1: return launch_patch_e<BN, BS, POOL, 1>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
+      case 2: return launch_patch_e<BN, BS, POOL, 2>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
+      case 3: return launch_patch_e<BN, BS, POOL, 3>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
+      case 4: return launch_patch_e<BN, BS, POOL, 4>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
+      default: break;
+    }
+  }
+  return launch_patch_e<BN, BS, POOL, 0>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
 }
 
 template <int BN, int BS>

@@ -26,7 +26,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--rounds', type=int, default=5)
     ap.add_argument('--crops', type=int, default=128, help='crops per launch (128 = one cfg3 pair)')
-    ap.add_argument('--variants', default='1,11', help='1 = 128-row tiles, 4 = 256-row tiles, 7..10 = LDS-DMA kernel variants 0..3, 11 = LDS-patch kernel')
+    ap.add_argument('--variants', default='1,11', help='1 = 128-row tiles, 4 = 256-row tiles, 7..10 = LDS-DMA kernel variants 0..3, 11 = LDS-patch kernel, 12..15 = its timing experiments 1..4 (wrong results)')
     args = ap.parse_args()
     ops = HipOps()
     lib = _lib.load()
@@ -52,7 +52,8 @@ def main():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 out.fill_(float('nan'))
                 e0.record()
-                if v == 11:  # LDS-resident patch kernel
+                if v >= 11:  # LDS-resident patch kernel (12..15: timing experiments, unpooled 128-channel tiles only)
+                    lib.mmmot_set_patch_variant(v - 11)
                     ops.conv3x3_hl16_patch(x16, w16, bias, out, L, H, W, Cin, Cout, bool(pool), 2.0 ** -shift)
                 elif v >= 7:  # LDS-DMA producer/consumer kernel (its own entry point)
                     ops.conv3x3_hl16_dma(x16, w16, bias, out, L, H, W, Cin, Cout, bool(pool), 2.0 ** -shift)
@@ -64,7 +65,7 @@ def main():
                     if ref is None:
                         ref = out.clone()
                     else:
-                        if v == 10:
+                        if v == 10 or v >= 12:
                             pass  # ASKIP timing experiment: results are wrong by construction
                         elif v >= 7:  # different K order (32-channel slabs): fp32 rounding differs, values must not
                             a, b = torch.empty_like(out), torch.empty_like(out)
@@ -80,6 +81,7 @@ def main():
     import ctypes
     buf = (ctypes.c_ulonglong * 8)()
     lib.mmmot_debug_read_phase_timers(buf, 1)
+    lib.mmmot_set_patch_variant(0)
     lib.mmmot_set_conv_variant(3)
     L, H, W, Cin, Cout, pool = LAYERS[2]
     L = args.crops
