@@ -160,8 +160,41 @@ typedef struct mmmot_gemm_args {
    * The A operand stays fp32 in memory and is split while staged.  oscale multiplies the
    * accumulator before bias. */
   int w_hl16; float oscale;
+  /* Fused consumer of the NEXT GroupNorm (v2): when colsum != NULL the epilogue also evaluates
+   * colsum[t][n] = sum over the tile's rows of relu(v[r][n] * osc[g][n] + osh[g][n]) (g = tile_group[t]),
+   * i.e. the per-tile part of "normalise + ReLU + per-detection mean" (reference
+   * modules/point_net.py:28-39,138-148) without the [rows][N] tensor ever reaching HBM: run the GEMM once
+   * with Y = NULL, part != NULL (statistics), finalize, and once with Y = NULL, colsum != NULL; tiles
+   * must not straddle the segments to be averaged; mmmot_segment_mean over the tile rows (seg_div =
+   * rows per segment) finishes the mean. */
+  const float* osc; const float* osh; int ldosc;   /* [G][ldosc] or NULL                */
+  float* colsum;                        /* [T][N] or NULL                     */
 } mmmot_gemm_args;
 int mmmot_gemm_rows(const mmmot_gemm_args* a, void* stream);
+
+/* A-resident row GEMM for layers whose output is only ever reduced (PointNet conv5 128->1024 and
+ * PointNet_v1.conv1 64->512, reference modules/point_net.py:28-39,138-148): the workgroup keeps its 128
+ * activation rows (normalised, ReLU'd, hi/lo split once) in LDS and walks all N/128 channel tiles;
+ *   v[r][n] = oscale * sum_k relu(X[r][k]*sc[g][k]+sh[g][k]) * W[n][k] + bias[n] + dbias[tile_dbrow[t]][n]
+ * is never stored.  Outputs, per 64-row HALF tile h of tile t (row index 2t+h; a half may be empty):
+ *   part   [2T][2][N]: sum and half-tile-centred M2 of v   -> mmmot_gn_finalize with tile_nrows = rows per half
+ *   colsum [2T][N]   : sum of relu(v*osc[g][n]+osh[g][n])  -> mmmot_segment_mean with seg_div
+ * W is hl16 ([N][K/8] units, pre-scaled by 1/oscale); K is 64 or 128; N % 128 == 0; tiles must not straddle
+ * the rows that share a dbias row (detection-aligned tiles).  At least one of part / colsum. */
+typedef struct mmmot_gemm_ares_args {
+  const float* X; int ldx;
+  const float* sc; const float* sh; int ldsc;   /* [G][ldsc] prologue scale / shift         */
+  const void* W;                                 /* hl16 weights                             */
+  const float* bias;                             /* [N] or NULL                              */
+  const float* dbias; const int* tile_dbrow; int lddb;  /* per-tile extra bias row or NULL   */
+  const int* tile_row0; const int* tile_nrows; const int* tile_group; /* [T]                 */
+  float* part;                                   /* [2T][2][N] or NULL                       */
+  const float* osc; const float* osh; int ldosc; /* [G][ldosc], needed with colsum           */
+  float* colsum;                                 /* [2T][N] or NULL                          */
+  int T; int N; int K;
+  float oscale;
+} mmmot_gemm_ares_args;
+int mmmot_gemm_ares(const mmmot_gemm_ares_args* a, void* stream);
 
 /* GroupNorm statistics -> per-channel scale/shift (fp64 combine).
  * part is [T][2][ldp] = per-tile (sum, tile-centred M2) as written by
@@ -173,9 +206,11 @@ int mmmot_gemm_rows(const mmmot_gemm_args* a, void* stream);
  * group g owns tiles [grp_tile0[g], +grp_ntiles[g]) and grp_count[g] rows;
  * the C channels are split into NG normalisation groups (nn.GroupNorm(NG, C),
  * eps, biased variance).  sc[g][c] = gamma[c]*rstd, sh[g][c] = beta[c]-mean*sc.
+ * tile_nrows (v2, may be NULL): rows of every tile when the tiles are NOT plain 128-row chunks
+ * (detection-aligned tiles of the fused PointNet path).
  * Replaces the statistics half of every F.group_norm on the path. */
 int mmmot_gn_finalize(const float* part, const int* grp_tile0, const int* grp_ntiles,
-                      const int* grp_count, int G, int ldp, int C, int NG,
+                      const int* grp_count, const int* tile_nrows, int G, int ldp, int C, int NG,
                       const float* gamma, const float* beta, float eps,
                       float* sc, float* sh, void* stream);
 
@@ -184,10 +219,12 @@ int mmmot_gn_finalize(const float* part, const int* grp_tile0, const int* grp_nt
  * Replaces the per-detection Python pooling loops of
  * reference modules/point_net.py:32-39,139-148, adaptive_avg_pool2d of
  * modules/appear_net.py:15,30 and the mean(dim=-2/-1) of
- * modules/new_end.py:70-71.  C % 4 == 0. seg_group / sc / sh may be NULL. */
+ * modules/new_end.py:70-71.  C % 4 == 0. seg_group / sc / sh may be NULL.
+ * seg_div (v2, may be NULL): divide the segment sum by seg_div[s] instead of count[s] (rows of X
+ * that are already per-tile partial sums, see mmmot_gemm_args.colsum). */
 int mmmot_segment_mean(const float* X, int ldx, int C,
                        const int* seg_start, const int* seg_count, const int* seg_stride,
-                       const int* seg_group, int nseg,
+                       const int* seg_group, const int* seg_div, int nseg,
                        const float* sc, const float* sh, int ldsc, int relu,
                        float* out, int ldo,
                        int hl16 /* 1: X rows are in the hl16 split-half format (see below) */,

@@ -13,7 +13,8 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libmmmot_hip.so')
-SOURCES = ['conv3x3.hip', 'conv3x3_hl16.hip', 'conv3x3_hl16_dma.hip', 'conv3x3_hl16_patch.hip', 'gemm_rows.hip', 'small_kernels.hip']
+SOURCES = ['conv3x3.hip', 'conv3x3_hl16.hip', 'conv3x3_hl16_dma.hip', 'conv3x3_hl16_patch.hip', 'gemm_rows.hip',
+           'gemm_ares.hip', 'small_kernels.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 HIPFLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
 
@@ -40,6 +41,25 @@ class GemmArgs(ctypes.Structure):
         ('T', c_i), ('N', c_i), ('K', c_i),
         ('amode', c_i), ('pairop', c_i), ('act', c_i),
         ('w_hl16', c_i), ('oscale', ctypes.c_float),
+        ('osc', c_f), ('osh', c_f), ('ldosc', c_i),
+        ('colsum', c_f),
+    ]
+
+
+class GemmAresArgs(ctypes.Structure):
+    """Mirror of ``mmmot_gemm_ares_args`` (include/mmmot_hip.h)."""
+    _fields_ = [
+        ('X', c_f), ('ldx', c_i),
+        ('sc', c_f), ('sh', c_f), ('ldsc', c_i),
+        ('W', c_f),
+        ('bias', c_f),
+        ('dbias', c_f), ('tile_dbrow', c_f), ('lddb', c_i),
+        ('tile_row0', c_f), ('tile_nrows', c_f), ('tile_group', c_f),
+        ('part', c_f),
+        ('osc', c_f), ('osh', c_f), ('ldosc', c_i),
+        ('colsum', c_f),
+        ('T', c_i), ('N', c_i), ('K', c_i),
+        ('oscale', ctypes.c_float),
     ]
 
 
@@ -49,8 +69,9 @@ SIGNATURES = {
     'mmmot_device_info': [c_i, ctypes.POINTER(c_i), ctypes.c_char_p, c_i],
     'mmmot_conv3x3_bn_relu': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f],
     'mmmot_gemm_rows': [ctypes.POINTER(GemmArgs), c_f],
-    'mmmot_gn_finalize': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, ctypes.c_float, c_f, c_f, c_f],
-    'mmmot_segment_mean': [c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_f, c_f, c_i, c_i, c_f, c_i, c_i, c_f],
+    'mmmot_gemm_ares': [ctypes.POINTER(GemmAresArgs), c_f],
+    'mmmot_gn_finalize': [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, ctypes.c_float, c_f, c_f, c_f],
+    'mmmot_segment_mean': [c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_f, c_i, c_i, c_f, c_i, c_i, c_f],
     'mmmot_conv3x3_bn_relu_hl16': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, c_f],
     'mmmot_conv3x3_bn_relu_hl16_dma': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, c_f],
     'mmmot_conv3x3_bn_relu_hl16_patch': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, c_f],

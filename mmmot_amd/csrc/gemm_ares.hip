@@ -1,0 +1,211 @@
+// A-resident row GEMM for the PointNet layers whose output is only ever reduced
+// (see include/mmmot_hip.h: mmmot_gemm_ares).
+//
+//   v[r][n] = oscale * sum_k relu(X[r][k]*sc[g][k] + sh[g][k]) * W[n][k] + bias[n] + dbias[tile_dbrow[t]][n]
+//
+// and, instead of storing v ([points][1024] fp32 = 1 GiB per cfg3 frame pair for PointNet conv5),
+//   part   [2t+h][0/1][n] = sum / centred M2 of v over the valid rows of 64-row half-tile h   (statistics pass)
+//   colsum [2t+h][n]      = sum over the same rows of relu(v*osc[g][n] + osh[g][n])           (consumer pass)
+//
+// Why a separate kernel: K is 64 or 128 and N is 512 or 1024, so in the generic 128x128-tile kernel
+// (gemm_rows.hip) every workgroup stages and splits the same activation rows once per channel tile and runs
+// 2 K-stages between a prologue and a three-barrier statistics epilogue - 70-200 TFLOP/s-equivalent.  Here a
+// workgroup keeps its 128 activation rows resident in LDS (normalised, ReLU'd and hi/lo split ONCE) and walks
+// all N/128 channel tiles: weights stream through a double-buffered LDS stage (one barrier per 64-channel
+// stage), the per-tile epilogue is register-only (each wave owns 64 rows x 32 channels: column sums by
+// lane-half shuffle, statistics centred on the wave's own 64-row mean), nothing but the partials is stored.
+// Arithmetic: fp16 matrix cores with the 3-term hi/lo split (same as gemm_rows F16 / conv3x3_hl16).
+#include "common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define AR_BM 128
+#define AR_BN 128
+#define AR_BK 64
+#define AR_LDT 72  // halves per LDS row (144 B): conflict-free ds_read_b128
+#define AR_THREADS 512
+
+template <int KS>  // K / 64
+__global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_args a) {
+  constexpr int PLANE = AR_BM * AR_LDT;  // halves per [128][72] plane
+  __shared__ __attribute__((aligned(16))) _Float16 As[KS][2][PLANE];  // [k stage][hi, lo]
+  __shared__ __attribute__((aligned(16))) _Float16 Bs[2][2][PLANE];   // [buffer][hi, lo]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves: 64 rows x 32 channels each
+  const int lr = lane & 31;
+  const int kh = (lane >> 5) * 8;
+
+  const int t = mm_xcd_remap(blockIdx.x, gridDim.x);
+  const int row0 = a.tile_row0[t];
+  const int nrows = a.tile_nrows[t];
+  const int grp = a.tile_group ? a.tile_group[t] : 0;
+  const int ntn = a.N / AR_BN;
+  const int NS = ntn * KS;  // weight stages
+
+  // ---- weight stage loader: thread -> (channel row = tid >> 2, units 2q, 2q+1 of the 8 in a 64-k stage) ----
+  const int wrow = tid >> 2, wq = tid & 3;
+  const u32x4* wp = reinterpret_cast<const u32x4*>(a.W);
+  const long ku = (long)(a.K >> 3);  // hl16 units per weight row
+  u32x4 rw[4];                       // hi, lo of two units
+  auto load_w = [&](int s) {
+    const int nt = s / KS, ks = s - nt * KS;
+    const u32x4* p = wp + ((long)(nt * AR_BN + wrow) * ku + ks * 8 + wq * 2) * 2;
+    rw[0] = p[0];
+    rw[1] = p[1];
+    rw[2] = p[2];
+    rw[3] = p[3];
+  };
+  auto store_w = [&](int buf) {
+    _Float16* bh = &Bs[buf][0][wrow * AR_LDT + wq * 16];
+    _Float16* bl = &Bs[buf][1][wrow * AR_LDT + wq * 16];
+    *reinterpret_cast<u32x4*>(bh) = rw[0];
+    *reinterpret_cast<u32x4*>(bl) = rw[1];
+    *reinterpret_cast<u32x4*>(bh + 8) = rw[2];
+    *reinterpret_cast<u32x4*>(bl + 8) = rw[3];
+  };
+
+  // ---- activation rows: normalise + ReLU + hi/lo split, once --------------------------------------------
+  {
+    // thread -> (row = tid >> 2, quarter q of the K axis: 16 * KS consecutive channels)
+    const int r = tid >> 2, q = tid & 3;
+    const bool rv = r < nrows;
+    const float* px = a.X + (long)(row0 + (rv ? r : 0)) * a.ldx + q * (16 * KS);
+    const float* psc = a.sc + (long)grp * a.ldsc + q * (16 * KS);
+    const float* psh = a.sh + (long)grp * a.ldsc + q * (16 * KS);
+#pragma unroll
+    for (int u = 0; u < 2 * KS; ++u) {  // 8-channel units of this thread
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(px + 8 * u), x1 = *reinterpret_cast<const f32x4*>(px + 8 * u + 4);
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(psc + 8 * u), s1 = *reinterpret_cast<const f32x4*>(psc + 8 * u + 4);
+      const f32x4 h0 = *reinterpret_cast<const f32x4*>(psh + 8 * u), h1 = *reinterpret_cast<const f32x4*>(psh + 8 * u + 4);
+      f16x8 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float y0 = fminf(fmaxf(fmaf(x0[e], s0[e], h0[e]), 0.f), 65000.f);
+        float y1 = fminf(fmaxf(fmaf(x1[e], s1[e], h1[e]), 0.f), 65000.f);
+        if (!rv) y0 = y1 = 0.f;
+        hi[e] = (_Float16)y0;
+        lo[e] = (_Float16)(y0 - (float)hi[e]);
+        hi[4 + e] = (_Float16)y1;
+        lo[4 + e] = (_Float16)(y1 - (float)hi[4 + e]);
+      }
+      const int k = q * (16 * KS) + 8 * u;  // channel of the unit
+      const int ks = k / AR_BK, kk = k - ks * AR_BK;
+      *reinterpret_cast<f16x8*>(&As[ks][0][r * AR_LDT + kk]) = hi;
+      *reinterpret_cast<f16x8*>(&As[ks][1][r * AR_LDT + kk]) = lo;
+    }
+  }
+  load_w(0);
+  store_w(0);
+  if (NS > 1) load_w(1);
+  __syncthreads();
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[tm][e] = 0.f;
+
+  const int nsub = min(max(nrows - 64 * wm, 0), 64);  // valid rows of this wave's half tile
+  const float inv_nsub = nsub > 0 ? 1.f / (float)nsub : 0.f;
+  const long prow = (long)(2 * t + wm);
+
+  for (int s = 0; s < NS; ++s) {
+    const int nt = s / KS, ks = s - nt * KS;
+    // stage s+1 -> the other buffer (last read in stage s-1, every wave is past that barrier)
+    if (s + 1 < NS) store_w((s + 1) & 1);
+    if (s + 2 < NS) load_w(s + 2);
+    const _Float16* ah = &As[ks][0][0];
+    const _Float16* al = &As[ks][1][0];
+    const _Float16* bh = &Bs[s & 1][0][0];
+    const _Float16* bl = &Bs[s & 1][1][0];
+#pragma unroll
+    for (int k16 = 0; k16 < AR_BK / 16; ++k16) {
+      f16x8 fah[2], fal[2];
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {
+        const int off = (wm * 64 + tm * 32 + lr) * AR_LDT + k16 * 16 + kh;
+        fah[tm] = *reinterpret_cast<const f16x8*>(ah + off);
+        fal[tm] = *reinterpret_cast<const f16x8*>(al + off);
+      }
+      const int offb = (wn * 32 + lr) * AR_LDT + k16 * 16 + kh;
+      const f16x8 fbh = *reinterpret_cast<const f16x8*>(bh + offb);
+      const f16x8 fbl = *reinterpret_cast<const f16x8*>(bl + offb);
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[tm], fbh, acc[tm], 0, 0, 0);
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[tm], fbl, acc[tm], 0, 0, 0);
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[tm], fbh, acc[tm], 0, 0, 0);
+    }
+    if (ks == KS - 1) {
+      // ---- channel tile nt finished: register-only epilogue for this wave's 64 rows x 32 channels ----
+      const int n = nt * AR_BN + wn * 32 + lr;
+      float cb = a.bias ? a.bias[n] : 0.f;
+      if (a.dbias) cb += a.dbias[(long)a.tile_dbrow[t] * a.lddb + n];
+      float v[32];
+      float s1 = 0.f;
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int r = wm * 64 + tm * 32 + mm_acc_row(e, lane);
+          const float x = fmaf(acc[tm][e], a.oscale, cb);
+          v[tm * 16 + e] = (r < nrows) ? x : 0.f;
+          s1 += v[tm * 16 + e];
+          acc[tm][e] = 0.f;
+        }
+      if (a.part) {
+        s1 += __shfl_xor(s1, 32);
+        const float mu = s1 * inv_nsub;
+        float s2 = 0.f;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int r = wm * 64 + tm * 32 + mm_acc_row(e, lane);
+            const float d = v[tm * 16 + e] - mu;
+            if (r < nrows) s2 += d * d;
+          }
+        s2 += __shfl_xor(s2, 32);
+        if (lane < 32) {
+          a.part[(prow * 2 + 0) * a.N + n] = s1;
+          a.part[(prow * 2 + 1) * a.N + n] = s2;
+        }
+      }
+      if (a.colsum) {
+        const float os = a.osc[(long)grp * a.ldosc + n], oh = a.osh[(long)grp * a.ldosc + n];
+        float s3 = 0.f;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int r = wm * 64 + tm * 32 + mm_acc_row(e, lane);
+            if (r < nrows) s3 += fmaxf(fmaf(v[tm * 16 + e], os, oh), 0.f);
+          }
+        s3 += __shfl_xor(s3, 32);
+        if (lane < 32) a.colsum[prow * a.N + n] = s3;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int mmmot_gemm_ares(const mmmot_gemm_ares_args* a, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!a || !a->X || !a->W || !a->sc || !a->sh || !a->tile_row0 || !a->tile_nrows || a->T <= 0) return MMMOT_EINVAL;
+  if ((a->K != 64 && a->K != 128) || a->N <= 0 || a->N % AR_BN != 0) return MMMOT_EINVAL;
+  if (a->ldx % 4 != 0 || a->ldsc % 4 != 0 || !mm_al16(a->X) || !mm_al16(a->W) || !mm_al16(a->sc) || !mm_al16(a->sh))
+    return MMMOT_EINVAL;
+  if (a->dbias && !a->tile_dbrow) return MMMOT_EINVAL;
+  if (a->colsum && (!a->osc || !a->osh)) return MMMOT_EINVAL;
+  if (!a->part && !a->colsum) return MMMOT_EINVAL;  // nothing to produce
+  if (a->K == 128)
+    hipLaunchKernelGGL(gemm_ares_kernel<2>, dim3(a->T), dim3(AR_THREADS), 0, s, *a);
+  else
+    hipLaunchKernelGGL(gemm_ares_kernel<1>, dim3(a->T), dim3(AR_THREADS), 0, s, *a);
+  return mm_check(hipGetLastError());
+}

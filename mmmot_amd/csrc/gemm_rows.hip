@@ -301,6 +301,33 @@ __global__ __launch_bounds__(MM_THREADS, 2) void gemm_rows_kernel(mmmot_gemm_arg
       a.part[((long)t * 2 + 1) * a.N + n0 + cl] = s;
     }
   }
+  // Fused consumer of the next GroupNorm: column sums of relu(v * osc + osh) over the tile's rows.
+  if (a.colsum) {
+    __syncthreads();  // red[] may still be read by the statistics path / the last K stage
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int cl = wn * TN * 32 + tn * 32 + (lane & 31);
+      const float os = a.osc[(long)grp * a.ldosc + n0 + cl], oh = a.osh[(long)grp * a.ldosc + n0 + cl];
+      float s3 = 0.f;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int r = wm * TM * 32 + tm * 32 + mm_acc_row(e, lane);
+          if (r < nrows) s3 += fmaxf(fmaf(acc[tm][tn][e], os, oh), 0.f);
+        }
+      }
+      s3 += __shfl_xor(s3, 32);
+      if (lane < 32) red[wm * BN + cl] = s3;
+    }
+    __syncthreads();
+    for (int cl = tid; cl < BN; cl += MM_THREADS) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) s += red[w * BN + cl];
+      a.colsum[(long)t * a.N + n0 + cl] = s;
+    }
+  }
   // F16 path: the output tile goes through LDS (fp32 [128][BN+4]) and leaves as 16-byte stores, 512
   // contiguous bytes per row.  The per-lane 4-byte stores of the fp32 path above made the short-K
   // PointNet layers (K = 64 / 128, N = 512 / 1024) store-issue bound: 1.5 TB/s of output.
@@ -371,6 +398,7 @@ extern "C" int mmmot_gemm_rows(const mmmot_gemm_args* a, void* stream) {
       return MMMOT_EINVAL;
   }
   if (a->dbias && !a->rowidx) return MMMOT_EINVAL;
+  if (a->colsum && (!a->osc || !a->osh)) return MMMOT_EINVAL;
   if (a->w_hl16 && a->Y && (a->ldy % 4 != 0 || !mm_al16(a->Y))) return MMMOT_EINVAL;
   return a->w_hl16 ? dispatch_gemm<true>(a, s) : dispatch_gemm<false>(a, s);
 }

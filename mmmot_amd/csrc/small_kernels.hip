@@ -9,15 +9,16 @@
 // GroupNorm statistics -> scale/shift.  One workgroup per (group, norm-group).
 __global__ __launch_bounds__(256) void gn_finalize_kernel(
     const float* __restrict__ part, const int* __restrict__ grp_tile0, const int* __restrict__ grp_ntiles,
-    const int* __restrict__ grp_count, int ldp, int C, int NG, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float eps, float* __restrict__ sc, float* __restrict__ sh) {
+    const int* __restrict__ grp_count, const int* __restrict__ tile_nrows, int ldp, int C, int NG,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float* __restrict__ sc,
+    float* __restrict__ sh) {
   __shared__ double red[2][4];
   const int g = blockIdx.x / NG, ng = blockIdx.x % NG;
   const int CG = C / NG, c0 = ng * CG;
   const int tile0 = grp_tile0[g], nt = grp_ntiles[g];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // part[t][0][c] = tile sum S, part[t][1][c] = tile-centred M2 (see gemm_rows.hip epilogue).
-  // Tiles of a group are consecutive MM_BM-row chunks, the last one partial.
+  // Tiles of a group are consecutive MM_BM-row chunks, the last one partial - unless tile_nrows says otherwise.
   const int rows = grp_count[g];
   const long total = (long)CG * nt;
   double s1 = 0.0;
@@ -38,9 +39,11 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(
     const int t = tile0 + ti;
     const int c = c0 + (int)(idx % CG);
     const int left = rows - ti * MM_BM;
-    const double n_t = (double)(left < MM_BM ? left : MM_BM);
-    const double d = (double)part[((long)t * 2 + 0) * ldp + c] / n_t - mean;
-    s2 += (double)part[((long)t * 2 + 1) * ldp + c] + n_t * d * d;
+    const double n_t = tile_nrows ? (double)tile_nrows[t] : (double)(left < MM_BM ? left : MM_BM);
+    if (n_t > 0.0) {  // half tiles of the A-resident GEMM may be empty
+      const double d = (double)part[((long)t * 2 + 0) * ldp + c] / n_t - mean;
+      s2 += (double)part[((long)t * 2 + 1) * ldp + c] + n_t * d * d;
+    }
   }
   s2 = wave_sum_d(s2);
   if (lane == 0) red[1][wave] = s2;
@@ -55,12 +58,13 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(
 }
 
 extern "C" int mmmot_gn_finalize(const float* part, const int* grp_tile0, const int* grp_ntiles,
-                                 const int* grp_count, int G, int ldp, int C, int NG, const float* gamma,
-                                 const float* beta, float eps, float* sc, float* sh, void* stream) {
+                                 const int* grp_count, const int* tile_nrows, int G, int ldp, int C, int NG,
+                                 const float* gamma, const float* beta, float eps, float* sc, float* sh,
+                                 void* stream) {
   if (!part || !grp_tile0 || !grp_ntiles || !grp_count || !gamma || !beta || !sc || !sh) return MMMOT_EINVAL;
   if (G <= 0 || C <= 0 || NG <= 0 || C % NG != 0 || ldp < C) return MMMOT_EINVAL;
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(G * NG), dim3(256), 0, (hipStream_t)stream, part, grp_tile0,
-                     grp_ntiles, grp_count, ldp, C, NG, gamma, beta, eps, sc, sh);
+                     grp_ntiles, grp_count, tile_nrows, ldp, C, NG, gamma, beta, eps, sc, sh);
   return mm_check(hipGetLastError());
 }
 
@@ -70,7 +74,7 @@ extern "C" int mmmot_gn_finalize(const float* part, const int* grp_tile0, const 
 __global__ __launch_bounds__(256) void segment_mean_kernel(
     const float* __restrict__ X, int ldx, int C, const int* __restrict__ seg_start,
     const int* __restrict__ seg_count, const int* __restrict__ seg_stride, const int* __restrict__ seg_group,
-    const float* __restrict__ sc, const float* __restrict__ sh, int ldsc, int relu,
+    const int* __restrict__ seg_div, const float* __restrict__ sc, const float* __restrict__ sh, int ldsc, int relu,
     float* __restrict__ out, int ldo, int hl16) {
   __shared__ __attribute__((aligned(16))) float red[4][256];
   const int s = blockIdx.x;
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(256) void segment_mean_kernel(
     r += *reinterpret_cast<const f32x4*>(&red[1][lane * 4]);
     r += *reinterpret_cast<const f32x4*>(&red[2][lane * 4]);
     r += *reinterpret_cast<const f32x4*>(&red[3][lane * 4]);
-    const float inv = 1.f / (float)count;
+    const float inv = 1.f / (float)(seg_div ? seg_div[s] : count);
 #pragma unroll
     for (int e = 0; e < 4; ++e) r[e] *= inv;
     *reinterpret_cast<f32x4*>(&out[(long)s * ldo + c]) = r;
@@ -133,16 +137,16 @@ __global__ __launch_bounds__(256) void segment_mean_kernel(
 }
 
 extern "C" int mmmot_segment_mean(const float* X, int ldx, int C, const int* seg_start, const int* seg_count,
-                                  const int* seg_stride, const int* seg_group, int nseg, const float* sc,
-                                  const float* sh, int ldsc, int relu, float* out, int ldo, int hl16,
-                                  void* stream) {
+                                  const int* seg_stride, const int* seg_group, const int* seg_div, int nseg,
+                                  const float* sc, const float* sh, int ldsc, int relu, float* out, int ldo,
+                                  int hl16, void* stream) {
   if (!X || !seg_start || !seg_count || !out || nseg <= 0 || C <= 0) return MMMOT_EINVAL;
   if (hl16 && (C % 8 != 0 || ldx % 8 != 0)) return MMMOT_EINVAL;
   if (C % 4 != 0 || ldx % 4 != 0 || ldo % 4 != 0 || !mm_al16(X) || !mm_al16(out)) return MMMOT_EINVAL;
   if ((sc == nullptr) != (sh == nullptr)) return MMMOT_EINVAL;
   if (sc && (ldsc % 4 != 0 || !mm_al16(sc) || !mm_al16(sh))) return MMMOT_EINVAL;
   hipLaunchKernelGGL(segment_mean_kernel, dim3(nseg, (C + 255) / 256), dim3(256), 0, (hipStream_t)stream, X,
-                     ldx, C, seg_start, seg_count, seg_stride, seg_group, sc, sh, ldsc, relu, out, ldo, hl16);
+                     ldx, C, seg_start, seg_count, seg_stride, seg_group, seg_div, sc, sh, ldsc, relu, out, ldo, hl16);
   return mm_check(hipGetLastError());
 }
 
@@ -451,7 +455,7 @@ extern "C" int mmmot_softmax_pairs(const float* logits, float* out, const int* g
 }
 
 // ---------------------------------------------------------------------------
-extern "C" int mmmot_abi_version(void) { return 1; }
+extern "C" int mmmot_abi_version(void) { return 2; }
 
 extern "C" int mmmot_device_info(int device, int* cu_count, char* arch, int arch_len) {
   hipDeviceProp_t p;

@@ -32,6 +32,9 @@ class Engine:
         self.conv_impl = os.environ.get('MMMOT_CONV', 'patch')
         if self.conv_impl not in ('patch', 'tile', 'dma'):
             raise ValueError("MMMOT_CONV must be 'patch', 'tile' or 'dma'")
+        # PointNet conv5 / conv1: statistics pass + fused normalise-ReLU-segment-sum pass instead of
+        # materialising the [P][1024] / [P][512] tensors (MMMOT_PN_FUSED=0 keeps the materialising path)
+        self.pn_fused = os.environ.get('MMMOT_PN_FUSED', '1') != '0'
         self.mlp = trunk  # the 1x1-conv / linear GEMMs follow the same arithmetic choice
         if affinity_op not in PAIR_OPS:
             raise ValueError('unknown affinity_op %r' % (affinity_op,))
@@ -136,28 +139,74 @@ class Engine:
         ops.pointnet_layer1(points, pn['w1'], pn['b1'], y1, part, T)
         sc1, sh1 = self._finalize('pn1', part, T, 64, 64, pn['g1'], pn['be1'])
         # conv2..conv5: each consumes relu(gn(previous)) through the GEMM prologue
+        fused = self.pn_fused
+        TD = plan.ptd_tiles if fused else T  # detection-aligned tiles for the fused epilogues
         x, sc, sh = y1, sc1, sh1
-        for i, (N, K) in zip((2, 3, 4, 5), ((64, 64), (64, 64), (128, 64), (1024, 128))):
+        for i, (N, K) in zip((2, 3, 4), ((64, 64), (64, 64), (128, 64))):
             y = self.buf('pn_y%d' % i, Pn, N)
             part = self._part(T, N)
             self._gemm(pn, 'w%d' % i, T, N, K, X=x, bias=pn['b%d' % i], Y=y, part=part, sc=sc, sh=sh,
                      amode=A_NORM_RELU)
             sc, sh = self._finalize('pn%d' % i, part, T, N, N, pn['g%d' % i], pn['be%d' % i])
             x = y
-        # per-detection average of relu(gn5(conv5)) (named max_feats in the reference, point_net.py:139-148)
+        # conv5 128->1024 + GN + ReLU + per-detection average (named max_feats in the reference,
+        # point_net.py:138-148).  Fused: the [P][1024] tensor (1 GiB per cfg3 pair) is never stored - one GEMM
+        # pass for the statistics, one that normalises in the epilogue and emits per-tile column sums.
         seg1024 = self.buf('pn_seg1024', Lt, 1024)
-        ops.segment_mean(x, 1024, plan.det_segs, seg1024, sc=sc, sh=sh, relu=True)
+        ares = fused and self.mlp == 'f16x3' and 'w5_h16' in pn  # A-resident kernel (hl16 weights only)
+        TH = plan.ptd_half if ares else None
+        if ares:
+            part = self._part(TH, 1024)
+            ops.gemm_ares(pn['w5_h16'], pn['w5_os'], TD, 1024, 128, x, sc, sh, bias=pn['b5'], part=part)
+            sc5, sh5 = self._finalize('pn5', part, TH, 1024, 1024, pn['g5'], pn['be5'])
+            cs = self.buf('pn_colsum', TH.T, 1024)
+            ops.gemm_ares(pn['w5_h16'], pn['w5_os'], TD, 1024, 128, x, sc, sh, bias=pn['b5'], osc=sc5, osh=sh5,
+                          colsum=cs)
+            ops.segment_mean(cs, 1024, plan.det_half_segs, seg1024)
+        elif fused:
+            part = self._part(TD, 1024)
+            self._gemm(pn, 'w5', TD, 1024, 128, X=x, bias=pn['b5'], part=part, sc=sc, sh=sh, amode=A_NORM_RELU)
+            sc5, sh5 = self._finalize('pn5', part, TD, 1024, 1024, pn['g5'], pn['be5'])
+            cs = self.buf('pn_colsum', TD.T, 1024)
+            self._gemm(pn, 'w5', TD, 1024, 128, X=x, bias=pn['b5'], sc=sc, sh=sh, amode=A_NORM_RELU,
+                       osc=sc5, osh=sh5, colsum=cs)
+            ops.segment_mean(cs, 1024, plan.det_tile_segs, seg1024)
+        else:
+            y = self.buf('pn_y5', Pn, 1024)
+            part = self._part(T, 1024)
+            self._gemm(pn, 'w5', T, 1024, 128, X=x, bias=pn['b5'], Y=y, part=part, sc=sc, sh=sh, amode=A_NORM_RELU)
+            sc5, sh5 = self._finalize('pn5', part, T, 1024, 1024, pn['g5'], pn['be5'])
+            ops.segment_mean(y, 1024, plan.det_segs, seg1024, sc=sc5, sh=sh5, relu=True)
         self._stash('pn_seg1024', seg1024)
         # PointNet_v1.conv1 split: per-detection 1024-channel part becomes a gathered bias
         dbias = self.buf('pn_dbias', Lt, 512)
         self._gemm(pn, 'wc1b', D, 512, 1024, X=seg1024, bias=pn['bc1'], Y=dbias)
-        yc1 = self.buf('pn_yc1', Pn, 512)
-        part = self._part(T, 512)
-        self._gemm(pn, 'wc1a', T, 512, 64, X=y1, Y=yc1, part=part, sc=sc1, sh=sh1, amode=A_NORM_RELU,
-                 dbias=dbias, rowidx=plan.row_det)
-        scc, shc = self._finalize('pnc1', part, T, 512, 512, pn['gc1'], pn['bec1'])
         seg512 = self.buf('pn_seg512', Lt, 512)
-        ops.segment_mean(yc1, 512, plan.det_segs, seg512, sc=scc, sh=shc, relu=True)
+        if ares:
+            part = self._part(TH, 512)
+            ops.gemm_ares(pn['wc1a_h16'], pn['wc1a_os'], TD, 512, 64, y1, sc1, sh1, dbias=dbias,
+                          tile_dbrow=plan.tile_det, part=part)
+            scc, shc = self._finalize('pnc1', part, TH, 512, 512, pn['gc1'], pn['bec1'])
+            cs = self.buf('pn_colsum', TH.T, 512)
+            ops.gemm_ares(pn['wc1a_h16'], pn['wc1a_os'], TD, 512, 64, y1, sc1, sh1, dbias=dbias,
+                          tile_dbrow=plan.tile_det, osc=scc, osh=shc, colsum=cs)
+            ops.segment_mean(cs, 512, plan.det_half_segs, seg512)
+        elif fused:
+            part = self._part(TD, 512)
+            self._gemm(pn, 'wc1a', TD, 512, 64, X=y1, part=part, sc=sc1, sh=sh1, amode=A_NORM_RELU,
+                       dbias=dbias, rowidx=plan.row_det)
+            scc, shc = self._finalize('pnc1', part, TD, 512, 512, pn['gc1'], pn['bec1'])
+            cs = self.buf('pn_colsum', TD.T, 512)
+            self._gemm(pn, 'wc1a', TD, 512, 64, X=y1, sc=sc1, sh=sh1, amode=A_NORM_RELU, dbias=dbias,
+                       rowidx=plan.row_det, osc=scc, osh=shc, colsum=cs)
+            ops.segment_mean(cs, 512, plan.det_tile_segs, seg512)
+        else:
+            yc1 = self.buf('pn_yc1', Pn, 512)
+            part = self._part(T, 512)
+            self._gemm(pn, 'wc1a', T, 512, 64, X=y1, Y=yc1, part=part, sc=sc1, sh=sh1, amode=A_NORM_RELU,
+                       dbias=dbias, rowidx=plan.row_det)
+            scc, shc = self._finalize('pnc1', part, T, 512, 512, pn['gc1'], pn['bec1'])
+            ops.segment_mean(yc1, 512, plan.det_segs, seg512, sc=scc, sh=shc, relu=True)
         yc2 = self.buf('pn_yc2', Lt, 512)
         part = self._part(D, 512)
         self._gemm(pn, 'wc2', D, 512, 512, X=seg512, bias=pn['bc2'], Y=yc2, part=part)

@@ -92,8 +92,9 @@ class HipOps:
 
     def gemm(self, W, tiles, N, K, X=None, bias=None, dbias=None, rowidx=None, Y=None, part=None,
              sc=None, sh=None, FA=None, FB=None, pair=None, amode=A_PLAIN, pairop=0, act=ACT_NONE,
-             w_hl16=False, oscale=1.0):
-        """W: [N][K] fp32 weights, or (w_hl16=True) the hl16 split-half copy scaled by 1/oscale."""
+             w_hl16=False, oscale=1.0, osc=None, osh=None, colsum=None):
+        """W: [N][K] fp32 weights, or (w_hl16=True) the hl16 split-half copy scaled by 1/oscale.
+        colsum [T][N] (+ osc/osh [G][N]): per-tile column sums of relu(v * osc + osh) (fused next-norm consumer)."""
         a = _lib.GemmArgs()
         a.X, a.ldx = _ptr(X), _ld(X)
         a.W = _ptr(W)
@@ -110,20 +111,41 @@ class HipOps:
         a.T, a.N, a.K = tiles.T, N, K
         a.amode, a.pairop, a.act = amode, pairop, act
         a.w_hl16, a.oscale = int(w_hl16), float(oscale)
+        a.osc, a.osh, a.ldosc = _ptr(osc), _ptr(osh), _ld(osc)
+        a.colsum = _ptr(colsum)
         _lib.check(self.lib.mmmot_gemm_rows(ctypes.byref(a), self._stream()), 'mmmot_gemm_rows')
+
+    def gemm_ares(self, W16, oscale, tiles, N, K, X, sc, sh, bias=None, dbias=None, tile_dbrow=None, part=None,
+                  osc=None, osh=None, colsum=None):
+        """A-resident GEMM (hl16 weights): statistics `part` [2T][2][N] and/or `colsum` [2T][N] per 64-row
+        half tile; the product itself is never stored (see include/mmmot_hip.h: mmmot_gemm_ares)."""
+        a = _lib.GemmAresArgs()
+        a.X, a.ldx = _ptr(X), _ld(X)
+        a.sc, a.sh, a.ldsc = _ptr(sc), _ptr(sh), _ld(sc)
+        a.W, a.bias = _ptr(W16), _ptr(bias)
+        a.dbias, a.tile_dbrow, a.lddb = _ptr(dbias), _iptr(tile_dbrow), _ld(dbias)
+        a.tile_row0, a.tile_nrows, a.tile_group = _iptr(tiles.row0), _iptr(tiles.nrows), _iptr(tiles.group)
+        a.part = _ptr(part)
+        a.osc, a.osh, a.ldosc = _ptr(osc), _ptr(osh), _ld(osc)
+        a.colsum = _ptr(colsum)
+        a.T, a.N, a.K, a.oscale = tiles.T, N, K, float(oscale)
+        _lib.check(self.lib.mmmot_gemm_ares(ctypes.byref(a), self._stream()), 'mmmot_gemm_ares')
 
     def gn_finalize(self, part, tiles, C, NG, gamma, beta, eps, sc, sh):
         """part: [T][2][>=C] view (unit inner stride); statistics of its first C channels."""
         if part.dim() != 3 or part.stride(2) != 1 or part.stride(0) != 2 * part.stride(1):
             raise ValueError('part must be a [T][2][C] view of a [T][2][ldp] buffer')
         st = self.lib.mmmot_gn_finalize(_ptr(part), _iptr(tiles.g_tile0), _iptr(tiles.g_ntiles),
-                                        _iptr(tiles.g_count), tiles.G, part.stride(1), C, NG, _ptr(gamma), _ptr(beta),
+                                        _iptr(tiles.g_count), _iptr(tiles.nrows) if tiles.ragged else None, tiles.G,
+                                        part.stride(1), C, NG, _ptr(gamma), _ptr(beta),
                                         float(eps), _ptr(sc), _ptr(sh), self._stream())
         _lib.check(st, 'mmmot_gn_finalize')
 
     def segment_mean(self, X, C, segs, out, sc=None, sh=None, relu=False, use_group=True, hl16=False):
+        """segs.div (optional int32 tensor): divisor per segment instead of its row count."""
         st = self.lib.mmmot_segment_mean(_ptr(X), _ld(X), C, _iptr(segs.start), _iptr(segs.count),
-                                         _iptr(segs.stride), _iptr(segs.group) if use_group else None, segs.n,
+                                         _iptr(segs.stride), _iptr(segs.group) if use_group else None,
+                                         _iptr(getattr(segs, 'div', None)), segs.n,
                                          _ptr(sc), _ptr(sh), _ld(sc), int(relu), _ptr(out), _ld(out),
                                          int(hl16), self._stream())
         _lib.check(st, 'mmmot_segment_mean')

@@ -23,22 +23,35 @@ TILE = 128
 
 
 class RowTiles:
-    """Tiles of <=128 rows over contiguous groups of rows."""
+    """Tiles of <=128 rows over contiguous groups of rows.
 
-    def __init__(self, counts, device):
+    ``sub_counts`` (optional, one list per group, summing to the group's count): the tiles additionally never
+    straddle these sub-segments (detections inside a sample) - the layout the fused "normalise + ReLU +
+    per-detection mean" GEMM epilogue needs.  Such tilings are ``ragged``: partial tiles occur inside a group
+    and the finalize kernel is handed the per-tile row counts."""
+
+    def __init__(self, counts, device, sub_counts=None):
         counts = [int(c) for c in counts]
         row0, nrows, group, g_tile0, g_ntiles, g_row0 = [], [], [], [], [], []
+        sub_tile0, sub_ntiles = [], []
         r = 0
         for g, c in enumerate(counts):
             g_tile0.append(len(row0))
             g_row0.append(r)
-            nt = (c + TILE - 1) // TILE
-            for t in range(nt):
-                row0.append(r + t * TILE)
-                nrows.append(min(TILE, c - t * TILE))
-                group.append(g)
-            g_ntiles.append(nt)
-            r += c
+            subs = [c] if sub_counts is None else [int(x) for x in sub_counts[g]]
+            if sum(subs) != c:
+                raise ValueError('sub-segment counts of group %d do not add up' % g)
+            for sc in subs:
+                sub_tile0.append(len(row0))
+                nt = (sc + TILE - 1) // TILE
+                for t in range(nt):
+                    row0.append(r + t * TILE)
+                    nrows.append(min(TILE, sc - t * TILE))
+                    group.append(g)
+                sub_ntiles.append(nt)
+                r += sc
+            g_ntiles.append(len(row0) - g_tile0[-1])
+        self.ragged = sub_counts is not None
         self.R = r
         self.T = len(row0)
         self.G = len(counts)
@@ -49,15 +62,31 @@ class RowTiles:
         self.h_g_ntiles = np.asarray(g_ntiles, np.int32)
         self.h_g_count = np.asarray(counts, np.int32)
         self.h_g_row0 = np.asarray(g_row0, np.int32)
+        self.h_sub_tile0 = np.asarray(sub_tile0, np.int32)
+        self.h_sub_ntiles = np.asarray(sub_ntiles, np.int32)
         up = lambda a: torch.from_numpy(a).to(device)
         self.row0, self.nrows, self.group = up(self.h_row0), up(self.h_nrows), up(self.h_group)
         self.g_tile0, self.g_ntiles = up(self.h_g_tile0), up(self.h_g_ntiles)
         self.g_count, self.g_row0 = up(self.h_g_count), up(self.h_g_row0)
 
 
-class Segments:
-    def __init__(self, start, count, stride, group, device):
+class HalfTiles:
+    """The 64-row halves of a RowTiles tiling as a statistics tiling: entry 2t+h, possibly empty."""
+
+    def __init__(self, tiles, device):
+        n = tiles.h_nrows.astype(np.int64)
+        self.h_nrows = np.stack([np.minimum(n, 64), np.clip(n - 64, 0, 64)], 1).reshape(-1).astype(np.int32)
+        self.T, self.G, self.R, self.ragged = 2 * tiles.T, tiles.G, tiles.R, True
+        self.h_g_tile0, self.h_g_ntiles, self.h_g_count = 2 * tiles.h_g_tile0, 2 * tiles.h_g_ntiles, tiles.h_g_count
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
+        self.nrows, self.g_tile0, self.g_ntiles, self.g_count = up(self.h_nrows), up(self.h_g_tile0), up(self.h_g_ntiles), tiles.g_count
+
+
+class Segments:
+    def __init__(self, start, count, stride, group, device, div=None):
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
+        self.h_div = None if div is None else np.asarray(div, np.int64)
+        self.div = None if div is None else up(div)  # divisor per segment (default: its row count)
         self.n = len(start)
         self.h_start, self.h_count = np.asarray(start, np.int64), np.asarray(count, np.int64)
         self.h_stride, self.h_group = np.asarray(stride, np.int64), np.asarray(group, np.int64)
@@ -116,6 +145,19 @@ class BatchPlan:
             self.row_det = up(np.repeat(np.arange(Lt, dtype=np.int64), cnts))
             det_sample = np.repeat(np.arange(self.B), L)
             self.det_segs = Segments(self.pt_split[:-1], cnts, np.ones(Lt), det_sample, device)
+            # detection-aligned point tiles + "tiles of one detection" segments (fused PointNet epilogues:
+            # the GEMM writes per-tile column sums, the segment mean adds a detection's tiles and divides
+            # by its point count)
+            per_sample = [cnts[self.det_off[b]:self.det_off[b + 1]] for b in range(self.B)]
+            self.ptd_tiles = RowTiles(P_b, device, sub_counts=per_sample)
+            self.det_tile_segs = Segments(self.ptd_tiles.h_sub_tile0, self.ptd_tiles.h_sub_ntiles, np.ones(Lt),
+                                          det_sample, device, div=cnts)
+            # 64-row half tiles of ptd_tiles (the A-resident GEMM emits its partials per wave = per half tile)
+            self.ptd_half = HalfTiles(self.ptd_tiles, device)
+            self.det_half_segs = Segments(2 * self.ptd_tiles.h_sub_tile0, 2 * self.ptd_tiles.h_sub_ntiles,
+                                          np.ones(Lt), det_sample, device, div=cnts)
+            # tile t belongs to detection tile_det[t]
+            self.tile_det = up(np.repeat(np.arange(Lt, dtype=np.int64), self.ptd_tiles.h_sub_ntiles))
 
         # ---- detection spaces -------------------------------------------
         self.det_tiles = RowTiles(L, device)

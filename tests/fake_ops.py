@@ -83,7 +83,7 @@ class TorchOps:
 
     def gemm(self, W, tiles, N, K, X=None, bias=None, dbias=None, rowidx=None, Y=None, part=None,
              sc=None, sh=None, FA=None, FB=None, pair=None, amode=0, pairop=0, act=ACT_NONE,
-             w_hl16=False, oscale=1.0):
+             w_hl16=False, oscale=1.0, osc=None, osh=None, colsum=None):
         if w_hl16:  # hl16 split-half weights, pre-scaled by 1/oscale
             from mmmot_amd.pack import from_hl16
             W = from_hl16(W[:N, :K].contiguous()).double() * oscale
@@ -111,8 +111,36 @@ class TorchOps:
                 r0, n = int(tiles.h_row0[t]), int(tiles.h_nrows[t])
                 part[t, 0, :N] = v[r0:r0 + n].sum(0)
                 part[t, 1, :N] = ((v[r0:r0 + n] - part[t, 0, :N] / n) ** 2).sum(0)
+        if colsum is not None:
+            w = torch.relu(v * osc[grp, :N] + osh[grp, :N])
+            for t in range(tiles.T):
+                r0, n = int(tiles.h_row0[t]), int(tiles.h_nrows[t])
+                colsum[t, :N] = w[r0:r0 + n].sum(0).to(colsum.dtype)
         if Y is not None:
             Y[:R, :N] = _act(v, act).to(Y.dtype)
+
+    def gemm_ares(self, W16, oscale, tiles, N, K, X, sc, sh, bias=None, dbias=None, tile_dbrow=None, part=None,
+                  osc=None, osh=None, colsum=None):
+        from mmmot_amd.pack import from_hl16
+        W = from_hl16(W16[:N, :K].contiguous()).double() * oscale
+        grp = _rows_groups(tiles)
+        A = torch.relu(X[:tiles.R, :K] * sc[grp, :K] + sh[grp, :K])
+        v = A.to(self.dtype) @ W.to(self.dtype).t()
+        if bias is not None:
+            v = v + bias[:N]
+        for t in range(tiles.T):
+            r0, n = int(tiles.h_row0[t]), int(tiles.h_nrows[t])
+            vt = v[r0:r0 + n]
+            if dbias is not None:
+                vt = vt + dbias[int(tile_dbrow[t]), :N]
+            g = int(tiles.h_group[t])
+            for h in range(2):
+                vh = vt[64 * h:64 * (h + 1)]
+                if part is not None:
+                    part[2 * t + h, 0, :N] = vh.sum(0)
+                    part[2 * t + h, 1, :N] = ((vh - vh.mean(0)) ** 2).sum(0) if vh.shape[0] else 0.0
+                if colsum is not None:
+                    colsum[2 * t + h, :N] = torch.relu(vh * osc[g, :N] + osh[g, :N]).sum(0).to(colsum.dtype)
 
     def gn_finalize(self, part, tiles, C, NG, gamma, beta, eps, sc, sh):
         CG = C // NG
@@ -121,7 +149,7 @@ class TorchOps:
             p = part[t0:t0 + nt, :, :C].double()                      # [nt][2][C]: tile sum, tile-centred M2
             n_t = torch.as_tensor(tiles.h_nrows[t0:t0 + nt]).double().view(nt, 1)
             s1 = p[:, 0].sum(0).view(NG, CG).sum(1) / (cnt * CG)      # group mean
-            dev = p[:, 0] / n_t - s1.repeat_interleave(CG)            # tile-channel mean minus group mean
+            dev = torch.where(n_t > 0, p[:, 0] / n_t.clamp(min=1) - s1.repeat_interleave(CG), torch.zeros_like(p[:, 0]))
             m2 = (p[:, 1] + n_t * dev * dev).sum(0).view(NG, CG).sum(1)   # Chan et al. parallel combine
             var = m2 / (cnt * CG)
             rstd = 1.0 / torch.sqrt(var + eps)
@@ -141,7 +169,8 @@ class TorchOps:
                 rows = rows * sc[g, :C] + sh[g, :C]
             if relu:
                 rows = torch.relu(rows)
-            out[s, :C] = rows.mean(0)
+            div = getattr(segs, 'h_div', None)
+            out[s, :C] = rows.mean(0) if div is None else rows.sum(0) / float(div[s])
 
     def rowdot(self, X, K, w, b, tiles, out, sc=None, sh=None, act=ACT_NONE, use_thr=False, thr=0.0, omap=None):
         R = tiles.R

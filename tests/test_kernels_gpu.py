@@ -408,3 +408,111 @@ def test_segment_mean_hl16_input(hip):
     outg = torch.zeros(Lt, C).cuda()
     hip.segment_mean(x16.cuda(), C, sg_g, outg, use_group=False, hl16=True)
     close(outg, out, 2e-6, 'segment_mean on hl16 rows')
+
+
+# ---- fused "next GroupNorm + ReLU + per-detection mean" path (C-ABI v2) -----------------------------------
+@pytest.mark.parametrize('w_hl16', [False, True])
+def test_gemm_colsum_on_ragged_tiles_end_to_end(hip, w_hl16):
+    """Two GEMM passes (statistics only, then normalise+ReLU+column sums) on detection-aligned tiles followed
+    by the tile-segment mean must equal: materialise Y, GroupNorm(C,C), ReLU, per-detection mean."""
+    from mmmot_amd.pack import hl16_weight_shift, to_hl16
+    emu = TorchOps(torch.float64)
+    det_counts = [[130, 1, 40, 257], [5, 128, 300]]          # two samples, ragged detections
+    counts = [sum(d) for d in det_counts]
+    cpu = RowTiles(counts, 'cpu', sub_counts=det_counts)
+    gpu = RowTiles(counts, 'cuda', sub_counts=det_counts)
+    assert cpu.ragged and (cpu.h_nrows < 128).sum() > 2
+    ndet = sum(len(d) for d in det_counts)
+    flat = [c for d in det_counts for c in d]
+    N, K, R = 256, 128, sum(counts)
+    X = rnd(R, K, seed=70)
+    W = rnd(N, K, seed=71, scale=K ** -0.5)
+    bias = rnd(N, seed=72)
+    sc, sh = rnd(2, K, seed=73).abs() + 0.5, rnd(2, K, seed=74)
+    gamma, beta = rnd(N, seed=75).abs() + 0.5, rnd(N, seed=76)
+    dbias = rnd(ndet, N, seed=77)
+    rowidx = torch.repeat_interleave(torch.arange(ndet), torch.tensor(flat)).int()
+    # reference: materialised path in fp64
+    Y = torch.zeros(R, N, dtype=torch.float64)
+    plain = RowTiles(counts, 'cpu')
+    part = torch.zeros(plain.T, 2, N, dtype=torch.float64)
+    emu.gemm(W, plain, N, K, X=X, bias=bias, Y=Y, part=part, sc=sc, sh=sh, amode=1, dbias=dbias, rowidx=rowidx)
+    osc_r, osh_r = torch.zeros(2, N), torch.zeros(2, N)
+    emu.gn_finalize(part, plain, N, N, gamma, beta, 1e-5, osc_r, osh_r)
+    starts = torch.tensor([0] + flat).cumsum(0)[:-1].tolist()
+    grp = [0] * len(det_counts[0]) + [1] * len(det_counts[1])
+    ref = torch.zeros(ndet, N, dtype=torch.float64)
+    emu.segment_mean(Y, N, Segments(starts, flat, [1] * ndet, grp, 'cpu'), ref, sc=osc_r.double(), sh=osh_r.double(),
+                     relu=True)
+    # HIP: fused path
+    if w_hl16:
+        shift = hl16_weight_shift(W)
+        Wg, kw = to_hl16(W.double() * 2.0 ** shift).cuda(), dict(w_hl16=True, oscale=2.0 ** -shift)
+    else:
+        Wg, kw = W.cuda(), {}
+    args = dict(X=X.cuda(), bias=bias.cuda(), sc=sc.cuda(), sh=sh.cuda(), amode=1, dbias=dbias.cuda(),
+                rowidx=rowidx.cuda(), **kw)
+    pg = torch.full((gpu.T, 2, N), float('nan')).cuda()
+    hip.gemm(Wg, gpu, N, K, part=pg, **args)
+    oscg, oshg = torch.zeros(2, N).cuda(), torch.zeros(2, N).cuda()
+    hip.gn_finalize(pg, gpu, N, N, gamma.cuda(), beta.cuda(), 1e-5, oscg, oshg)
+    close(oscg, osc_r, 2e-5, 'scale from ragged-tile statistics')
+    close(oshg, osh_r, 2e-5, 'shift from ragged-tile statistics')
+    cs = torch.full((gpu.T, N), float('nan')).cuda()
+    hip.gemm(Wg, gpu, N, K, osc=oscg, osh=oshg, colsum=cs, **args)
+    segs = Segments(cpu.h_sub_tile0, cpu.h_sub_ntiles, [1] * ndet, grp, 'cuda', div=flat)
+    out = torch.full((ndet, N), float('nan')).cuda()
+    hip.segment_mean(cs, N, segs, out)
+    close(out, ref.float(), 2e-5, 'fused norm+relu+segment mean')
+    # and the emulation of the same calls (documents the contract of colsum / seg_div)
+    pe, ce, oe = torch.zeros(cpu.T, 2, N), torch.zeros(cpu.T, N), torch.zeros(ndet, N)
+    e32 = TorchOps(torch.float64)
+    e32.gemm(W, cpu, N, K, X=X, bias=bias, part=pe, sc=sc, sh=sh, amode=1, dbias=dbias, rowidx=rowidx)
+    se, he = torch.zeros(2, N), torch.zeros(2, N)
+    e32.gn_finalize(pe, cpu, N, N, gamma, beta, 1e-5, se, he)
+    e32.gemm(W, cpu, N, K, X=X, bias=bias, sc=sc, sh=sh, amode=1, dbias=dbias, rowidx=rowidx, osc=se, osh=he, colsum=ce)
+    e32.segment_mean(ce, N, Segments(cpu.h_sub_tile0, cpu.h_sub_ntiles, [1] * ndet, grp, 'cpu', div=flat), oe)
+    close(oe, ref.float(), 2e-5, 'emulated fused path')
+
+
+@pytest.mark.parametrize('K,N', [(128, 1024), (64, 512), (64, 128)])
+def test_gemm_ares_statistics_and_colsum(hip, K, N):
+    """A-resident GEMM: per-half-tile statistics and normalise+ReLU column sums vs the fp64 emulation, on
+    detection-aligned tiles with empty second halves (<= 64 rows), partial halves and a per-tile bias row."""
+    from mmmot_amd.pack import hl16_weight_shift, to_hl16
+    from mmmot_amd.plan import HalfTiles
+    emu = TorchOps(torch.float64)
+    det_counts = [[130, 1, 40, 257, 64], [5, 128, 300, 65]]
+    counts = [sum(d) for d in det_counts]
+    cpu = RowTiles(counts, 'cpu', sub_counts=det_counts)
+    gpu = RowTiles(counts, 'cuda', sub_counts=det_counts)
+    hc, hg = HalfTiles(cpu, 'cpu'), HalfTiles(gpu, 'cuda')
+    flat = [c for d in det_counts for c in d]
+    ndet, R = len(flat), sum(counts)
+    X = rnd(R, K, seed=80) + 0.5
+    W = rnd(N, K, seed=81, scale=K ** -0.5)
+    bias = rnd(N, seed=82)
+    sc, sh = rnd(2, K, seed=83).abs() + 0.5, rnd(2, K, seed=84)
+    dbias = rnd(ndet, N, seed=85)
+    tile_det = torch.repeat_interleave(torch.arange(ndet), torch.tensor(cpu.h_sub_ntiles).long()).int()
+    osc, osh = rnd(2, N, seed=86).abs() + 0.5, rnd(2, N, seed=87)
+    shift = hl16_weight_shift(W)
+    W16 = to_hl16(W.double() * 2.0 ** shift)
+    osv = 2.0 ** -shift
+    part, cs = torch.zeros(hc.T, 2, N, dtype=torch.float64), torch.zeros(hc.T, N, dtype=torch.float64)
+    emu.gemm_ares(W16, osv, cpu, N, K, X, sc, sh, bias=bias, dbias=dbias, tile_dbrow=tile_det, part=part,
+                  osc=osc, osh=osh, colsum=cs)
+    pg, cg = torch.full((hg.T, 2, N), float('nan')).cuda(), torch.full((hg.T, N), float('nan')).cuda()
+    hip.gemm_ares(W16.cuda(), osv, gpu, N, K, X.cuda(), sc.cuda(), sh.cuda(), bias=bias.cuda(), dbias=dbias.cuda(),
+                  tile_dbrow=tile_det.cuda(), part=pg, osc=osc.cuda(), osh=osh.cuda(), colsum=cg)
+    close(pg[:, 0], part[:, 0].float(), 1e-5, 'ares half-tile sums')
+    close(pg[:, 1], part[:, 1].float(), 1e-4, 'ares half-tile M2')
+    close(cg, cs.float(), 1e-5, 'ares column sums')
+    # the statistics feed gn_finalize through the half-tile tables
+    gamma, beta = rnd(N, seed=88).abs() + 0.5, rnd(N, seed=89)
+    s_r, h_r = torch.zeros(2, N), torch.zeros(2, N)
+    emu.gn_finalize(part, hc, N, N, gamma, beta, 1e-5, s_r, h_r)
+    s_g, h_g = torch.zeros(2, N).cuda(), torch.zeros(2, N).cuda()
+    hip.gn_finalize(pg, hg, N, N, gamma.cuda(), beta.cuda(), 1e-5, s_g, h_g)
+    close(s_g, s_r, 2e-5, 'scale from half-tile statistics')
+    close(h_g, h_r, 2e-5, 'shift from half-tile statistics')
