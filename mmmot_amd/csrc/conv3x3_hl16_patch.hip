@@ -111,22 +111,26 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA destinations stay in SGPRs
 
-  // XCD-aware, channel-tile-major order (see conv3x3_hl16.hip)
-  const int nwg = gridDim.x;
-  const int lid = mm_xcd_remap(blockIdx.x, nwg);
-  const int xq = nwg >> 3, xr = nwg & 7;
+  // Persistent workgroups: gridDim.x (a multiple of 8, at most one workgroup per CU - LDS allows no more)
+  // workgroups walk the nitems = ntm * ntn tiles.  The dispatcher places workgroup b on XCD b % 8; every XCD
+  // owns a contiguous chunk of the logical tile order (channel-tile-major inside the chunk, so the weights
+  // of a channel tile stay in that XCD's L2) and its workgroups take the chunk's tiles round-robin.  One
+  // launch-time workgroup per tile would leave the CU idle for a dispatch latency between tiles: with a
+  // single resident workgroup nothing overlaps it (measured: fixed cost of ~2 channel slabs per tile).
+  const int nitems = ntm * ntn;
+  const int xq = nitems >> 3, xr = nitems & 7;
   const int xcd = blockIdx.x & 7;
   const int cbase = (xcd < xr) ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
   const int clen = (xcd < xr) ? xq + 1 : xq;
+  for (int item = blockIdx.x >> 3; item < clen; item += gridDim.x >> 3) {
   int mt, nt;
   if (clen % ntn == 0 && cbase % ntn == 0) {
     const int mcount = clen / ntn;
-    const int s = lid - cbase;
-    nt = s / mcount;
-    mt = cbase / ntn + s % mcount;
+    nt = item / mcount;
+    mt = cbase / ntn + item % mcount;
   } else {
-    mt = lid / ntn;
-    nt = lid % ntn;
+    mt = (cbase + item) / ntn;
+    nt = (cbase + item) % ntn;
   }
   const int n0 = nt * BN;
   const int cin8 = Cin >> 3;
@@ -412,9 +416,26 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   slab_body(std::true_type{}, nslab - 1);
 
   // ---- epilogue: accumulators -> LDS fp32 [256][BN+4] -> pool/bias/relu/split -> hl16 -------------
+  // thread -> fixed channel unit u (8 channels) and rows r0, r0 + RSTEP, ...: bias is loaded once, before
+  // the barriers (a load inside the store loop costs one L2 round trip per iteration)
+  constexpr int UN = BN / 8;
+  constexpr int RSTEP = 512 / UN;  // 32 / 64
+  const int eu = tid % UN, er0 = tid / UN;
+  const f32x8 bv = *reinterpret_cast<const f32x8*>(&bias[n0 + eu * 8]);
+  // blocks of this tile: validity and first pixel (block-local (0,0)) of each
+  int bcrop[G::NB], bgy0[G::NB], bgx0[G::NB];
+#pragma unroll
+  for (int k = 0; k < G::NB; ++k) {
+    const int b = mt * G::NB + k;
+    const int crop = b / nbpc;
+    const int br = b - crop * nbpc;
+    const int by = br / nbx;
+    bcrop[k] = (b < nblk) ? crop : -1;
+    bgy0[k] = by * BS;
+    bgx0[k] = (br - by * nbx) * BS;
+  }
   __syncthreads();  // every wave is past its last LDS read; no DMA in flight (the last stages drained)
   float* Cs = reinterpret_cast<float*>(smem);
-  constexpr int UN = BN / 8;
   const int cout8 = Cout >> 3;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
@@ -426,17 +447,21 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   __syncthreads();
   if constexpr (POOL) {
     const int Hq = H >> 1, Wq = W >> 1;
-    for (int w = tid; w < (P_BM / 4) * UN; w += 512) {
-      const int qd = w / UN, u = w - qd * UN;
+#pragma unroll
+    for (int i = 0; i < (P_BM / 4) / RSTEP; ++i) {
+      const int qd = er0 + i * RSTEP;
       int blk, y, x;
       pt_row_to_pixel<BS>(qd >> 3, (qd & 7) * 4, blk, y, x);
-      const int b = mt * G::NB + blk;
-      const int crop = b / nbpc;
-      const int br = b - crop * nbpc;
-      const int by = br / nbx, bx = br - by * nbx;
-      const int gy = by * BS + y, gx = bx * BS + x;
-      if (b < nblk && gy < H && gx < W) {
-        const float* c = &Cs[(qd * 4) * CLD + u * 8];
+      int crop = bcrop[0], gy = bgy0[0] + y, gx = bgx0[0] + x;
+#pragma unroll
+      for (int k = 1; k < G::NB; ++k)
+        if (blk == k) {
+          crop = bcrop[k];
+          gy = bgy0[k] + y;
+          gx = bgx0[k] + x;
+        }
+      if (crop >= 0 && gy < H && gx < W) {
+        const float* c = &Cs[(qd * 4) * CLD + eu * 8];
         f32x8 v = *reinterpret_cast<const f32x8*>(c);
 #pragma unroll
         for (int r = 1; r < 4; ++r) {
@@ -444,41 +469,45 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], w2[e]);
         }
-        const f32x8 bv = *reinterpret_cast<const f32x8*>(&bias[n0 + u * 8]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], oscale, bv[e]), 0.f);
         u32x4 hi, lo;
         pt_split8(v, hi, lo);
         const long pix = ((long)crop * Hq + (gy >> 1)) * Wq + (gx >> 1);
-        u32x4* o = out + (pix * cout8 + (n0 >> 3) + u) * 2;
+        u32x4* o = out + (pix * cout8 + (n0 >> 3) + eu) * 2;
         o[0] = hi;
         o[1] = lo;
       }
     }
   } else {
-    for (int w = tid; w < P_BM * UN; w += 512) {
-      const int r = w / UN, u = w - r * UN;
+#pragma unroll
+    for (int i = 0; i < P_BM / RSTEP; ++i) {
+      const int r = er0 + i * RSTEP;
       int blk, y, x;
       pt_row_to_pixel<BS>(r >> 5, r & 31, blk, y, x);
-      const int b = mt * G::NB + blk;
-      const int crop = b / nbpc;
-      const int br = b - crop * nbpc;
-      const int by = br / nbx, bx = br - by * nbx;
-      const int gy = by * BS + y, gx = bx * BS + x;
-      if (b < nblk && gy < H && gx < W) {
-        f32x8 v = *reinterpret_cast<const f32x8*>(&Cs[r * CLD + u * 8]);
-        const f32x8 bv = *reinterpret_cast<const f32x8*>(&bias[n0 + u * 8]);
+      int crop = bcrop[0], gy = bgy0[0] + y, gx = bgx0[0] + x;
+#pragma unroll
+      for (int k = 1; k < G::NB; ++k)
+        if (blk == k) {
+          crop = bcrop[k];
+          gy = bgy0[k] + y;
+          gx = bgx0[k] + x;
+        }
+      if (crop >= 0 && gy < H && gx < W) {
+        f32x8 v = *reinterpret_cast<const f32x8*>(&Cs[r * CLD + eu * 8]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], oscale, bv[e]), 0.f);
         u32x4 hi, lo;
         pt_split8(v, hi, lo);
         const long pix = ((long)crop * H + gy) * W + gx;
-        u32x4* o = out + (pix * cout8 + (n0 >> 3) + u) * 2;
+        u32x4* o = out + (pix * cout8 + (n0 >> 3) + eu) * 2;
         o[0] = hi;
         o[1] = lo;
       }
     }
   }
+  __syncthreads();  // the staging area is the next tile's patch / ring
+  }  // persistent tile loop
 }
 
 static int g_patch_exp = 0;
@@ -496,7 +525,17 @@ static int launch_patch_e(const void* in, const void* wp, const float* bias, voi
   constexpr int NB = PatchGeom<BS>::NB;
   const int ntm = (nblk + NB - 1) / NB;
   const int ntn = Cout / BN;
-  hipLaunchKernelGGL((conv3x3_hl16_patch_kernel<BN, BS, POOL, EXP>), dim3(ntm * ntn), dim3(512), 0, s, (const u32x4*)in,
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MMMOT_EINVAL;
+    n_cu = prop.multiProcessorCount;
+  }
+  const int nitems = ntm * ntn;
+  int grid = (n_cu / 8) * 8;                       // one persistent workgroup per CU, whole XCDs
+  if (grid > ((nitems + 7) / 8) * 8) grid = ((nitems + 7) / 8) * 8;
+  hipLaunchKernelGGL((conv3x3_hl16_patch_kernel<BN, BS, POOL, EXP>), dim3(grid), dim3(512), 0, s, (const u32x4*)in,
                      (const u32x4*)wp, bias, (u32x4*)out, L, H, W, Cin, Cout, nby, nbx, nblk, ntm, ntn, oscale);
   return mm_check(hipGetLastError());
 }

@@ -15,6 +15,8 @@
 // stage), the per-tile epilogue is register-only (each wave owns 64 rows x 32 channels: column sums by
 // lane-half shuffle, statistics centred on the wave's own 64-row mean), nothing but the partials is stored.
 // Arithmetic: fp16 matrix cores with the 3-term hi/lo split (same as gemm_rows F16 / conv3x3_hl16).
+#include <type_traits>
+
 #include "common.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -26,7 +28,13 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define AR_LDT 72  // halves per LDS row (144 B): conflict-free ds_read_b128
 #define AR_THREADS 512
 
-template <int KS>  // K / 64
+static __device__ float ar_zeros[4096];  // stands in for absent bias / dbias / osc / osh rows (branch-free loads)
+
+// KS = K / 64; MODE bit 0: statistics (part), bit 1: normalise + ReLU + column sums (colsum).
+// Every global load of the K loop is unconditional (indices clamped at the end): with a fixed number of
+// loads in flight the compiler can wait with counted vmcnt(N) instead of draining the two weight stages
+// that are meant to stay in flight.
+template <int KS, int MODE>
 __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_args a) {
   constexpr int PLANE = AR_BM * AR_LDT;  // halves per [128][72] plane
   __shared__ __attribute__((aligned(16))) _Float16 As[KS][2][PLANE];  // [k stage][hi, lo]
@@ -50,23 +58,27 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
   const int wrow = tid >> 2, wq = tid & 3;
   const u32x4* wp = reinterpret_cast<const u32x4*>(a.W);
   const long ku = (long)(a.K >> 3);  // hl16 units per weight row
-  u32x4 rw[4];                       // hi, lo of two units
-  auto load_w = [&](int s) {
+  u32x4 rw[2][4];                    // two stages in flight; hi, lo of two units each
+  auto load_w = [&](int s, auto SLOT) {
+    constexpr int sl = decltype(SLOT)::value;
     const int nt = s / KS, ks = s - nt * KS;
     const u32x4* p = wp + ((long)(nt * AR_BN + wrow) * ku + ks * 8 + wq * 2) * 2;
-    rw[0] = p[0];
-    rw[1] = p[1];
-    rw[2] = p[2];
-    rw[3] = p[3];
+    rw[sl][0] = p[0];
+    rw[sl][1] = p[1];
+    rw[sl][2] = p[2];
+    rw[sl][3] = p[3];
   };
-  auto store_w = [&](int buf) {
+  auto store_w = [&](int buf, auto SLOT) {
+    constexpr int sl = decltype(SLOT)::value;
     _Float16* bh = &Bs[buf][0][wrow * AR_LDT + wq * 16];
     _Float16* bl = &Bs[buf][1][wrow * AR_LDT + wq * 16];
-    *reinterpret_cast<u32x4*>(bh) = rw[0];
-    *reinterpret_cast<u32x4*>(bl) = rw[1];
-    *reinterpret_cast<u32x4*>(bh + 8) = rw[2];
-    *reinterpret_cast<u32x4*>(bl + 8) = rw[3];
+    *reinterpret_cast<u32x4*>(bh) = rw[sl][0];
+    *reinterpret_cast<u32x4*>(bl) = rw[sl][1];
+    *reinterpret_cast<u32x4*>(bh + 8) = rw[sl][2];
+    *reinterpret_cast<u32x4*>(bl + 8) = rw[sl][3];
   };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
 
   // ---- activation rows: normalise + ReLU + hi/lo split, once --------------------------------------------
   {
@@ -98,9 +110,12 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
       *reinterpret_cast<f16x8*>(&As[ks][1][r * AR_LDT + kk]) = lo;
     }
   }
-  load_w(0);
-  store_w(0);
-  if (NS > 1) load_w(1);
+  // weight stages: s -> register slot s & 1; two stages of global loads are always in flight (one LDS
+  // stage of latency is not enough: the L2 round trip under load is longer than a 24-MFMA stage)
+  load_w(0, S0{});
+  load_w(min(1, NS - 1), S1{});
+  store_w(0, S0{});
+  load_w(min(2, NS - 1), S0{});
   __syncthreads();
 
   f32x16 acc[2];
@@ -113,15 +128,36 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
   const float inv_nsub = nsub > 0 ? 1.f / (float)nsub : 0.f;
   const long prow = (long)(2 * t + wm);
 
-  for (int s = 0; s < NS; ++s) {
-    const int nt = s / KS, ks = s - nt * KS;
-    // stage s+1 -> the other buffer (last read in stage s-1, every wave is past that barrier)
-    if (s + 1 < NS) store_w((s + 1) & 1);
-    if (s + 2 < NS) load_w(s + 2);
+  // per-channel epilogue constants of a channel tile: combined bias, output scale / shift.  They are
+  // loaded one channel tile ahead and BEFORE the weight loads of that stage: vmcnt retires in order, so a
+  // load issued at epilogue time would also wait for the two weight stages in flight.
+  const float* pbias = a.bias ? a.bias : ar_zeros;
+  const float* pdb = a.dbias ? a.dbias + (long)a.tile_dbrow[t] * a.lddb : ar_zeros;
+  const float* posc = (MODE & 2) ? a.osc + (long)grp * a.ldosc : ar_zeros;
+  const float* posh = (MODE & 2) ? a.osh + (long)grp * a.ldosc : ar_zeros;
+  auto epi_consts = [&](int nt, float& cb, float& os, float& oh) {
+    const int n = nt * AR_BN + wn * 32 + lr;
+    cb = pbias[n] + pdb[n];
+    os = posc[n];
+    oh = posh[n];
+  };
+  float cbc, osc_c, osh_c, cbn = 0.f, osc_n = 0.f, osh_n = 0.f;
+  epi_consts(0, cbc, osc_c, osh_c);
+  const bool full = (nsub == 64);
+
+  auto stage = [&](int s, auto ODD) {
+    constexpr int odd = decltype(ODD)::value;  // s & 1
+    constexpr int ks = (KS == 2) ? odd : 0;  // NS is a multiple of KS and stages alternate
+    const int nt = s / KS;
+    if constexpr (ks == 0) epi_consts(min(nt + 1, ntn - 1), cbn, osc_n, osh_n);
+    // stage s+1 (register slot !odd) -> the other LDS buffer (last read in stage s-1, every wave is past
+    // that barrier); then its slot takes the loads of stage s+3 (clamped: the tail re-loads the last stage)
+    store_w(1 - odd, std::integral_constant<int, 1 - odd>{});
+    load_w(min(s + 3, NS - 1), std::integral_constant<int, 1 - odd>{});
     const _Float16* ah = &As[ks][0][0];
     const _Float16* al = &As[ks][1][0];
-    const _Float16* bh = &Bs[s & 1][0][0];
-    const _Float16* bl = &Bs[s & 1][1][0];
+    const _Float16* bh = &Bs[odd][0][0];
+    const _Float16* bl = &Bs[odd][1][0];
 #pragma unroll
     for (int k16 = 0; k16 < AR_BK / 16; ++k16) {
       f16x8 fah[2], fal[2];
@@ -141,56 +177,93 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[tm], fbh, acc[tm], 0, 0, 0);
     }
-    if (ks == KS - 1) {
+    if constexpr (ks == KS - 1) {
       // ---- channel tile nt finished: register-only epilogue for this wave's 64 rows x 32 channels ----
+      // v = acc*oscale + cb is never formed for full half tiles: the sums are taken on the raw accumulators
+      // and rescaled (S = oscale*sum(acc) + n*cb, M2 = oscale^2 * M2(acc), relu(v*os+oh) = relu(acc*(oscale*os)
+      // + (cb*os+oh))); 3 VALU ops per value.
       const int n = nt * AR_BN + wn * 32 + lr;
-      float cb = a.bias ? a.bias[n] : 0.f;
-      if (a.dbias) cb += a.dbias[(long)a.tile_dbrow[t] * a.lddb + n];
-      float v[32];
-      float s1 = 0.f;
+      const float cb = cbc, os = osc_c, oh = osh_c;  // fetched one channel tile ahead (see below)
+      if constexpr (MODE & 1) {
+        float s1 = 0.f;
+        if (full) {
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
+          for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int r = wm * 64 + tm * 32 + mm_acc_row(e, lane);
-          const float x = fmaf(acc[tm][e], a.oscale, cb);
-          v[tm * 16 + e] = (r < nrows) ? x : 0.f;
-          s1 += v[tm * 16 + e];
-          acc[tm][e] = 0.f;
+            for (int e = 0; e < 16; ++e) s1 += acc[tm][e];
+        } else {
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+              if (wm * 64 + tm * 32 + mm_acc_row(e, lane) < nrows) s1 += acc[tm][e];
         }
-      if (a.part) {
         s1 += __shfl_xor(s1, 32);
-        const float mu = s1 * inv_nsub;
+        const float mu = s1 * inv_nsub;  // mean of the raw accumulators over the half tile
         float s2 = 0.f;
+        if (full) {
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
+          for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int r = wm * 64 + tm * 32 + mm_acc_row(e, lane);
-            const float d = v[tm * 16 + e] - mu;
-            if (r < nrows) s2 += d * d;
-          }
+            for (int e = 0; e < 16; ++e) {
+              const float d = acc[tm][e] - mu;
+              s2 = fmaf(d, d, s2);
+            }
+        } else {
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const float d = acc[tm][e] - mu;
+              if (wm * 64 + tm * 32 + mm_acc_row(e, lane) < nrows) s2 = fmaf(d, d, s2);
+            }
+        }
         s2 += __shfl_xor(s2, 32);
         if (lane < 32) {
-          a.part[(prow * 2 + 0) * a.N + n] = s1;
-          a.part[(prow * 2 + 1) * a.N + n] = s2;
+          a.part[(prow * 2 + 0) * a.N + n] = fmaf(s1, a.oscale, (float)nsub * cb);
+          a.part[(prow * 2 + 1) * a.N + n] = s2 * a.oscale * a.oscale;
         }
       }
-      if (a.colsum) {
-        const float os = a.osc[(long)grp * a.ldosc + n], oh = a.osh[(long)grp * a.ldosc + n];
+      if constexpr (MODE & 2) {
+        const float m1 = a.oscale * os, m0 = fmaf(cb, os, oh);
         float s3 = 0.f;
+        if (full) {
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
+          for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int r = wm * 64 + tm * 32 + mm_acc_row(e, lane);
-            if (r < nrows) s3 += fmaxf(fmaf(v[tm * 16 + e], os, oh), 0.f);
-          }
+            for (int e = 0; e < 16; ++e) s3 += fmaxf(fmaf(acc[tm][e], m1, m0), 0.f);
+        } else {
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+              if (wm * 64 + tm * 32 + mm_acc_row(e, lane) < nrows) s3 += fmaxf(fmaf(acc[tm][e], m1, m0), 0.f);
+        }
         s3 += __shfl_xor(s3, 32);
         if (lane < 32) a.colsum[prow * a.N + n] = s3;
       }
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[tm][e] = 0.f;
+      cbc = cbn;
+      osc_c = osc_n;
+      osh_c = osh_n;
     }
     __syncthreads();
+  };
+  if constexpr (KS == 2) {
+    for (int s = 0; s < NS; s += 2) {
+      stage(s, S0{});
+      stage(s + 1, S1{});
+    }
+  } else {
+    int s = 0;
+    for (; s + 1 < NS; s += 2) {
+      stage(s, S0{});
+      stage(s + 1, S1{});
+    }
+    if (s < NS) stage(s, S0{});
   }
 }
 
@@ -203,9 +276,15 @@ extern "C" int mmmot_gemm_ares(const mmmot_gemm_ares_args* a, void* stream) {
   if (a->dbias && !a->tile_dbrow) return MMMOT_EINVAL;
   if (a->colsum && (!a->osc || !a->osh)) return MMMOT_EINVAL;
   if (!a->part && !a->colsum) return MMMOT_EINVAL;  // nothing to produce
-  if (a->K == 128)
-    hipLaunchKernelGGL(gemm_ares_kernel<2>, dim3(a->T), dim3(AR_THREADS), 0, s, *a);
-  else
-    hipLaunchKernelGGL(gemm_ares_kernel<1>, dim3(a->T), dim3(AR_THREADS), 0, s, *a);
+  if (a->N > 4096) return MMMOT_EINVAL;
+  const int mode = (a->part ? 1 : 0) | (a->colsum ? 2 : 0);
+#define AR_LAUNCH(KSV, MODEV) \
+  hipLaunchKernelGGL((gemm_ares_kernel<KSV, MODEV>), dim3(a->T), dim3(AR_THREADS), 0, s, *a)
+  if (a->K == 128) {
+    if (mode == 1) AR_LAUNCH(2, 1); else if (mode == 2) AR_LAUNCH(2, 2); else AR_LAUNCH(2, 3);
+  } else {
+    if (mode == 1) AR_LAUNCH(1, 1); else if (mode == 2) AR_LAUNCH(1, 2); else AR_LAUNCH(1, 3);
+  }
+#undef AR_LAUNCH
   return mm_check(hipGetLastError());
 }
