@@ -275,6 +275,26 @@ int mmmot_softmax_pairs(const float* logits, float* out,
                         int max_nm /* max over groups of N+M (LDS sizing) */,
                         int mode, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Point-cloud gather (the step that produces det_info['points'] /
+ * det_info['points_split'] for the path above).  Replaces the numba loop
+ * _points_in_convex_polygon_3d_jit (reference point_cloud/geometry.py:96-114) and the per-box
+ * boolean-index loop of read_and_prep_points (point_cloud/preprocess.py:70-96).
+ *   pts    [P][F] fp32, F = 3 or 4, xyz first
+ *   planes [NB][6][4] fp64 rows (nx, ny, nz, d) of convex polygons whose normals point inwards (3D boxes,
+ *          image / 2D-box frustums); a point is inside iff ((x*nx + y*ny) + z*nz) + d < 0 for all six,
+ *          evaluated in fp64 left to right without FMA contraction - the reference's arithmetic, so the
+ *          decision is bit-identical.  NB <= 256 per call.
+ * mmmot_points_count : cnt (ints, NB*ceil(P/256) + NB) and split [NB+1] = first output row of every polygon;
+ *                      with pad_empty an empty polygon owns ONE all-zero row (preprocess.py:80-81).
+ * mmmot_points_scatter: out [split[NB]][Fo] = per polygon its inside points in input order; Fo == F, or
+ *                      Fo == 3 with F == 4 (the reflectivity column dropped, preprocess.py:97-100).
+ * The caller reads split[NB] (one D2H of the split it hands to the host plan anyway) to size out. */
+int mmmot_points_count(const float* pts, int P, int F, const double* planes, int NB, int pad_empty,
+                       int* cnt, int* split, void* stream);
+int mmmot_points_scatter(const float* pts, int P, int F, const double* planes, int NB, const int* cnt,
+                         const int* split, float* out, int Fo, void* stream);
+
 /* MFMA fragment-layout self test: C[32][32] = A[32][K] * B[32][K]^T through
  * the same fragment mapping the GEMM kernels use (K % 8 == 0). */
 int mmmot_selftest_mfma(const float* A, const float* B, float* C, int K, void* stream);

@@ -1,0 +1,155 @@
+// Point-cloud gather: which LiDAR points lie inside which convex polygon (3D box or image frustum), and the
+// per-polygon ordered compaction that produces det_info['points'] / det_info['points_split']
+// (see include/mmmot_hip.h: mmmot_points_count / mmmot_points_scatter).
+//
+// Replaces the numba loop _points_in_convex_polygon_3d_jit (reference point_cloud/geometry.py:96-114) and
+// the per-box boolean-index loop of read_and_prep_points (point_cloud/preprocess.py:70-96).  HBM-bound byte
+// shuffling: every point is read twice (count pass, scatter pass), every kept point written once; the
+// membership arithmetic is the reference's - float64, left to right, no FMA contraction - so that the
+// inside/outside decision is bit-identical.
+#include "common.h"
+
+#define PG_THREADS 256
+#define PG_MAX_POLY 256  // polygons per call (24 doubles each in LDS)
+
+__device__ __forceinline__ bool pg_inside(double x, double y, double z, const double* __restrict__ pl) {
+  bool in = true;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    // ((x*nx + y*ny) + z*nz) + d, each operation rounded on its own (numba without fastmath)
+    double s = __dadd_rn(__dmul_rn(x, pl[4 * k + 0]), __dmul_rn(y, pl[4 * k + 1]));
+    s = __dadd_rn(s, __dmul_rn(z, pl[4 * k + 2]));
+    s = __dadd_rn(s, pl[4 * k + 3]);
+    in = in && !(s >= 0.0);
+  }
+  return in;
+}
+
+__device__ __forceinline__ void pg_load_planes(double* lpl, const double* __restrict__ planes, int NB) {
+  for (int i = threadIdx.x; i < NB * 24; i += PG_THREADS) lpl[i] = planes[i];
+}
+
+__global__ __launch_bounds__(PG_THREADS) void pg_count_kernel(const float* __restrict__ pts, int P, int F,
+                                                              const double* __restrict__ planes, int NB,
+                                                              int* __restrict__ cnt, int nblk) {
+  __shared__ double lpl[PG_MAX_POLY * 24];
+  __shared__ int lcnt[PG_MAX_POLY];
+  pg_load_planes(lpl, planes, NB);
+  for (int j = threadIdx.x; j < NB; j += PG_THREADS) lcnt[j] = 0;
+  __syncthreads();
+  const int i = blockIdx.x * PG_THREADS + threadIdx.x;
+  const bool valid = i < P;
+  double x = 0, y = 0, z = 0;
+  if (valid) {
+    x = (double)pts[(long)i * F + 0];
+    y = (double)pts[(long)i * F + 1];
+    z = (double)pts[(long)i * F + 2];
+  }
+  const int lane = threadIdx.x & 63;
+  for (int j = 0; j < NB; ++j) {
+    const bool in = valid && pg_inside(x, y, z, &lpl[j * 24]);
+    const unsigned long long m = __ballot(in);
+    if (lane == 0 && m) atomicAdd(&lcnt[j], __popcll(m));
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < NB; j += PG_THREADS) cnt[(long)j * nblk + blockIdx.x] = lcnt[j];
+}
+
+// One workgroup: per polygon, the per-block counts become exclusive offsets; split = cumulative rows per
+// polygon (an empty polygon occupies one row when pad_empty).
+__global__ __launch_bounds__(PG_THREADS) void pg_scan_kernel(int* __restrict__ cnt, int NB, int nblk, int pad_empty,
+                                                             int* __restrict__ split) {
+  __shared__ int rows[PG_MAX_POLY];
+  for (int j = threadIdx.x; j < NB; j += PG_THREADS) {
+    int run = 0;
+    int* c = cnt + (long)j * nblk;
+    for (int b = 0; b < nblk; ++b) {
+      const int v = c[b];
+      c[b] = run;
+      run += v;
+    }
+    rows[j] = (run == 0 && pad_empty) ? 1 : run;
+    cnt[(long)NB * nblk + j] = run;  // polygon totals follow the [NB][nblk] offsets
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int j = 0; j < NB; ++j) {
+      split[j] = run;
+      run += rows[j];
+    }
+    split[NB] = run;
+  }
+}
+
+__global__ __launch_bounds__(PG_THREADS) void pg_scatter_kernel(const float* __restrict__ pts, int P, int F,
+                                                                const double* __restrict__ planes, int NB,
+                                                                const int* __restrict__ off, int nblk,
+                                                                const int* __restrict__ split, float* __restrict__ out,
+                                                                int Fo) {
+  __shared__ double lpl[PG_MAX_POLY * 24];
+  __shared__ int wcnt[PG_MAX_POLY][PG_THREADS / 64];
+  pg_load_planes(lpl, planes, NB);
+  __syncthreads();
+  const int i = blockIdx.x * PG_THREADS + threadIdx.x;
+  const bool valid = i < P;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (valid) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < F) v[c] = pts[(long)i * F + c];
+  }
+  const double x = (double)v[0], y = (double)v[1], z = (double)v[2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int j = 0; j < NB; ++j) {
+    const bool in = valid && pg_inside(x, y, z, &lpl[j * 24]);
+    const unsigned long long m = __ballot(in);
+    if (lane == 0) wcnt[j][wave] = __popcll(m);
+  }
+  __syncthreads();
+  for (int j = 0; j < NB; ++j) {
+    const bool in = valid && pg_inside(x, y, z, &lpl[j * 24]);
+    const unsigned long long m = __ballot(in);
+    if (in) {
+      int pos = __popcll(m & ((1ull << lane) - 1ull));
+      for (int w = 0; w < wave; ++w) pos += wcnt[j][w];
+      float* o = out + ((long)split[j] + off[(long)j * nblk + blockIdx.x] + pos) * Fo;
+      o[0] = v[0];
+      o[1] = v[1];
+      o[2] = v[2];
+      if (Fo == 4) o[3] = v[3];
+    }
+  }
+}
+
+// An empty polygon owns ONE all-zero row (preprocess.py:80-81): total[j] == 0 while split says one row.
+__global__ void pg_pad_kernel(const int* __restrict__ total, const int* __restrict__ split, int NB, float* __restrict__ out,
+                              int Fo) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < NB && total[j] == 0 && split[j + 1] - split[j] == 1)
+    for (int c = 0; c < Fo; ++c) out[(long)split[j] * Fo + c] = 0.f;
+}
+
+extern "C" int mmmot_points_count(const float* pts, int P, int F, const double* planes, int NB, int pad_empty,
+                                  int* cnt, int* split, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!pts || !planes || !cnt || !split || P <= 0 || NB <= 0 || NB > PG_MAX_POLY) return MMMOT_EINVAL;
+  if (F != 3 && F != 4) return MMMOT_EINVAL;
+  const int nblk = (P + PG_THREADS - 1) / PG_THREADS;
+  // cnt: [NB][nblk] per-block counts -> exclusive block offsets, followed by [NB] polygon totals
+  hipLaunchKernelGGL(pg_count_kernel, dim3(nblk), dim3(PG_THREADS), 0, s, pts, P, F, planes, NB, cnt, nblk);
+  hipLaunchKernelGGL(pg_scan_kernel, dim3(1), dim3(PG_THREADS), 0, s, cnt, NB, nblk, pad_empty, split);
+  return mm_check(hipGetLastError());
+}
+
+extern "C" int mmmot_points_scatter(const float* pts, int P, int F, const double* planes, int NB, const int* cnt,
+                                    const int* split, float* out, int Fo, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!pts || !planes || !cnt || !split || !out || P <= 0 || NB <= 0 || NB > PG_MAX_POLY) return MMMOT_EINVAL;
+  if ((F != 3 && F != 4) || (Fo != 3 && Fo != F)) return MMMOT_EINVAL;
+  const int nblk = (P + PG_THREADS - 1) / PG_THREADS;
+  hipLaunchKernelGGL(pg_scatter_kernel, dim3(nblk), dim3(PG_THREADS), 0, s, pts, P, F, planes, NB, cnt, nblk, split,
+                     out, Fo);
+  hipLaunchKernelGGL(pg_pad_kernel, dim3((NB + 63) / 64), dim3(64), 0, s, cnt + (long)NB * nblk, split, NB, out, Fo);
+  return mm_check(hipGetLastError());
+}

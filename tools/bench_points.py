@@ -1,0 +1,99 @@
+#!/usr/bin/env python
+"""Throughput of the device point-cloud gather on one MI355X, CPU oracle timed beside it.
+
+    python tools/bench_points.py [--points 120000] [--boxes 16] [--sweeps 64] [--steps 20]
+
+Workload: ``--sweeps`` KITTI-like sweeps of ``--points`` x 4 floats each, resident in HBM; per sweep the
+reference's two stages (image-frustum filter: 1 polygon, no padding; per-box gather: ``--boxes`` 3D boxes,
+zero-row padding, reflectivity dropped).  One JSON line: sweeps/s, the HBM roofline of the gather kernels
+(algorithmic bytes = every input point read twice - count pass, scatter pass - plus the rows written, measured
+with HIP events around the launches) and the numpy oracle on the host cores."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mmmot_amd import points as PT  # noqa: E402
+
+
+def scene(seed, P, N):
+    rng = np.random.default_rng(seed)
+    pts = np.stack([rng.uniform(0, 70, P), rng.uniform(-30, 30, P), rng.uniform(-2.5, 1.0, P), rng.uniform(0, 1, P)], 1)
+    boxes = np.concatenate([rng.uniform([5, -20, -1.9], [50, 20, -1.2], (N, 3)), rng.uniform([1.4, 3.2, 1.3], [2, 4.8, 1.8], (N, 3)),
+                            rng.uniform(-3.1, 3.1, (N, 1))], 1)
+    return pts.astype(np.float32), boxes
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--points', type=int, default=120000)
+    ap.add_argument('--boxes', type=int, default=16)
+    ap.add_argument('--sweeps', type=int, default=64)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--cpu-sweeps', type=int, default=8)
+    a = ap.parse_args()
+    from oracle import points_ref as O  # baseline / checker only
+    P, N = a.points, a.boxes
+    sc = [scene(100 + i, P, N) for i in range(a.sweeps)]
+    view = O.rbbox_planes(np.array([[33.5, 0.0, -3.0, 63.0, 56.0, 3.9, 0.0]]))  # a box-shaped field of view: most points
+    dev = [(torch.from_numpy(p).cuda(), O.rbbox_planes(b)) for p, b in sc]
+    torch.cuda.synchronize()
+
+    def step():
+        rows = 0
+        for pts, planes in dev:
+            kept, _ = PT.gather_points(pts, view, pad_empty=False)
+            r, split = PT.gather_points(kept, planes, pad_empty=True, drop_reflectivity=True)
+            rows += kept.shape[0] + r.shape[0]
+        return rows
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # kernel-only time of the two gathers (HIP events on the launch stream, one sweep at a time)
+    ev_ms, bytes_alg = 0.0, 0.0
+    for pts, planes in dev:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        kept, _ = PT.gather_points(pts, view, pad_empty=False)
+        r, _ = PT.gather_points(kept, planes, pad_empty=True, drop_reflectivity=True)
+        e1.record()
+        torch.cuda.synchronize()
+        ev_ms += e0.elapsed_time(e1)
+        bytes_alg += 2 * pts.numel() * 4 + kept.numel() * 4 + 2 * kept.numel() * 4 + r.numel() * 4
+    # parity + CPU baseline on a bounded sample
+    times = []
+    for (p, b), (pd, planes) in list(zip(sc, dev))[:a.cpu_sweeps]:
+        t1 = time.perf_counter()
+        keep = O.inside_planes(p, view)[:, 0]
+        rows, split = O.gather_per_box(p[keep], planes)
+        times.append(time.perf_counter() - t1)
+        kept, _ = PT.gather_points(pd, view, pad_empty=False)
+        r, gs = PT.gather_points(kept, planes, pad_empty=True, drop_reflectivity=True)
+        assert gs.tolist() == split.tolist() and np.array_equal(r.cpu().numpy(), rows[:, :3]), 'parity'
+    sweeps = a.steps * a.sweeps
+    gbps = bytes_alg / (ev_ms * 1e-3) / 1e9
+    print(json.dumps({
+        'metric': 'LiDAR sweeps/s through the point-cloud gather (frustum filter + per-box compaction)',
+        'value': round(sweeps / dt, 1), 'unit': 'sweeps/s', 'n_gpus': 1, 'steps': a.steps, 'higher_is_better': True,
+        'dtype': 'f64 membership test on f32 points', 'data': 'synthetic',
+        'config': {'workload': '%d sweeps x %d points x 4 floats, 1 + %d polygons per sweep' % (a.sweeps, P, N)},
+        'roofline': {'bound': 'hbm', 'achieved': round(gbps, 1), 'peak': 8000.0, 'unit': 'GB/s',
+                     'frac': round(gbps / 8000.0, 4), 'traffic': None,
+                     'note': 'includes the split D2H and launch gaps between the 5 small kernels per gather: the '
+                             'sweeps are 1.9 MB each, far below what fills the chip'},
+        'cpu_baseline': {'value': round(1.0 / float(np.median(times)), 2), 'unit': 'sweeps/s', 'cores': os.cpu_count(),
+                         'kind': 'port', 'sample': '%d sweeps, numpy-vectorised oracle (the reference loop is numba)' % len(times)},
+        'parity': 'bit-exact rows and split on %d sweeps' % len(times)}))
+
+
+if __name__ == '__main__':
+    main()
