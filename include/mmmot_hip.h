@@ -295,6 +295,21 @@ int mmmot_points_count(const float* pts, int P, int F, const double* planes, int
 int mmmot_points_scatter(const float* pts, int P, int F, const double* planes, int NB, const int* cnt,
                          const int* split, float* out, int Fo, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Per-detection image preparation: crop with zero padding -> antialiased bilinear
+ * resize to S x S -> to_tensor -> normalize = the model input ``dets`` [N][3][S][S].  Replaces, per
+ * detection, PIL img.crop(box).resize((S, S), Image.BILINEAR) + torchvision ToTensor/Normalize
+ * (reference dataset/test_seq_dataset.py:212-218, utils/build_util.py:111-112,137-142) with Pillow's
+ * arithmetic (Resample.c: double-precision triangle coefficients, 22-bit fixed point, two passes with an
+ * 8-bit intermediate): the uint8 image and the float32 tensor are bit-identical to that pipeline.
+ *   img   [H][W][3] uint8 (RGB frame, device)      boxes [N][4] int (x1, y1, x2, y2), may leave the frame
+ *   kmax  >= 2*ceil(max(1, max box extent / S)) + 1 (coefficients per output index)
+ *   mean_std [6] floats (mean rgb, std rgb)          work  N*2*S*(2+kmax) ints (scratch)
+ *   out   [N][3][S][S] fp32                           out_u8 [N][S][S][3] uint8 or NULL (the resized image)
+ * S <= 256. */
+int mmmot_crop_resize_norm(const unsigned char* img, int H, int W, const int* boxes, int N, int S, int kmax,
+                           const float* mean_std, int* work, float* out, unsigned char* out_u8, void* stream);
+
 /* MFMA fragment-layout self test: C[32][32] = A[32][K] * B[32][K]^T through
  * the same fragment mapping the GEMM kernels use (K % 8 == 0). */
 int mmmot_selftest_mfma(const float* A, const float* B, float* C, int K, void* stream);

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libmmmot_hip.so')
 SOURCES = ['conv3x3.hip', 'conv3x3_hl16.hip', 'conv3x3_hl16_dma.hip', 'conv3x3_hl16_patch.hip', 'gemm_rows.hip',
-           'gemm_ares.hip', 'points_gather.hip', 'small_kernels.hip']
+           'gemm_ares.hip', 'points_gather.hip', 'crop_resize.hip', 'small_kernels.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 HIPFLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
 
@@ -92,6 +92,7 @@ SIGNATURES = {
     'mmmot_softmax_pairs': [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f],
     'mmmot_points_count': [c_f, c_i, c_i, c_f, c_i, c_i, c_f, c_f, c_f],
     'mmmot_points_scatter': [c_f, c_i, c_i, c_f, c_i, c_f, c_f, c_f, c_i, c_f],
+    'mmmot_crop_resize_norm': [c_f, c_i, c_i, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f],
     'mmmot_selftest_mfma': [c_f, c_f, c_f, c_i, c_f],
 }
 
