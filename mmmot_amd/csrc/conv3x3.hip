@@ -143,9 +143,14 @@ __global__ __launch_bounds__(MM_THREADS, 2) void conv3x3_kernel(
               acc[tm][tn][e];
     __syncthreads();
     constexpr int UN = BN / 8;
+    constexpr int RSTEP = MM_THREADS / UN;  // rows per sweep; the thread's channel unit is fixed
     u32x4* out16 = reinterpret_cast<u32x4*>(out);
-    for (int w = tid; w < MM_BM * UN; w += MM_THREADS) {
-      const int r = w / UN, u = w - r * UN;
+    const int u = tid % UN, r0 = tid / UN;
+    float bv[8];  // loaded once (a load inside the store loop costs an L2 round trip per iteration)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = bias[n0 + u * 8 + e];
+#pragma unroll 4
+    for (int r = r0; r < MM_BM; r += RSTEP) {
       const int m = mt * MM_BM + r;
       if (m < Mtot) {
         const int q = m >> 2, sub = m & 3;
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(MM_THREADS, 2) void conv3x3_kernel(
         f16x8 hh, ll;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float val = fminf(fmaxf(Cs[r * CLD + u * 8 + e] + bias[n0 + u * 8 + e], 0.f), 65000.f);
+          const float val = fminf(fmaxf(Cs[r * CLD + u * 8 + e] + bv[e], 0.f), 65000.f);
           hh[e] = (_Float16)val;
           ll[e] = (_Float16)(val - (float)hh[e]);
         }

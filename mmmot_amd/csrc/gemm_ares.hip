@@ -154,29 +154,58 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
     // that barrier); then its slot takes the loads of stage s+3 (clamped: the tail re-loads the last stage)
     store_w(1 - odd, std::integral_constant<int, 1 - odd>{});
     load_w(min(s + 3, NS - 1), std::integral_constant<int, 1 - odd>{});
+    // Four 16-channel steps; the fragments of step j+1 are read while the six MFMAs of step j issue, one
+    // read per MFMA (sched_barrier pins the order): the two waves of a SIMD run in lockstep after every
+    // barrier, so an LDS round trip that is not covered by this wave's own MFMAs is idle matrix-pipe time.
     const _Float16* ah = &As[ks][0][0];
     const _Float16* al = &As[ks][1][0];
     const _Float16* bh = &Bs[odd][0][0];
     const _Float16* bl = &Bs[odd][1][0];
-#pragma unroll
-    for (int k16 = 0; k16 < AR_BK / 16; ++k16) {
-      f16x8 fah[2], fal[2];
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm) {
-        const int off = (wm * 64 + tm * 32 + lr) * AR_LDT + k16 * 16 + kh;
-        fah[tm] = *reinterpret_cast<const f16x8*>(ah + off);
-        fal[tm] = *reinterpret_cast<const f16x8*>(al + off);
-      }
-      const int offb = (wn * 32 + lr) * AR_LDT + k16 * 16 + kh;
-      const f16x8 fbh = *reinterpret_cast<const f16x8*>(bh + offb);
-      const f16x8 fbl = *reinterpret_cast<const f16x8*>(bl + offb);
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[tm], fbh, acc[tm], 0, 0, 0);
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[tm], fbl, acc[tm], 0, 0, 0);
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[tm], fbh, acc[tm], 0, 0, 0);
-    }
+    const int offa0 = (wm * 64 + lr) * AR_LDT + kh, offa1 = offa0 + 32 * AR_LDT;
+    const int offb = (wn * 32 + lr) * AR_LDT + kh;
+    struct Fr {
+      f16x8 v[6];  // ah0, al0, ah1, al1, bh, bl
+    };
+    auto rd1 = [&](Fr& f, auto JC, auto RC) {
+      constexpr int j = decltype(JC)::value, r = decltype(RC)::value;
+      if constexpr (r == 0) f.v[0] = *reinterpret_cast<const f16x8*>(ah + offa0 + j * 16);
+      if constexpr (r == 1) f.v[1] = *reinterpret_cast<const f16x8*>(al + offa0 + j * 16);
+      if constexpr (r == 2) f.v[2] = *reinterpret_cast<const f16x8*>(ah + offa1 + j * 16);
+      if constexpr (r == 3) f.v[3] = *reinterpret_cast<const f16x8*>(al + offa1 + j * 16);
+      if constexpr (r == 4) f.v[4] = *reinterpret_cast<const f16x8*>(bh + offb + j * 16);
+      if constexpr (r == 5) f.v[5] = *reinterpret_cast<const f16x8*>(bl + offb + j * 16);
+    };
+    auto mm1 = [&](const Fr& f, auto IC) {  // term-major: consecutive MFMAs alternate between the two accumulators
+      constexpr int i = decltype(IC)::value;
+      constexpr int tm = i & 1, term = i >> 1;
+      if constexpr (term == 0) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.v[2 * tm + 1], f.v[4], acc[tm], 0, 0, 0);
+      if constexpr (term == 1) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.v[2 * tm], f.v[5], acc[tm], 0, 0, 0);
+      if constexpr (term == 2) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.v[2 * tm], f.v[4], acc[tm], 0, 0, 0);
+    };
+    auto step = [&](const Fr& cur, Fr& nxt, auto JN) {  // MFMAs of the current step, reads of step JN underneath
+      constexpr int jn = decltype(JN)::value;
+#define AR_PAIR(I)                                                   \
+  mm1(cur, std::integral_constant<int, I>{});                        \
+  __builtin_amdgcn_sched_barrier(0);                                 \
+  if constexpr (jn < 4) {                                            \
+    rd1(nxt, JN, std::integral_constant<int, I>{});                  \
+    __builtin_amdgcn_sched_barrier(0);                               \
+  }
+      AR_PAIR(0) AR_PAIR(1) AR_PAIR(2) AR_PAIR(3) AR_PAIR(4) AR_PAIR(5)
+#undef AR_PAIR
+    };
+    Fr f0, f1;
+    rd1(f0, S0{}, std::integral_constant<int, 0>{});
+    rd1(f0, S0{}, std::integral_constant<int, 1>{});
+    rd1(f0, S0{}, std::integral_constant<int, 2>{});
+    rd1(f0, S0{}, std::integral_constant<int, 3>{});
+    rd1(f0, S0{}, std::integral_constant<int, 4>{});
+    rd1(f0, S0{}, std::integral_constant<int, 5>{});
+    __builtin_amdgcn_sched_barrier(0);
+    step(f0, f1, std::integral_constant<int, 1>{});
+    step(f1, f0, std::integral_constant<int, 2>{});
+    step(f0, f1, std::integral_constant<int, 3>{});
+    step(f1, f0, std::integral_constant<int, 4>{});
     if constexpr (ks == KS - 1) {
       // ---- channel tile nt finished: register-only epilogue for this wave's 64 rows x 32 channels ----
       // v = acc*oscale + cb is never formed for full half tiles: the sums are taken on the raw accumulators
