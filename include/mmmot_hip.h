@@ -196,6 +196,26 @@ typedef struct mmmot_gemm_ares_args {
 } mmmot_gemm_ares_args;
 int mmmot_gemm_ares(const mmmot_gemm_ares_args* a, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * GroupNorm statistics of a 1x1-conv output from the second moments of its INPUT (v2):
+ * for v = W a + b with a = relu(X*sc + sh) over the rows of a group, per output channel
+ *   mean = w.m + b,  var = w^T Cov(a) w  (m = E[a], Cov = E[a a^T] - m m^T)
+ * so PointNet conv5 128->1024 + GroupNorm(1024,1024) (reference modules/point_net.py:138) needs ONE pass of
+ * the 128->1024 GEMM (the normalise + ReLU + per-detection-sum pass of mmmot_gemm_ares) instead of two.
+ * mmmot_gram_rows: per super-tile t (tile_row0/nrows/group, any row count, fp32 accumulation restarts every 128
+ *   rows and is merged with compensated summation) Gout[t][K][K] = sum a a^T and Sout[t][K] = sum a, float64.
+ *   K = 64 or 128.
+ * mmmot_gn_finalize_gram: sums the super-tiles of every group (grp_tile0 / grp_ntiles), forms Cov in float64
+ *   and writes sc[g][n] = gamma[n]*rstd, sh[g][n] = beta[n] - mean*sc for the N output channels of
+ *   W [N][K] (fp32, unscaled) / bias [N] (may be NULL).  work: G*(K*K+K) doubles. */
+int mmmot_gram_rows(const float* X, int ldx, int K, const float* sc, const float* sh, int ldsc,
+                    const int* tile_row0, const int* tile_nrows, const int* tile_group, int T,
+                    double* Gout, double* Sout, void* stream);
+int mmmot_gn_finalize_gram(const double* Gp, const double* Sp, const int* grp_tile0, const int* grp_ntiles,
+                           const int* grp_count, int G, int K, const float* W, const float* bias, int N,
+                           const float* gamma, const float* beta, float eps, double* work, float* sc,
+                           float* sh, void* stream);
+
 /* GroupNorm statistics -> per-channel scale/shift (fp64 combine).
  * part is [T][2][ldp] = per-tile (sum, tile-centred M2) as written by
  * mmmot_gemm_rows / mmmot_pointnet_layer1 (the C channels start at part[0];

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libmmmot_hip.so')
 SOURCES = ['conv3x3.hip', 'conv3x3_hl16.hip', 'conv3x3_hl16_dma.hip', 'conv3x3_hl16_patch.hip', 'gemm_rows.hip',
-           'gemm_ares.hip', 'points_gather.hip', 'crop_resize.hip', 'small_kernels.hip']
+           'gemm_ares.hip', 'gram.hip', 'points_gather.hip', 'crop_resize.hip', 'small_kernels.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 HIPFLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
 
@@ -70,6 +70,8 @@ SIGNATURES = {
     'mmmot_conv3x3_bn_relu': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f],
     'mmmot_gemm_rows': [ctypes.POINTER(GemmArgs), c_f],
     'mmmot_gemm_ares': [ctypes.POINTER(GemmAresArgs), c_f],
+    'mmmot_gram_rows': [c_f, c_i, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_f, c_f, c_f],
+    'mmmot_gn_finalize_gram': [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_i, c_f, c_f, ctypes.c_float, c_f, c_f, c_f, c_f],
     'mmmot_gn_finalize': [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, ctypes.c_float, c_f, c_f, c_f],
     'mmmot_segment_mean': [c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_f, c_i, c_i, c_f, c_i, c_i, c_f],
     'mmmot_conv3x3_bn_relu_hl16': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, c_f],

@@ -47,12 +47,26 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
   const int lr = lane & 31;
   const int kh = (lane >> 5) * 8;
 
-  const int t = mm_xcd_remap(blockIdx.x, gridDim.x);
-  const int row0 = a.tile_row0[t];
-  const int nrows = a.tile_nrows[t];
-  const int grp = a.tile_group ? a.tile_group[t] : 0;
   const int ntn = a.N / AR_BN;
-  const int NS = ntn * KS;  // weight stages
+  const int NS = ntn * KS;  // weight stages per row tile
+  // Persistent workgroups (LDS allows one per CU): tiles blockIdx.x, + gridDim.x, ...  The weight stream
+  // wraps around (stage NS continues with stage 0 of the next tile), the next tile's activation rows are
+  // fetched into registers during the current tile's last stages, so a tile switch costs one conversion
+  // pass + one barrier instead of a cold prologue (measured fixed cost before: 8 us of a 31 us tile).
+  struct TileMeta {
+    int row0, nrows, grp, dbrow;
+  };
+  auto meta_of = [&](int tt) {
+    TileMeta m;
+    m.row0 = a.tile_row0[tt];
+    m.nrows = a.tile_nrows[tt];
+    m.grp = a.tile_group ? a.tile_group[tt] : 0;
+    m.dbrow = a.dbias ? a.tile_dbrow[tt] : 0;
+    return m;
+  };
+  int t = blockIdx.x;
+  if (t >= a.T) return;
+  TileMeta cur = meta_of(t);
 
   // ---- weight stage loader: thread -> (channel row = tid >> 2, units 2q, 2q+1 of the 8 in a 64-k stage) ----
   const int wrow = tid >> 2, wq = tid & 3;
@@ -80,17 +94,25 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
 
-  // ---- activation rows: normalise + ReLU + hi/lo split, once --------------------------------------------
-  {
-    // thread -> (row = tid >> 2, quarter q of the K axis: 16 * KS consecutive channels)
-    const int r = tid >> 2, q = tid & 3;
-    const bool rv = r < nrows;
-    const float* px = a.X + (long)(row0 + (rv ? r : 0)) * a.ldx + q * (16 * KS);
-    const float* psc = a.sc + (long)grp * a.ldsc + q * (16 * KS);
-    const float* psh = a.sh + (long)grp * a.ldsc + q * (16 * KS);
+  // ---- activation rows: raw rows -> registers (load_x), normalise + ReLU + hi/lo split -> LDS (stage_a) ------
+  // thread -> (row = tid >> 2, quarter q of the K axis: 16 * KS consecutive channels)
+  const int ar = tid >> 2, aq = tid & 3;
+  f32x4 xr[2 * KS][2];
+  auto load_x = [&](const TileMeta& m) {
+    const float* px = a.X + (long)(m.row0 + (ar < m.nrows ? ar : 0)) * a.ldx + aq * (16 * KS);
+#pragma unroll
+    for (int u = 0; u < 2 * KS; ++u) {
+      xr[u][0] = *reinterpret_cast<const f32x4*>(px + 8 * u);
+      xr[u][1] = *reinterpret_cast<const f32x4*>(px + 8 * u + 4);
+    }
+  };
+  auto stage_a = [&](const TileMeta& m) {
+    const bool rv = ar < m.nrows;
+    const float* psc = a.sc + (long)m.grp * a.ldsc + aq * (16 * KS);
+    const float* psh = a.sh + (long)m.grp * a.ldsc + aq * (16 * KS);
 #pragma unroll
     for (int u = 0; u < 2 * KS; ++u) {  // 8-channel units of this thread
-      const f32x4 x0 = *reinterpret_cast<const f32x4*>(px + 8 * u), x1 = *reinterpret_cast<const f32x4*>(px + 8 * u + 4);
+      const f32x4 x0 = xr[u][0], x1 = xr[u][1];
       const f32x4 s0 = *reinterpret_cast<const f32x4*>(psc + 8 * u), s1 = *reinterpret_cast<const f32x4*>(psc + 8 * u + 4);
       const f32x4 h0 = *reinterpret_cast<const f32x4*>(psh + 8 * u), h1 = *reinterpret_cast<const f32x4*>(psh + 8 * u + 4);
       f16x8 hi, lo;
@@ -104,19 +126,25 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
         hi[4 + e] = (_Float16)y1;
         lo[4 + e] = (_Float16)(y1 - (float)hi[4 + e]);
       }
-      const int k = q * (16 * KS) + 8 * u;  // channel of the unit
+      const int k = aq * (16 * KS) + 8 * u;  // channel of the unit
       const int ks = k / AR_BK, kk = k - ks * AR_BK;
-      *reinterpret_cast<f16x8*>(&As[ks][0][r * AR_LDT + kk]) = hi;
-      *reinterpret_cast<f16x8*>(&As[ks][1][r * AR_LDT + kk]) = lo;
+      *reinterpret_cast<f16x8*>(&As[ks][0][ar * AR_LDT + kk]) = hi;
+      *reinterpret_cast<f16x8*>(&As[ks][1][ar * AR_LDT + kk]) = lo;
     }
-  }
+  };
+  load_x(cur);
+  stage_a(cur);
   // weight stages: s -> register slot s & 1; two stages of global loads are always in flight (one LDS
   // stage of latency is not enough: the L2 round trip under load is longer than a 24-MFMA stage)
-  load_w(0, S0{});
-  load_w(min(1, NS - 1), S1{});
-  store_w(0, S0{});
-  load_w(min(2, NS - 1), S0{});
-  __syncthreads();
+  auto prime_w = [&]() {
+    load_w(0, S0{});
+    load_w(1 % NS, S1{});
+    store_w(0, S0{});
+    load_w(2 % NS, S0{});
+    __syncthreads();
+  };
+  prime_w();
+  const bool wrap_ok = (NS % 2) == 0;  // the LDS buffer parity of stage 0 repeats only for even NS
 
   f32x16 acc[2];
 #pragma unroll
@@ -124,36 +152,52 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[tm][e] = 0.f;
 
-  const int nsub = min(max(nrows - 64 * wm, 0), 64);  // valid rows of this wave's half tile
-  const float inv_nsub = nsub > 0 ? 1.f / (float)nsub : 0.f;
-  const long prow = (long)(2 * t + wm);
-
-  // per-channel epilogue constants of a channel tile: combined bias, output scale / shift.  They are
-  // loaded one channel tile ahead and BEFORE the weight loads of that stage: vmcnt retires in order, so a
-  // load issued at epilogue time would also wait for the two weight stages in flight.
+  // per-tile epilogue state (set by begin_tile)
+  int nrows = 0, nsub = 0, grp = 0;
+  float inv_nsub = 0.f;
+  long prow = 0;
+  bool full = false;
   const float* pbias = a.bias ? a.bias : ar_zeros;
-  const float* pdb = a.dbias ? a.dbias + (long)a.tile_dbrow[t] * a.lddb : ar_zeros;
-  const float* posc = (MODE & 2) ? a.osc + (long)grp * a.ldosc : ar_zeros;
-  const float* posh = (MODE & 2) ? a.osh + (long)grp * a.ldosc : ar_zeros;
-  auto epi_consts = [&](int nt, float& cb, float& os, float& oh) {
+  // per-channel epilogue constants of a channel tile: combined bias, output scale / shift.  They are
+  // loaded one channel tile ahead (for the last channel tile: those of the NEXT row tile) and BEFORE the
+  // weight loads of that stage: vmcnt retires in order, so a load issued at epilogue time would also wait
+  // for the two weight stages in flight.
+  auto epi_consts = [&](const TileMeta& m, int nt, float& cb, float& os, float& oh) {
     const int n = nt * AR_BN + wn * 32 + lr;
+    const float* pdb = a.dbias ? a.dbias + (long)m.dbrow * a.lddb : ar_zeros;
+    const float* posc = (MODE & 2) ? a.osc + (long)m.grp * a.ldosc : ar_zeros;
+    const float* posh = (MODE & 2) ? a.osh + (long)m.grp * a.ldosc : ar_zeros;
     cb = pbias[n] + pdb[n];
     os = posc[n];
     oh = posh[n];
   };
   float cbc, osc_c, osh_c, cbn = 0.f, osc_n = 0.f, osh_n = 0.f;
-  epi_consts(0, cbc, osc_c, osh_c);
-  const bool full = (nsub == 64);
+  epi_consts(cur, 0, cbc, osc_c, osh_c);
+  TileMeta nxt = cur;
+  auto begin_tile = [&](const TileMeta& m, int tt) {
+    nrows = m.nrows;
+    grp = m.grp;
+    nsub = min(max(nrows - 64 * wm, 0), 64);  // valid rows of this wave's half tile
+    inv_nsub = nsub > 0 ? 1.f / (float)nsub : 0.f;
+    prow = (long)(2 * tt + wm);
+    full = (nsub == 64);
+  };
+  begin_tile(cur, t);
 
   auto stage = [&](int s, auto ODD) {
     constexpr int odd = decltype(ODD)::value;  // s & 1
     constexpr int ks = (KS == 2) ? odd : 0;  // NS is a multiple of KS and stages alternate
     const int nt = s / KS;
-    if constexpr (ks == 0) epi_consts(min(nt + 1, ntn - 1), cbn, osc_n, osh_n);
+    if constexpr (ks == 0) {
+      const bool last_nt = nt + 1 >= ntn;  // then: first channel tile of the next row tile (same loads, other rows)
+      TileMeta m = cur;
+      if (last_nt) m = nxt;
+      epi_consts(m, last_nt ? 0 : nt + 1, cbn, osc_n, osh_n);
+    }
     // stage s+1 (register slot !odd) -> the other LDS buffer (last read in stage s-1, every wave is past
-    // that barrier); then its slot takes the loads of stage s+3 (clamped: the tail re-loads the last stage)
+    // that barrier); then its slot takes the loads of stage s+3
     store_w(1 - odd, std::integral_constant<int, 1 - odd>{});
-    load_w(min(s + 3, NS - 1), std::integral_constant<int, 1 - odd>{});
+    load_w((s + 3) % NS, std::integral_constant<int, 1 - odd>{});  // wraps into the next row tile
     // Four 16-channel steps; the fragments of step j+1 are read while the six MFMAs of step j issue, one
     // read per MFMA (sched_barrier pins the order): the two waves of a SIMD run in lockstep after every
     // barrier, so an LDS round trip that is not covered by this wave's own MFMAs is idle matrix-pipe time.
@@ -281,18 +325,25 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
     }
     __syncthreads();
   };
-  if constexpr (KS == 2) {
+  for (;;) {
+    const int tn = t + gridDim.x;
+    const bool more = tn < a.T;
+    if (more) nxt = meta_of(tn);
+    // the next tile's rows are requested two stages before the end of this tile
+    const int s_fetch = NS >= 3 ? NS - 3 : 0;
     for (int s = 0; s < NS; s += 2) {
+      if (more && (s == (s_fetch & ~1))) load_x(nxt);
       stage(s, S0{});
-      stage(s + 1, S1{});
+      if (s + 1 < NS) stage(s + 1, S1{});
     }
-  } else {
-    int s = 0;
-    for (; s + 1 < NS; s += 2) {
-      stage(s, S0{});
-      stage(s + 1, S1{});
-    }
-    if (s < NS) stage(s, S0{});
+    if (!more) break;
+    // tile switch: every wave is past the barrier that ended the last stage, As is free
+    stage_a(nxt);
+    if (wrap_ok) __syncthreads();
+    else prime_w();  // odd stage count: the buffer parity restarts, re-prime the weight pipeline
+    cur = nxt;
+    t = tn;
+    begin_tile(cur, t);
   }
 }
 
@@ -307,8 +358,16 @@ extern "C" int mmmot_gemm_ares(const mmmot_gemm_ares_args* a, void* stream) {
   if (!a->part && !a->colsum) return MMMOT_EINVAL;  // nothing to produce
   if (a->N > 4096) return MMMOT_EINVAL;
   const int mode = (a->part ? 1 : 0) | (a->colsum ? 2 : 0);
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MMMOT_EINVAL;
+    n_cu = prop.multiProcessorCount;
+  }
+  const int grid = a->T < n_cu ? a->T : n_cu;  // persistent: one workgroup per CU
 #define AR_LAUNCH(KSV, MODEV) \
-  hipLaunchKernelGGL((gemm_ares_kernel<KSV, MODEV>), dim3(a->T), dim3(AR_THREADS), 0, s, *a)
+  hipLaunchKernelGGL((gemm_ares_kernel<KSV, MODEV>), dim3(grid), dim3(AR_THREADS), 0, s, *a)
   if (a->K == 128) {
     if (mode == 1) AR_LAUNCH(2, 1); else if (mode == 2) AR_LAUNCH(2, 2); else AR_LAUNCH(2, 3);
   } else {

@@ -1,0 +1,254 @@
+// GroupNorm statistics of a 1x1-conv output WITHOUT running the conv: second moments of its input.
+// (see include/mmmot_hip.h: mmmot_gram_rows / mmmot_gn_finalize_gram)
+//
+// For v = W a + b over the rows of a normalisation group (per-channel GroupNorm(C, C), e.g. PointNet conv5
+// 128 -> 1024 over all points of a sample, reference modules/point_net.py:138):
+//     mean_c = w_c . m + b_c,   var_c = w_c^T Cov(a) w_c,   m = E[a],  Cov(a) = E[a a^T] - m m^T
+// so one pass over the K-channel INPUT (K = 64 / 128) replaces a full pass of the K -> N GEMM (N = 1024:
+// 1.0 ms of a 17 ms step at cfg3).  Checked on the cfg3 weights against float64 statistics of v: relative
+// variance error <= 8e-7 (the direct per-tile fp32 scheme: 1e-7), i.e. 4e-7 on the scale - noise next to the
+// 1e-3 budget.  What makes it safe:
+//   * a = relu(x*sc + sh) is non-negative with mean ~ std, so E[a a^T] - m m^T cancels at most a factor ~2;
+//   * Gram tiles are accumulated over 128 rows in fp32 on the matrix cores (3-term hi/lo split of the fp16
+//     operands: products exact to 2^-22), then merged into a COMPENSATED (two-float) running sum per element
+//     and written as float64; tiles/groups are merged and the quadratic forms evaluated in float64.
+#include "common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+#define GR_ROWS 128      // rows per sub-tile (fp32 accumulation length)
+#define GR_LD 136        // halves per transposed LDS row: [channel][row], 272 B
+#define GR_THREADS 256
+
+// Fast two-sum accumulate: (s, c) += x with the rounding error of s + x collected in c.
+__device__ __forceinline__ void gr_acc(float& s, float& c, float x) {
+  const float t = s + x;
+  const float bp = t - s;
+  c += (s - (t - bp)) + (x - bp);
+  s = t;
+}
+
+// grid = super-tiles (<= 8 sub-tiles of 128 rows inside one group).  K = 64 or 128 channels.
+template <int K>
+__global__ __launch_bounds__(GR_THREADS) void gram_rows_kernel(const float* __restrict__ X, int ldx,
+                                                                const float* __restrict__ sc,
+                                                                const float* __restrict__ sh, int ldsc,
+                                                                const int* __restrict__ tile_row0,
+                                                                const int* __restrict__ tile_nrows,
+                                                                const int* __restrict__ tile_group,
+                                                                double* __restrict__ Gout, double* __restrict__ Sout) {
+  constexpr int CT = K / 32;            // 32-channel MFMA tiles per side: 4 / 2
+  constexpr int WT = (K == 128) ? 2 : 1;  // tiles per wave per side (4 waves: 2x2 waves over the K x K output)
+  __shared__ __attribute__((aligned(16))) _Float16 Th[K * GR_LD];  // hi plane, transposed [channel][row]
+  __shared__ __attribute__((aligned(16))) _Float16 Tl[K * GR_LD];  // lo plane
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1;  // this wave's block of the Gram matrix
+  const int lr = lane & 31, kh = (lane >> 5) * 8;
+  const int t = blockIdx.x;
+  const int row0 = tile_row0[t], nrows = tile_nrows[t];
+  const int grp = tile_group ? tile_group[t] : 0;
+
+  // staging: thread -> (row = tid >> 1, half h of the channels) for K = 128 / (row = tid >> 1 ...): 2 threads per row
+  const int sr = tid >> 1, sq = tid & 1;
+  constexpr int CPT = K / 2;  // channels per staging thread: 64 / 32
+  float gs[WT][WT][16], gc[WT][WT][16];
+#pragma unroll
+  for (int a = 0; a < WT; ++a)
+#pragma unroll
+    for (int b = 0; b < WT; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) gs[a][b][e] = gc[a][b][e] = 0.f;
+  float ss = 0.f, scc = 0.f;  // compensated column sum of channel `tid` (threads < K)
+
+  for (int r0 = 0; r0 < nrows; r0 += GR_ROWS) {
+    const int nr = min(GR_ROWS, nrows - r0);
+    // ---- stage: normalise + ReLU + hi/lo split, transposed into LDS ([channel][row]) ----
+    {
+      const bool rv = sr < nr;
+      const float* px = X + (long)(row0 + r0 + (rv ? sr : 0)) * ldx + sq * CPT;
+      const float* ps = sc + (long)grp * ldsc + sq * CPT;
+      const float* ph = sh + (long)grp * ldsc + sq * CPT;
+#pragma unroll 4
+      for (int c4 = 0; c4 < CPT; c4 += 4) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(px + c4);
+        const f32x4 s4 = *reinterpret_cast<const f32x4*>(ps + c4);
+        const f32x4 h4 = *reinterpret_cast<const f32x4*>(ph + c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float y = fminf(fmaxf(fmaf(x[e], s4[e], h4[e]), 0.f), 65000.f);
+          if (!rv) y = 0.f;
+          const _Float16 hi = (_Float16)y;
+          const int c = sq * CPT + c4 + e;
+          Th[c * GR_LD + sr] = hi;
+          Tl[c * GR_LD + sr] = (_Float16)(y - (float)hi);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- column sums (deterministic order): thread c adds its channel's 128 rows, hi and lo ----
+    if (tid < K) {
+      float acc = 0.f;
+#pragma unroll 4
+      for (int r8 = 0; r8 < GR_ROWS; r8 += 8) {
+        const f16x8 h = *reinterpret_cast<const f16x8*>(&Th[tid * GR_LD + r8]);
+        const f16x8 l = *reinterpret_cast<const f16x8*>(&Tl[tid * GR_LD + r8]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc += (float)h[e] + (float)l[e];
+      }
+      gr_acc(ss, scc, acc);
+    }
+    // ---- Gram of the sub-tile on the matrix cores: G[i][j] = sum_r a[r][i] a[r][j] ----
+    f32x16 acc[WT][WT];
+#pragma unroll
+    for (int a = 0; a < WT; ++a)
+#pragma unroll
+      for (int b = 0; b < WT; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+#pragma unroll
+    for (int k16 = 0; k16 < GR_ROWS / 16; ++k16) {
+      f16x8 ah[WT], al[WT], bh[WT], bl[WT];
+#pragma unroll
+      for (int a = 0; a < WT; ++a) {
+        const int off = ((wi * WT + a) * 32 + lr) * GR_LD + k16 * 16 + kh;
+        ah[a] = *reinterpret_cast<const f16x8*>(&Th[off]);
+        al[a] = *reinterpret_cast<const f16x8*>(&Tl[off]);
+      }
+#pragma unroll
+      for (int b = 0; b < WT; ++b) {
+        const int off = ((wj * WT + b) * 32 + lr) * GR_LD + k16 * 16 + kh;
+        bh[b] = *reinterpret_cast<const f16x8*>(&Th[off]);
+        bl[b] = *reinterpret_cast<const f16x8*>(&Tl[off]);
+      }
+#pragma unroll
+      for (int a = 0; a < WT; ++a)
+#pragma unroll
+        for (int b = 0; b < WT; ++b) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < WT; ++a)
+#pragma unroll
+      for (int b = 0; b < WT; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) gr_acc(gs[a][b][e], gc[a][b][e], acc[a][b][e]);
+    __syncthreads();  // the planes are rewritten by the next sub-tile
+  }
+  // ---- write the super-tile's partial as float64 ----
+  double* G = Gout + (long)t * K * K;
+#pragma unroll
+  for (int a = 0; a < WT; ++a)
+#pragma unroll
+    for (int b = 0; b < WT; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = (wi * WT + a) * 32 + mm_acc_row(e, lane);
+        const int j = (wj * WT + b) * 32 + lr;
+        G[(long)i * K + j] = (double)gs[a][b][e] + (double)gc[a][b][e];
+      }
+  if (tid < K) Sout[(long)t * K + tid] = (double)ss + (double)scc;
+  (void)CT;
+}
+
+// sum of the super-tile partials of every group: red[g][K*K + K] doubles (Gram, then column sums)
+__global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restrict__ Gp, const double* __restrict__ Sp,
+                                                          const int* __restrict__ grp_tile0,
+                                                          const int* __restrict__ grp_ntiles, int K,
+                                                          double* __restrict__ red) {
+  const int g = blockIdx.y;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int KK = K * K;
+  if (idx >= KK + K) return;
+  const int t0 = grp_tile0[g], nt = grp_ntiles[g];
+  double s = 0.0;
+  if (idx < KK)
+    for (int t = 0; t < nt; ++t) s += Gp[(long)(t0 + t) * KK + idx];
+  else
+    for (int t = 0; t < nt; ++t) s += Sp[(long)(t0 + t) * K + (idx - KK)];
+  red[(long)g * (KK + K) + idx] = s;
+}
+
+// scale / shift of GroupNorm(N, N) applied to v = W a + b: one workgroup per (group, 64 output channels);
+// Cov(a) lives in LDS as float64 (K = 128: 128 KB).
+template <int K>
+__global__ __launch_bounds__(256) void gn_finalize_gram_kernel(const double* __restrict__ red,
+                                                               const int* __restrict__ grp_count,
+                                                               const float* __restrict__ Wm,
+                                                               const float* __restrict__ bias, int N,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps,
+                                                               float* __restrict__ sc, float* __restrict__ sh) {
+  __shared__ double C[K * K];
+  __shared__ double m[K];
+  const int g = blockIdx.x, n0 = blockIdx.y * 64;
+  const double cnt = (double)grp_count[g];
+  const double* R = red + (long)g * (K * K + K);
+  for (int k = threadIdx.x; k < K; k += 256) m[k] = R[K * K + k] / cnt;
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < K * K; idx += 256) C[idx] = R[idx] / cnt - m[idx / K] * m[idx % K];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int cc = wave; cc < 64; cc += 4) {
+    const int n = n0 + cc;
+    if (n >= N) break;
+    const float* w = Wm + (long)n * K;
+    // y = C w restricted to this lane's rows; var = w . y, mean = w . m + b
+    double var = 0.0, mean = 0.0;
+    for (int i = lane; i < K; i += 64) {
+      double y = 0.0;
+      for (int j = 0; j < K; ++j) y += C[j * K + i] * (double)w[j];  // C is symmetric: lanes read consecutive doubles
+      var += (double)w[i] * y;
+      mean += (double)w[i] * m[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      var += __shfl_xor(var, o);
+      mean += __shfl_xor(mean, o);
+    }
+    if (lane == 0) {
+      mean += bias ? (double)bias[n] : 0.0;
+      var = var > 0.0 ? var : 0.0;
+      const double scv = (double)gamma[n] / sqrt(var + (double)eps);
+      sc[(long)g * N + n] = (float)scv;
+      sh[(long)g * N + n] = (float)((double)beta[n] - mean * scv);
+    }
+  }
+}
+
+extern "C" int mmmot_gram_rows(const float* X, int ldx, int K, const float* sc, const float* sh, int ldsc,
+                               const int* tile_row0, const int* tile_nrows, const int* tile_group, int T,
+                               double* Gout, double* Sout, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!X || !sc || !sh || !tile_row0 || !tile_nrows || !Gout || !Sout || T <= 0) return MMMOT_EINVAL;
+  if ((K != 64 && K != 128) || ldx % 4 != 0 || ldsc % 4 != 0 || !mm_al16(X) || !mm_al16(sc) || !mm_al16(sh))
+    return MMMOT_EINVAL;
+  if (K == 128)
+    hipLaunchKernelGGL(gram_rows_kernel<128>, dim3(T), dim3(GR_THREADS), 0, s, X, ldx, sc, sh, ldsc, tile_row0, tile_nrows,
+                       tile_group, Gout, Sout);
+  else
+    hipLaunchKernelGGL(gram_rows_kernel<64>, dim3(T), dim3(GR_THREADS), 0, s, X, ldx, sc, sh, ldsc, tile_row0, tile_nrows,
+                       tile_group, Gout, Sout);
+  return mm_check(hipGetLastError());
+}
+
+extern "C" int mmmot_gn_finalize_gram(const double* Gp, const double* Sp, const int* grp_tile0, const int* grp_ntiles,
+                                      const int* grp_count, int G, int K, const float* W, const float* bias, int N,
+                                      const float* gamma, const float* beta, float eps, double* work, float* sc,
+                                      float* sh, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!Gp || !Sp || !grp_tile0 || !grp_ntiles || !grp_count || !W || !gamma || !beta || !work || !sc || !sh)
+    return MMMOT_EINVAL;
+  if ((K != 64 && K != 128) || G <= 0 || N <= 0) return MMMOT_EINVAL;
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3((K * K + K + 255) / 256, G), dim3(256), 0, s, Gp, Sp, grp_tile0,
+                     grp_ntiles, K, work);
+  if (K == 128)
+    hipLaunchKernelGGL(gn_finalize_gram_kernel<128>, dim3(G, (N + 63) / 64), dim3(256), 0, s, work, grp_count, W, bias,
+                       N, gamma, beta, eps, sc, sh);
+  else
+    hipLaunchKernelGGL(gn_finalize_gram_kernel<64>, dim3(G, (N + 63) / 64), dim3(256), 0, s, work, grp_count, W, bias,
+                       N, gamma, beta, eps, sc, sh);
+  return mm_check(hipGetLastError());
+}

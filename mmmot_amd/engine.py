@@ -35,6 +35,8 @@ class Engine:
         # PointNet conv5 / conv1: statistics pass + fused normalise-ReLU-segment-sum pass instead of
         # materialising the [P][1024] / [P][512] tensors (MMMOT_PN_FUSED=0 keeps the materialising path)
         self.pn_fused = os.environ.get('MMMOT_PN_FUSED', '1') != '0'
+        # conv5 statistics from the Gram matrix of its input instead of a statistics pass of the GEMM
+        self.pn_gram = os.environ.get('MMMOT_PN_GRAM', '1') != '0'
         self.mlp = trunk  # the 1x1-conv / linear GEMMs follow the same arithmetic choice
         if affinity_op not in PAIR_OPS:
             raise ValueError('unknown affinity_op %r' % (affinity_op,))
@@ -62,6 +64,16 @@ class Engine:
         t = self.ws.get(name)
         if t is None or t.numel() < n or (device is not None and t.device != torch.device(device)):
             t = torch.empty(max(n, 4), dtype=torch.float32, device=device if device is not None else self.dev)
+            self.ws[name] = t
+        return t[:n].view(*shape)
+
+    def buf64(self, name, *shape):
+        n = 1
+        for s in shape:
+            n *= int(s)
+        t = self.ws.get(name)
+        if t is None or t.numel() < n or t.dtype != torch.float64:
+            t = torch.empty(max(n, 4), dtype=torch.float64, device=self.dev)
             self.ws[name] = t
         return t[:n].view(*shape)
 
@@ -156,9 +168,18 @@ class Engine:
         ares = fused and self.mlp == 'f16x3' and 'w5_h16' in pn  # A-resident kernel (hl16 weights only)
         TH = plan.ptd_half if ares else None
         if ares:
-            part = self._part(TH, 1024)
-            ops.gemm_ares(pn['w5_h16'], pn['w5_os'], TD, 1024, 128, x, sc, sh, bias=pn['b5'], part=part)
-            sc5, sh5 = self._finalize('pn5', part, TH, 1024, 1024, pn['g5'], pn['be5'])
+            if self.pn_gram:
+                # statistics of conv5's output from the second moments of its 128-channel input: no GEMM pass
+                GT = plan.gram_tiles
+                Gp, Sp = self.buf64('gram_G', GT.T, 128 * 128), self.buf64('gram_S', GT.T, 128)
+                ops.gram_rows(x, 128, sc, sh, GT, Gp, Sp)
+                sc5, sh5 = self.buf('pn5_sc', GT.G, 1024), self.buf('pn5_sh', GT.G, 1024)
+                ops.gn_finalize_gram(Gp, Sp, GT, 128, pn['w5'], pn['b5'], 1024, pn['g5'], pn['be5'], EPS,
+                                     self.buf64('gram_work', GT.G, 128 * 128 + 128), sc5, sh5)
+            else:
+                part = self._part(TH, 1024)
+                ops.gemm_ares(pn['w5_h16'], pn['w5_os'], TD, 1024, 128, x, sc, sh, bias=pn['b5'], part=part)
+                sc5, sh5 = self._finalize('pn5', part, TH, 1024, 1024, pn['g5'], pn['be5'])
             cs = self.buf('pn_colsum', TH.T, 1024)
             ops.gemm_ares(pn['w5_h16'], pn['w5_os'], TD, 1024, 128, x, sc, sh, bias=pn['b5'], osc=sc5, osh=sh5,
                           colsum=cs)

@@ -131,6 +131,21 @@ class HipOps:
         a.T, a.N, a.K, a.oscale = tiles.T, N, K, float(oscale)
         _lib.check(self.lib.mmmot_gemm_ares(ctypes.byref(a), self._stream()), 'mmmot_gemm_ares')
 
+    def gram_rows(self, X, K, sc, sh, tiles, Gout, Sout):
+        """Per super-tile Gram matrix / column sums (float64) of relu(X*sc+sh); see mmmot_gram_rows."""
+        st = self.lib.mmmot_gram_rows(_ptr(X), _ld(X), K, _ptr(sc), _ptr(sh), _ld(sc), _iptr(tiles.row0),
+                                      _iptr(tiles.nrows), _iptr(tiles.group), tiles.T,
+                                      _ptr(Gout, torch.float64), _ptr(Sout, torch.float64), self._stream())
+        _lib.check(st, 'mmmot_gram_rows')
+
+    def gn_finalize_gram(self, Gp, Sp, tiles, K, W, bias, N, gamma, beta, eps, work, sc, sh):
+        """GroupNorm(N, N) scale/shift of v = W a + b from the Gram partials of a; see mmmot_gn_finalize_gram."""
+        st = self.lib.mmmot_gn_finalize_gram(_ptr(Gp, torch.float64), _ptr(Sp, torch.float64), _iptr(tiles.g_tile0),
+                                             _iptr(tiles.g_ntiles), _iptr(tiles.g_count), tiles.G, K, _ptr(W),
+                                             _ptr(bias), N, _ptr(gamma), _ptr(beta), float(eps),
+                                             _ptr(work, torch.float64), _ptr(sc), _ptr(sh), self._stream())
+        _lib.check(st, 'mmmot_gn_finalize_gram')
+
     def gn_finalize(self, part, tiles, C, NG, gamma, beta, eps, sc, sh):
         """part: [T][2][>=C] view (unit inner stride); statistics of its first C channels."""
         if part.dim() != 3 or part.stride(2) != 1 or part.stride(0) != 2 * part.stride(1):

@@ -142,6 +142,26 @@ class TorchOps:
                 if colsum is not None:
                     colsum[2 * t + h, :N] = torch.relu(vh * osc[g, :N] + osh[g, :N]).sum(0).to(colsum.dtype)
 
+    def gram_rows(self, X, K, sc, sh, tiles, Gout, Sout):
+        grp = _rows_groups(tiles)
+        A = torch.relu(X[:tiles.R, :K] * sc[grp, :K] + sh[grp, :K]).double()
+        for t in range(tiles.T):
+            r0, n = int(tiles.h_row0[t]), int(tiles.h_nrows[t])
+            Gout[t] = (A[r0:r0 + n].t() @ A[r0:r0 + n]).reshape(-1)
+            Sout[t] = A[r0:r0 + n].sum(0)
+
+    def gn_finalize_gram(self, Gp, Sp, tiles, K, W, bias, N, gamma, beta, eps, work, sc, sh):
+        for g in range(tiles.G):
+            t0, nt, cnt = int(tiles.h_g_tile0[g]), int(tiles.h_g_ntiles[g]), float(tiles.h_g_count[g])
+            m = Sp[t0:t0 + nt].double().sum(0) / cnt
+            C = Gp[t0:t0 + nt].double().sum(0).view(K, K) / cnt - torch.outer(m, m)
+            Wd = W[:N, :K].double()
+            mean = Wd @ m + (bias[:N].double() if bias is not None else 0.0)
+            var = torch.einsum('nk,kl,nl->n', Wd, C, Wd).clamp(min=0.0)
+            scv = gamma[:N].double() / torch.sqrt(var + eps)
+            sc[g, :N] = scv.float()
+            sh[g, :N] = (beta[:N].double() - mean * scv).float()
+
     def gn_finalize(self, part, tiles, C, NG, gamma, beta, eps, sc, sh):
         CG = C // NG
         for g in range(tiles.G):

@@ -516,3 +516,38 @@ def test_gemm_ares_statistics_and_colsum(hip, K, N):
     hip.gn_finalize(pg, hg, N, N, gamma.cuda(), beta.cuda(), 1e-5, s_g, h_g)
     close(s_g, s_r, 2e-5, 'scale from half-tile statistics')
     close(h_g, h_r, 2e-5, 'shift from half-tile statistics')
+
+
+@pytest.mark.parametrize('K,N', [(128, 1024), (64, 192)])
+def test_gram_statistics_match_direct_statistics(hip, K, N):
+    """GroupNorm(N, N) scale/shift of v = W relu(X*sc+sh) + b from the Gram matrix of the input (gram_rows +
+    gn_finalize_gram) vs float64 statistics of v itself; ragged super-tiles, two groups, |mean| >> std inputs."""
+    emu = TorchOps(torch.float64)
+    counts = [3000, 1025]
+    cpu, gpu = RowTiles(counts, 'cpu', tile=1024), RowTiles(counts, 'cuda', tile=1024)
+    assert cpu.T == 5 and int(cpu.h_nrows.min()) == 1
+    R = sum(counts)
+    X = rnd(R, K, seed=90) * 2.0 + 0.7
+    sc, sh = rnd(2, K, seed=91).abs() + 0.5, rnd(2, K, seed=92) * 0.5
+    W = rnd(N, K, seed=93, scale=K ** -0.5)
+    bias, gamma, beta = rnd(N, seed=94), rnd(N, seed=95).abs() + 0.5, rnd(N, seed=96)
+    grp = torch.repeat_interleave(torch.arange(2), torch.tensor(counts))
+    A = torch.relu(X.double() * sc.double()[grp] + sh.double()[grp])
+    v = A @ W.double().t() + bias.double()
+    sc_ref, sh_ref = torch.zeros(2, N, dtype=torch.float64), torch.zeros(2, N, dtype=torch.float64)
+    for g in range(2):
+        vg = v[grp == g]
+        s = gamma.double() / torch.sqrt(vg.var(0, unbiased=False) + 1e-5)
+        sc_ref[g], sh_ref[g] = s, beta.double() - vg.mean(0) * s
+    Gp = torch.zeros(gpu.T, K * K, dtype=torch.float64).cuda()
+    Sp = torch.zeros(gpu.T, K, dtype=torch.float64).cuda()
+    hip.gram_rows(X.cuda(), K, sc.cuda(), sh.cuda(), gpu, Gp, Sp)
+    Ge, Se = torch.zeros(cpu.T, K * K, dtype=torch.float64), torch.zeros(cpu.T, K, dtype=torch.float64)
+    emu.gram_rows(X, K, sc, sh, cpu, Ge, Se)
+    close(Sp.float(), Se.float(), 2e-6, 'column sums')
+    close(Gp.float(), Ge.float(), 2e-6, 'Gram partials')
+    scg, shg = torch.zeros(2, N).cuda(), torch.zeros(2, N).cuda()
+    work = torch.zeros(2, K * K + K, dtype=torch.float64).cuda()
+    hip.gn_finalize_gram(Gp, Sp, gpu, K, W.cuda(), bias.cuda(), N, gamma.cuda(), beta.cuda(), 1e-5, work, scg, shg)
+    close(scg, sc_ref.float(), 5e-6, 'scale from the Gram route')
+    close(shg, sh_ref.float(), 5e-6, 'shift from the Gram route')
