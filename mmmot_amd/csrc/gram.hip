@@ -48,9 +48,11 @@ __global__ __launch_bounds__(GR_THREADS) void gram_rows_kernel(const float* __re
   const int row0 = tile_row0[t], nrows = tile_nrows[t];
   const int grp = tile_group ? tile_group[t] : 0;
 
-  // staging: thread -> (row = tid >> 1, half h of the channels) for K = 128 / (row = tid >> 1 ...): 2 threads per row
-  const int sr = tid >> 1, sq = tid & 1;
-  constexpr int CPT = K / 2;  // channels per staging thread: 64 / 32
+  // staging: thread -> (4 consecutive rows sr4 .. sr4+3, CPT consecutive channels): the transposed LDS image
+  // [channel][row] then takes one 8-byte store per channel and plane instead of four 2-byte ones
+  constexpr int TPR = GR_THREADS / (GR_ROWS / 4);  // threads per row quad: 8
+  constexpr int CPT = K / TPR;                     // channels per staging thread: 16 / 8
+  const int sr4 = (tid / TPR) * 4, sq = tid % TPR;
   float gs[WT][WT][16], gc[WT][WT][16];
 #pragma unroll
   for (int a = 0; a < WT; ++a)
@@ -64,23 +66,33 @@ __global__ __launch_bounds__(GR_THREADS) void gram_rows_kernel(const float* __re
     const int nr = min(GR_ROWS, nrows - r0);
     // ---- stage: normalise + ReLU + hi/lo split, transposed into LDS ([channel][row]) ----
     {
-      const bool rv = sr < nr;
-      const float* px = X + (long)(row0 + r0 + (rv ? sr : 0)) * ldx + sq * CPT;
+      typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
       const float* ps = sc + (long)grp * ldsc + sq * CPT;
       const float* ph = sh + (long)grp * ldsc + sq * CPT;
-#pragma unroll 4
+#pragma unroll
       for (int c4 = 0; c4 < CPT; c4 += 4) {
-        const f32x4 x = *reinterpret_cast<const f32x4*>(px + c4);
         const f32x4 s4 = *reinterpret_cast<const f32x4*>(ps + c4);
         const f32x4 h4 = *reinterpret_cast<const f32x4*>(ph + c4);
+        f32x4 x[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const bool rv = sr4 + rr < nr;
+          x[rr] = *reinterpret_cast<const f32x4*>(X + (long)(row0 + r0 + (rv ? sr4 + rr : 0)) * ldx + sq * CPT + c4);
+          if (!rv) x[rr] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float y = fminf(fmaxf(fmaf(x[e], s4[e], h4[e]), 0.f), 65000.f);
-          if (!rv) y = 0.f;
-          const _Float16 hi = (_Float16)y;
+          f16x4 hi, lo;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            float y = fminf(fmaxf(fmaf(x[rr][e], s4[e], h4[e]), 0.f), 65000.f);
+            if (sr4 + rr >= nr) y = 0.f;  // rows past the end of the super-tile contribute nothing
+            hi[rr] = (_Float16)y;
+            lo[rr] = (_Float16)(y - (float)hi[rr]);
+          }
           const int c = sq * CPT + c4 + e;
-          Th[c * GR_LD + sr] = hi;
-          Tl[c * GR_LD + sr] = (_Float16)(y - (float)hi);
+          *reinterpret_cast<f16x4*>(&Th[c * GR_LD + sr4]) = hi;
+          *reinterpret_cast<f16x4*>(&Tl[c * GR_LD + sr4]) = lo;
         }
       }
     }
@@ -171,7 +183,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restri
   red[(long)g * (KK + K) + idx] = s;
 }
 
-// scale / shift of GroupNorm(N, N) applied to v = W a + b: one workgroup per (group, 64 output channels);
+// scale / shift of GroupNorm(N, N) applied to v = W a + b: one workgroup per (group, 16 output channels);
 // Cov(a) lives in LDS as float64 (K = 128: 128 KB).
 template <int K>
 __global__ __launch_bounds__(256) void gn_finalize_gram_kernel(const double* __restrict__ red,
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(256) void gn_finalize_gram_kernel(const double* __r
                                                                float* __restrict__ sc, float* __restrict__ sh) {
   __shared__ double C[K * K];
   __shared__ double m[K];
-  const int g = blockIdx.x, n0 = blockIdx.y * 64;
+  const int g = blockIdx.x, n0 = blockIdx.y * 16;
   const double cnt = (double)grp_count[g];
   const double* R = red + (long)g * (K * K + K);
   for (int k = threadIdx.x; k < K; k += 256) m[k] = R[K * K + k] / cnt;
@@ -191,7 +203,7 @@ __global__ __launch_bounds__(256) void gn_finalize_gram_kernel(const double* __r
   for (int idx = threadIdx.x; idx < K * K; idx += 256) C[idx] = R[idx] / cnt - m[idx / K] * m[idx % K];
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int cc = wave; cc < 64; cc += 4) {
+  for (int cc = wave; cc < 16; cc += 4) {
     const int n = n0 + cc;
     if (n >= N) break;
     const float* w = Wm + (long)n * K;
@@ -245,10 +257,10 @@ extern "C" int mmmot_gn_finalize_gram(const double* Gp, const double* Sp, const 
   hipLaunchKernelGGL(gram_reduce_kernel, dim3((K * K + K + 255) / 256, G), dim3(256), 0, s, Gp, Sp, grp_tile0,
                      grp_ntiles, K, work);
   if (K == 128)
-    hipLaunchKernelGGL(gn_finalize_gram_kernel<128>, dim3(G, (N + 63) / 64), dim3(256), 0, s, work, grp_count, W, bias,
+    hipLaunchKernelGGL(gn_finalize_gram_kernel<128>, dim3(G, (N + 15) / 16), dim3(256), 0, s, work, grp_count, W, bias,
                        N, gamma, beta, eps, sc, sh);
   else
-    hipLaunchKernelGGL(gn_finalize_gram_kernel<64>, dim3(G, (N + 63) / 64), dim3(256), 0, s, work, grp_count, W, bias,
+    hipLaunchKernelGGL(gn_finalize_gram_kernel<64>, dim3(G, (N + 15) / 16), dim3(256), 0, s, work, grp_count, W, bias,
                        N, gamma, beta, eps, sc, sh);
   return mm_check(hipGetLastError());
 }

@@ -31,7 +31,7 @@ class RowTiles:
     and the finalize kernel is handed the per-tile row counts."""
 
     def __init__(self, counts, device, sub_counts=None, tile=TILE):
-        TILE = int(tile)  # rows per tile (128 for the GEMM kernels; 1024 for the Gram super-tiles)
+        TILE = int(tile)  # rows per tile (128 for the GEMM kernels; 4096 for the Gram super-tiles)
         counts = [int(c) for c in counts]
         row0, nrows, group, g_tile0, g_ntiles, g_row0 = [], [], [], [], [], []
         sub_tile0, sub_ntiles = [], []
@@ -153,8 +153,8 @@ class BatchPlan:
             self.ptd_tiles = RowTiles(P_b, device, sub_counts=per_sample)
             self.det_tile_segs = Segments(self.ptd_tiles.h_sub_tile0, self.ptd_tiles.h_sub_ntiles, np.ones(Lt),
                                           det_sample, device, div=cnts)
-            # super-tiles of <= 1024 rows inside a sample: second-moment (Gram) statistics of a layer's input
-            self.gram_tiles = RowTiles(P_b, device, tile=1024)
+            # super-tiles of <= 4096 rows inside a sample: second-moment (Gram) statistics of a layer's input
+            self.gram_tiles = RowTiles(P_b, device, tile=4096)
             # 64-row half tiles of ptd_tiles (the A-resident GEMM emits its partials per wave = per half tile)
             self.ptd_half = HalfTiles(self.ptd_tiles, device)
             self.det_half_segs = Segments(2 * self.ptd_tiles.h_sub_tile0, 2 * self.ptd_tiles.h_sub_ntiles,
