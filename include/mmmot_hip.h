@@ -112,6 +112,14 @@ int mmmot_conv3x3_bn_relu_hl16_dma(const void* in, const void* wp, const float* 
 int mmmot_conv3x3_bn_relu_hl16_patch(const void* in, const void* wp, const float* bias, void* out,
                                      int L, int H, int W, int Cin, int Cout, int pool, float oscale,
                                      void* stream);
+/* conv1_1 (3->64) + conv1_2 (64->64) + 2x2 max-pool of the VGG trunk in ONE kernel (reference modules/vgg.py:67-80,
+ * layers 0-6 of vgg16_bn.features): the patch kernel computes conv1_1 for the haloed 18x18 patch of every tile in
+ * its prologue instead of reading it, so the [L][H][W][64] tensor (537 MB per cfg3 pair) is never written.
+ *   crops NCHW fp32 [L][3][H][W];  w1 hl16 [64][32] (k = (ky*3+kx)*3 + colour, zero-padded), bias1 [64], oscale1;
+ *   w2 hl16 [9][64][64], bias2 [64], oscale2;  out hl16 NHWC [L][H/2][W/2][64].  H, W even. */
+int mmmot_conv1_fused_hl16(const float* crops, const void* w1, const float* bias1, float oscale1,
+                           const void* w2, const float* bias2, float oscale2, void* out, int L, int H, int W,
+                           void* stream);
 int mmmot_set_patch_variant(int v); /* timing experiments of the patch kernel (0 = product; 1..4 give WRONG results) */
 int mmmot_set_dma_variant(int v); /* tuning / experiment knob of the LDS-DMA kernel (0 = default) */
 int mmmot_conv3x3_first_hl16(const float* in, const float* wp, const float* bias, void* out,

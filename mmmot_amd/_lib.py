@@ -77,6 +77,7 @@ SIGNATURES = {
     'mmmot_conv3x3_bn_relu_hl16': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, c_f],
     'mmmot_conv3x3_bn_relu_hl16_dma': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, c_f],
     'mmmot_conv3x3_bn_relu_hl16_patch': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, c_f],
+    'mmmot_conv1_fused_hl16': [c_f, c_f, c_f, ctypes.c_float, c_f, c_f, ctypes.c_float, c_f, c_i, c_i, c_i, c_f],
     'mmmot_conv3x3_first_hl16': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
     'mmmot_set_conv_variant': [c_i],
     'mmmot_set_dma_variant': [c_i],

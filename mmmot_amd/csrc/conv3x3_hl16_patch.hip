@@ -88,11 +88,24 @@ __device__ __forceinline__ void pt_row_to_pixel(int g, int i, int& blk, int& y, 
 
 // EXP: timing experiments only (WRONG results unless 0): 1 = no loads in the K loop, 2 = no barriers in
 // the K loop, 3 = no fragment reads in the K loop, 4 = no MFMAs
-template <int BN, int BS, bool POOL, int EXP>
+// FUSE1: the layer's input is not read from memory but COMPUTED: conv1_1 (3 -> 64, folded BN, ReLU) of the
+// raw crops is evaluated for the 18x18 haloed patch of every tile in the prologue (a 352 x 64 x 32 mini-GEMM on
+// the matrix cores: K = 27 taps*colours padded to 32) and written straight into the two LDS patch buffers
+// (Cin = 64 = both 32-channel slabs).  The [L][H][W][64] conv1_1 tensor (537 MB per cfg3 pair: written once,
+// read 1.3x) never exists.  Requires BN = 64, BS = 16, Cin = Cout = 64.
+struct Fuse1Args {
+  const float* raw;    // crops, NCHW fp32 [L][3][H][W]
+  const u32x4* w1;     // conv1_1 weights, hl16 [64][32] (k = tap*3 + colour, zero for k >= 27), scaled by 2^shift
+  const float* bias1;  // [64] folded BN bias
+  float oscale1;       // 2^-shift
+};
+
+template <int BN, int BS, bool POOL, int EXP, bool FUSE1 = false>
 __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     const u32x4* __restrict__ in, const u32x4* __restrict__ wp, const float* __restrict__ bias,
     u32x4* __restrict__ out, int L, int H, int W, int Cin, int Cout, int nby, int nbx, int nblk, int ntm, int ntn,
-    float oscale) {
+    float oscale, Fuse1Args fz) {
+  static_assert(!FUSE1 || (BN == 64 && BS == 16), "the fused first layer exists for 64-channel 16x16 tiles");
   using G = PatchGeom<BS>;
   constexpr int WN = (BN == 128) ? 2 : 1;  // waves along channels
   constexpr int WM = 8 / WN;               // waves along pixels
@@ -104,7 +117,9 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   constexpr int RING0 = 2 * G::BYTES;
   constexpr int LOOP_BYTES = RING0 + 3 * B_BYTES;
   constexpr int EPI_BYTES = P_BM * CLD * 4;
-  constexpr int SMEM = LOOP_BYTES > EPI_BYTES ? LOOP_BYTES : EPI_BYTES;
+  constexpr int RAW_OFF = LOOP_BYTES;                      // FUSE1: raw input window [3][20][20] fp32
+  constexpr int RAW_BYTES = FUSE1 ? 3 * 20 * 20 * 4 + 256 : 0;  // + conv1_1 bias [64]
+  constexpr int SMEM = (LOOP_BYTES + RAW_BYTES) > EPI_BYTES ? (LOOP_BYTES + RAW_BYTES) : EPI_BYTES;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
 
   const int tid = threadIdx.x;
@@ -117,6 +132,29 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   // of a channel tile stay in that XCD's L2) and its workgroups take the chunk's tiles round-robin.  One
   // launch-time workgroup per tile would leave the CU idle for a dispatch latency between tiles: with a
   // single resident workgroup nothing overlaps it (measured: fixed cost of ~2 channel slabs per tile).
+  // FUSE1: conv1_1 weight fragments (B operand: channel lr + 32*nt, k = 16j + 8h ..+7) stay in registers for
+  // the whole (persistent) kernel; the raw-window offsets of the 16 k values a lane gathers are fixed too
+  f16x8 w1h[2][2], w1l[2][2];
+  int roff[2][8];
+  if constexpr (FUSE1) {
+    const int l31 = threadIdx.x & 31, hh = (threadIdx.x & 63) >> 5;
+#pragma unroll
+    for (int nt1 = 0; nt1 < 2; ++nt1)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const u32x4* p = fz.w1 + ((nt1 * 32 + l31) * 4 + (2 * j + hh)) * 2;
+        w1h[nt1][j] = __builtin_bit_cast(f16x8, p[0]);
+        w1l[nt1][j] = __builtin_bit_cast(f16x8, p[1]);
+      }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = 16 * j + 8 * hh + e;
+        const int tap = k / 3, c = k - 3 * tap;
+        roff[j][e] = (k < 27) ? c * 400 + (tap / 3) * 20 + (tap % 3) : -1;
+      }
+  }
   const int nitems = ntm * ntn;
   const int xq = nitems >> 3, xr = nitems & 7;
   const int xcd = blockIdx.x & 7;
@@ -295,7 +333,87 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   int pcur = 0;          // patch buffer of the current slab (byte offset in smem)
   int pnext = G::BYTES;  // patch buffer being filled for the next slab
   static_assert(G::BYTES % 256 == 0 && RING0 % 256 == 0 && B_BYTES % 256 == 0, "hi/lo xor addressing");
-  {
+  if constexpr (FUSE1) {
+    issue_b(0, 0, 0);  // conv1_2's weight ring flies while the patch is computed
+    issue_b(1, 0, 1);
+    issue_b(2, 0, 2);
+    // ---- raw window: image rows by*16-2 .. +19, columns bx*16-2 .. +19 of the 3 colour planes (zero outside) ----
+    float* R = reinterpret_cast<float*>(smem + RAW_OFF);
+    const int b0 = mt;  // NB == 1
+    const int crop0 = b0 / nbpc, br0 = b0 - crop0 * nbpc;
+    const int by0 = br0 / nbx, bx0 = br0 - by0 * nbx;
+    for (int i = tid; i < 1200; i += 512) {
+      const int c = i / 400, rem = i - c * 400;
+      const int wy = rem / 20, wx = rem - wy * 20;
+      const int gy = by0 * 16 - 2 + wy, gx = bx0 * 16 - 2 + wx;
+      float v = 0.f;
+      if (b0 < nblk && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+        v = fz.raw[(((long)crop0 * 3 + c) * H + gy) * W + gx];
+      R[i] = v;
+    }
+    if (tid < 64) R[1200 + tid] = fz.bias1[tid];
+    __syncthreads();
+    // ---- conv1_1 on the 324 patch pixels as C^T = W1 X^T: MFMA rows = channels, columns = pixels, so a lane
+    // ends up with ONE pixel (lane & 31 of pixel tile g) and, per 8-channel unit, 4 consecutive channels: its
+    // hi and lo halves leave as two 8-byte LDS stores and all per-pixel work (coordinates, swizzle, image
+    // mask) is done once per lane.  11 pixel tiles of 32: waves take g = wave, wave + 8. ----
+    const float* B1 = reinterpret_cast<const float*>(smem + RAW_OFF + 4800);  // conv1_1 bias [64] (staged above)
+#pragma nounroll
+    for (int g = wave; g < 11; g += 8) {
+      const int n = g * 32 + lr;  // this lane's patch pixel
+      const int ppy = n / 18, ppx = n - ppy * 18;
+      const int rbase = ppy * 20 + ppx;  // window position of tap (0,0)
+      f32x16 c1[2];
+#pragma unroll
+      for (int nt1 = 0; nt1 < 2; ++nt1)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) c1[nt1][e] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f16x8 xh, xl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float v = 0.f;
+          if (n < 324 && roff[j][e] >= 0) v = R[rbase + roff[j][e]];
+          xh[e] = (_Float16)v;
+          xl[e] = (_Float16)(v - (float)xh[e]);
+        }
+#pragma unroll
+        for (int nt1 = 0; nt1 < 2; ++nt1) {
+          c1[nt1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1l[nt1][j], xh, c1[nt1], 0, 0, 0);
+          c1[nt1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h[nt1][j], xl, c1[nt1], 0, 0, 0);
+          c1[nt1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h[nt1][j], xh, c1[nt1], 0, 0, 0);
+        }
+      }
+      if (n < 324) {
+        // bias + ReLU; zero outside the image (conv1_2's zero padding applies to conv1_1's OUTPUT)
+        const int gy = by0 * 16 - 1 + ppy, gx = bx0 * 16 - 1 + ppx;
+        const bool inimg = (b0 < nblk) && ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
+        const int sw = pt_swz_a(ppy, ppx);
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int nt1 = 0; nt1 < 2; ++nt1) {
+          const int pb = (nt1 == 0 ? pcur : pnext) + n * P_ROWB + h * 8;  // 32-channel slab nt1, this pixel's record
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {  // unit q of the slab: channels 8q + 4h .. + 3 are registers 4q .. 4q+3
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(&B1[nt1 * 32 + 8 * q + 4 * h]);
+            f16x4 hi, lo;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float v = fminf(fmaxf(fmaf(c1[nt1][4 * q + r], fz.oscale1, bq[r]), 0.f), 65000.f);
+              if (!inimg) v = 0.f;
+              hi[r] = (_Float16)v;
+              lo[r] = (_Float16)(v - (float)hi[r]);
+            }
+            *reinterpret_cast<f16x4*>(smem + pb + (((2 * q) ^ sw) << 4)) = hi;
+            *reinterpret_cast<f16x4*>(smem + pb + (((2 * q + 1) ^ sw) << 4)) = lo;
+          }
+        }
+      }
+    }
+    pt_wait_vm<2 * NBL>();  // weight stage 0 landed (this wave's part)
+    __syncthreads();        // both patch slabs are complete
+  } else {
     issue_patch_round(std::integral_constant<int, 0>{}, 0, pcur);
     issue_patch_round(std::integral_constant<int, 1>{}, 0, pcur);
     issue_patch_round(std::integral_constant<int, 2>{}, 0, pcur);
@@ -323,7 +441,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     constexpr int ptap = (tap + 8) % 9;  // tap of the previous stage
     constexpr int prev_issued =
         (tap == 0) ? NBL  // previous stage = tap 8 of a non-last slab (or the prologue's stage-2 weights)
-                   : ((last ? 0 : (ptap < G::PA ? 1 : 0)) + ((last && ptap + 3 > 8) ? 0 : NBL));
+                   : (((last || FUSE1) ? 0 : (ptap < G::PA ? 1 : 0)) + ((last && ptap + 3 > 8) ? 0 : NBL));
     // Half stages are written as ONE MFMA + ONE other instruction at a time (sched_barrier pins the order):
     // the two waves of a SIMD run in lockstep after every barrier, so any run of non-MFMA issue (8 ds_reads,
     // an LDS-DMA with its address math) leaves the matrix pipe idle unless it is cut into MFMA-sized gaps.
@@ -372,7 +490,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
       if constexpr (EXP != 1) {
         constexpr int at_patch = (NMMA >= 12) ? 2 : 1, at_b0 = (NMMA >= 12) ? 6 : 4, at_b1 = 10;
         if constexpr (i == at_patch) {
-          if constexpr (!last && tap < G::PA) issue_patch_round(TAPC, slab + 1, pnext);
+          if constexpr (!FUSE1 && !last && tap < G::PA) issue_patch_round(TAPC, slab + 1, pnext);
           __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (i == at_b0 || (i == at_b1 && NBL > 1)) {
@@ -517,9 +635,9 @@ extern "C" int mmmot_set_patch_variant(int v) {
   return MMMOT_OK;
 }
 
-template <int BN, int BS, bool POOL, int EXP>
+template <int BN, int BS, bool POOL, int EXP, bool FUSE1 = false>
 static int launch_patch_e(const void* in, const void* wp, const float* bias, void* out, int L, int H, int W, int Cin,
-                        int Cout, float oscale, hipStream_t s) {
+                        int Cout, float oscale, hipStream_t s, Fuse1Args fz = Fuse1Args{nullptr, nullptr, nullptr, 1.f}) {
   const int nby = (H + BS - 1) / BS, nbx = (W + BS - 1) / BS;
   const int nblk = L * nby * nbx;
   constexpr int NB = PatchGeom<BS>::NB;
@@ -535,8 +653,9 @@ static int launch_patch_e(const void* in, const void* wp, const float* bias, voi
   const int nitems = ntm * ntn;
   int grid = (n_cu / 8) * 8;                       // one persistent workgroup per CU, whole XCDs
   if (grid > ((nitems + 7) / 8) * 8) grid = ((nitems + 7) / 8) * 8;
-  hipLaunchKernelGGL((conv3x3_hl16_patch_kernel<BN, BS, POOL, EXP>), dim3(grid), dim3(512), 0, s, (const u32x4*)in,
-                     (const u32x4*)wp, bias, (u32x4*)out, L, H, W, Cin, Cout, nby, nbx, nblk, ntm, ntn, oscale);
+  hipLaunchKernelGGL((conv3x3_hl16_patch_kernel<BN, BS, POOL, EXP, FUSE1>), dim3(grid), dim3(512), 0, s,
+                     (const u32x4*)in, (const u32x4*)wp, bias, (u32x4*)out, L, H, W, Cin, Cout, nby, nbx, nblk, ntm, ntn,
+                     oscale, fz);
   return mm_check(hipGetLastError());
 }
 
@@ -577,4 +696,15 @@ extern "C" int mmmot_conv3x3_bn_relu_hl16_patch(const void* in, const void* wp, 
                : launch_patch_p<128, 8>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
   return big ? launch_patch_p<64, 16>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s)
              : launch_patch_p<64, 8>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
+}
+
+// conv1_1 (3 -> 64) + conv1_2 (64 -> 64) + 2x2 max-pool in one kernel: see FUSE1 above.
+extern "C" int mmmot_conv1_fused_hl16(const float* crops, const void* w1, const float* bias1, float oscale1,
+                                      const void* w2, const float* bias2, float oscale2, void* out, int L, int H,
+                                      int W, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!crops || !w1 || !bias1 || !w2 || !bias2 || !out || L <= 0 || H <= 0 || W <= 0) return MMMOT_EINVAL;
+  if ((H & 1) || (W & 1) || !mm_al16(w1) || !mm_al16(w2) || !mm_al16(out)) return MMMOT_EINVAL;
+  Fuse1Args fz{crops, (const u32x4*)w1, bias1, oscale1};
+  return launch_patch_e<64, 16, true, 0, true>(nullptr, w2, bias2, out, L, H, W, 64, 64, oscale2, s, fz);
 }

@@ -37,6 +37,8 @@ class Engine:
         self.pn_fused = os.environ.get('MMMOT_PN_FUSED', '1') != '0'
         # conv5 statistics from the Gram matrix of its input instead of a statistics pass of the GEMM
         self.pn_gram = os.environ.get('MMMOT_PN_GRAM', '1') != '0'
+        # conv1_1 evaluated inside conv1_2's patch prologue (MMMOT_FUSE_CONV1=0: two launches)
+        self.fuse_conv1 = os.environ.get('MMMOT_FUSE_CONV1', '1') != '0'
         self.mlp = trunk  # the 1x1-conv / linear GEMMs follow the same arithmetic choice
         if affinity_op not in PAIR_OPS:
             raise ValueError('unknown affinity_op %r' % (affinity_op,))
@@ -104,13 +106,24 @@ class Engine:
         ops, Lt, S = self.ops, plan.Lt, plan.S
         x, H, W = crops, S, S
         f16 = (self.trunk == 'f16x3')  # activations travel in the hl16 split-half format (same bytes)
-        for li, cv in enumerate(self.P['vgg']):
+        vgg = self.P['vgg']
+        # conv1_1 + conv1_2 + pool as one launch when the trunk has the VGG16 head (3 -> 64 -> 64, pool)
+        fuse1 = (f16 and self.conv_impl == 'patch' and self.fuse_conv1 and len(vgg) > 1 and vgg[0]['cout'] == 64 and
+                 vgg[1]['cin'] == 64 and vgg[1]['cout'] == 64 and vgg[1]['pool'] and not vgg[0]['last'] and
+                 not vgg[0]['pool'] and H % 2 == 0 and W % 2 == 0)
+        for li, cv in enumerate(vgg):
+            if fuse1 and li == 0:
+                continue
             Ho, Wo = (H // 2, W // 2) if cv['pool'] else (H, W)
             out = self.buf('vgg%d' % (li & 1), Lt * Ho * Wo, cv['cout'])
             if self.conv_events is not None:  # bench.py: HIP events around every trunk launch
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            if not f16:
+            if fuse1 and li == 1:
+                c0 = vgg[0]
+                ops.conv1_fused_hl16(x, c0['wp16'], c0['bias'], c0['oscale'], cv['wp16'], cv['bias'], cv['oscale'], out,
+                                     Lt, H, W)
+            elif not f16:
                 ops.conv3x3(x, cv['wp'], cv['bias'], out, Lt, H, W, cv['cin'], cv['cout'], li == 0, cv['pool'])
             elif li == 0:
                 ops.conv3x3_first_hl16(x, cv['wp'], cv['bias'], out, Lt, H, W, cv['cout'])

@@ -79,6 +79,12 @@ class HipOps:
                                                        Cout, int(pool), float(oscale), self._stream())
         _lib.check(st, 'mmmot_conv3x3_bn_relu_hl16_patch')
 
+    def conv1_fused_hl16(self, crops, w1, bias1, oscale1, w2, bias2, oscale2, out, L, H, W):
+        """conv1_1 + conv1_2 + max-pool in one launch (the conv1_1 tensor never reaches HBM)."""
+        st = self.lib.mmmot_conv1_fused_hl16(_ptr(crops), _ptr(w1), _ptr(bias1), float(oscale1), _ptr(w2),
+                                             _ptr(bias2), float(oscale2), _ptr(out), L, H, W, self._stream())
+        _lib.check(st, 'mmmot_conv1_fused_hl16')
+
     def conv3x3_first_hl16(self, inp, wp, bias, out, L, H, W, Cout):
         st = self.lib.mmmot_conv3x3_first_hl16(_ptr(inp), _ptr(wp), _ptr(bias), _ptr(out), L, H, W, Cout,
                                                self._stream())

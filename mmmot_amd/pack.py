@@ -121,8 +121,9 @@ def pack_weights(sd, fusion, device, eps=1e-5):
                     wp = w.permute(2, 3, 0, 1).reshape(9, cout, cin)
                 cv = dict(wp=f32(wp), bias=f32(b), cin=cin, cout=cout, pool=pool, stage=s,
                           last=(idx == stage[-1][0]))
-                if cin != 3:
-                    # fp16-split (hl16) copy for the f16 matrix-core trunk: weights scaled by 2^shift
+                if True:
+                    # fp16-split (hl16) copy for the f16 matrix-core trunk: weights scaled by 2^shift (the first
+                    # layer's [Cout][32] copy feeds the fused conv1_1+conv1_2 kernel)
                     shift = hl16_weight_shift(wp)
                     cv['wp16'] = to_hl16(wp * (2.0 ** shift)).contiguous().to(device)
                     cv['oscale'] = 2.0 ** (-shift)

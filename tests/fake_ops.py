@@ -67,6 +67,13 @@ class TorchOps:
         rows = y.permute(0, 2, 3, 1).reshape(-1, Cout)
         out.reshape(-1)[:rows.numel()].view(-1, Cout).copy_(to_hl16(rows))
 
+    def conv1_fused_hl16(self, crops, w1, bias1, oscale1, w2, bias2, oscale2, out, L, H, W):
+        from mmmot_amd.pack import from_hl16, to_hl16
+        w1f = from_hl16(w1.reshape(64, 32)) * oscale1
+        tmp = torch.zeros(L * H * W, 64)
+        self.conv3x3(crops, w1f, bias1, tmp, L, H, W, 3, 64, True, False)
+        self.conv3x3_hl16(to_hl16(tmp), w2, bias2, out, L, H, W, 64, 64, True, oscale2)
+
     def conv3x3_first_hl16(self, inp, wp, bias, out, L, H, W, Cout):
         from mmmot_amd.pack import to_hl16
         tmp = torch.zeros(L * H * W, Cout)

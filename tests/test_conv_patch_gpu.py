@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from fake_ops import TorchOps
-from mmmot_amd.pack import from_hl16, hl16_weight_shift, to_hl16
+from mmmot_amd.pack import from_hl16, hl16_weight_shift, to_hl16  # noqa: F401
 from test_kernels_gpu import close, hip, rnd  # noqa: F401  (hip is a fixture)
 
 pytestmark = pytest.mark.gpu
@@ -71,3 +71,30 @@ def test_patch_matches_tile_kernel_and_is_deterministic(hip):
             first = o.clone()
         else:
             assert torch.equal(first, o), 'patch kernel is not deterministic across launches'
+
+
+@pytest.mark.parametrize('L,H,W', [(2, 16, 16), (3, 32, 48), (1, 14, 22), (5, 64, 64), (2, 8, 8)])
+def test_conv1_fused_matches_two_layer_reference(hip, L, H, W):
+    """conv1_1 (3->64) + conv1_2 (64->64) + max-pool in one launch vs the float64 two-layer computation; maps that
+    are not multiples of the 16x16 block, crops smaller than a block, tiles at image borders."""
+    crops = rnd(L, 3, H, W, seed=500) * 1.5
+    w1 = rnd(64, 3, 3, 3, seed=501, scale=(2.0 / 27) ** 0.5)
+    b1 = rnd(64, seed=502, scale=0.1)
+    w2 = rnd(9, 64, 64, seed=503, scale=(2.0 / 576) ** 0.5)
+    b2 = rnd(64, seed=504, scale=0.1)
+    w1p = torch.zeros(64, 32)
+    w1p[:, :27] = w1.permute(0, 2, 3, 1).reshape(64, 27)
+    s1, s2 = hl16_weight_shift(w1p), hl16_weight_shift(w2)
+    w1h, w2h = to_hl16(w1p.double() * 2.0 ** s1), to_hl16(w2.double() * 2.0 ** s2)
+    # float64 reference built from the SAME (hl16-rounded) weights
+    w1r = (from_hl16(w1h) * 2.0 ** -s1)[:, :27].view(64, 3, 3, 3).permute(0, 3, 1, 2).double()
+    w2r = (from_hl16(w2h.reshape(9 * 64, 64)) * 2.0 ** -s2).view(3, 3, 64, 64).permute(2, 3, 0, 1).double()
+    y = torch.relu(torch.nn.functional.conv2d(crops.double(), w1r, b1.double(), padding=1))
+    y = torch.relu(torch.nn.functional.conv2d(y, w2r, b2.double(), padding=1))
+    y = torch.nn.functional.max_pool2d(y, 2, 2)
+    ref = y.permute(0, 2, 3, 1).reshape(-1, 64).float()
+    out16 = torch.full((L * (H // 2) * (W // 2), 64), float('nan')).cuda()
+    hip.conv1_fused_hl16(crops.cuda(), w1h.cuda(), b1.cuda(), 2.0 ** -s1, w2h.cuda(), b2.cuda(), 2.0 ** -s2, out16, L, H, W)
+    out = torch.zeros_like(out16)
+    hip.hl16_unpack(out16, out)
+    close(out, ref, 3e-6, 'fused conv1_1 + conv1_2 + pool vs float64')
