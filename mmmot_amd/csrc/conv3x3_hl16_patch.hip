@@ -160,16 +160,39 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   const int xcd = blockIdx.x & 7;
   const int cbase = (xcd < xr) ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
   const int clen = (xcd < xr) ? xq + 1 : xq;
+  auto decode_item = [&](int item, int& mt, int& nt) {
+    if (clen % ntn == 0 && cbase % ntn == 0) {
+      const int mcount = clen / ntn;
+      nt = item / mcount;
+      mt = cbase / ntn + item % mcount;
+    } else {
+      mt = (cbase + item) / ntn;
+      nt = (cbase + item) % ntn;
+    }
+  };
+  // FUSE1: the raw input window of the NEXT tile is fetched into registers while the current tile's
+  // epilogue runs (nothing else hides that round trip: one workgroup per CU)
+  float rawv[3] = {0.f, 0.f, 0.f};
+  bool raw_ready = false;
+  auto fetch_raw = [&](int mtile) {
+    const int nbpc_ = nby * nbx;
+    const int crop = mtile / nbpc_, br = mtile - crop * nbpc_;
+    const int by = br / nbx, bx = br - by * nbx;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int i = threadIdx.x + 512 * k;
+      const int c = i / 400, rem = i - c * 400;
+      const int wy = rem / 20, wx = rem - wy * 20;
+      const int gy = by * 16 - 2 + wy, gx = bx * 16 - 2 + wx;
+      float v = 0.f;
+      if (i < 1200 && mtile < nblk && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+        v = fz.raw[(((long)crop * 3 + c) * H + gy) * W + gx];
+      rawv[k] = v;
+    }
+  };
   for (int item = blockIdx.x >> 3; item < clen; item += gridDim.x >> 3) {
   int mt, nt;
-  if (clen % ntn == 0 && cbase % ntn == 0) {
-    const int mcount = clen / ntn;
-    nt = item / mcount;
-    mt = cbase / ntn + item % mcount;
-  } else {
-    mt = (cbase + item) / ntn;
-    nt = (cbase + item) % ntn;
-  }
+  decode_item(item, mt, nt);
   const int n0 = nt * BN;
   const int cin8 = Cin >> 3;
   const int nslab = Cin >> 5;
@@ -342,15 +365,10 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     const int b0 = mt;  // NB == 1
     const int crop0 = b0 / nbpc, br0 = b0 - crop0 * nbpc;
     const int by0 = br0 / nbx, bx0 = br0 - by0 * nbx;
-    for (int i = tid; i < 1200; i += 512) {
-      const int c = i / 400, rem = i - c * 400;
-      const int wy = rem / 20, wx = rem - wy * 20;
-      const int gy = by0 * 16 - 2 + wy, gx = bx0 * 16 - 2 + wx;
-      float v = 0.f;
-      if (b0 < nblk && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
-        v = fz.raw[(((long)crop0 * 3 + c) * H + gy) * W + gx];
-      R[i] = v;
-    }
+    if (!raw_ready) fetch_raw(b0);  // first tile of this workgroup
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (tid + 512 * k < 1200) R[tid + 512 * k] = rawv[k];
     if (tid < 64) R[1200 + tid] = fz.bias1[tid];
     __syncthreads();
     // ---- conv1_1 on the 324 patch pixels as C^T = W1 X^T: MFMA rows = channels, columns = pixels, so a lane
@@ -533,6 +551,15 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   }
   slab_body(std::true_type{}, nslab - 1);
 
+  if constexpr (FUSE1) {
+    const int nitem = item + (gridDim.x >> 3);
+    raw_ready = nitem < clen;
+    if (raw_ready) {
+      int mt2, nt2;
+      decode_item(nitem, mt2, nt2);
+      fetch_raw(mt2);
+    }
+  }
   // ---- epilogue: accumulators -> LDS fp32 [256][BN+4] -> pool/bias/relu/split -> hl16 -------------
   // thread -> fixed channel unit u (8 channels) and rows r0, r0 + RSTEP, ...: bias is loaded once, before
   // the barriers (a load inside the store loop costs one L2 round trip per iteration)
