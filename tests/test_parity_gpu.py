@@ -151,3 +151,23 @@ def test_full_size_properties_cfg3():
     assert ((new.cpu() >= 0) & (new.cpu() <= 1)).all() and ((link >= 0) & (link <= 1)).all()
     # dual_add: sum over all entries = (N + M) / 2 per modality row
     assert (link.sum(dim=(1, 2)) - (N + M) / 2).abs().max() < 1e-3
+
+
+@pytest.mark.parametrize('knobs', [
+    dict(conv_impl='tile'), dict(conv_impl='dma'), dict(fuse_conv1=False), dict(pn_gram=False), dict(pn_fused=False),
+    dict(conv_impl='tile', pn_fused=False, pn_gram=False, fuse_conv1=False)], ids=lambda k: ','.join('%s=%s' % kv for kv in k.items()))
+@pytest.mark.parametrize('name', ['s4_cfg2_A', 's2_C_minus_abs_dual_add', 's3_kitti_A'])
+def test_alternative_engine_paths_match_golden(name, knobs):
+    """Every machine mapping the engine can be switched to (tile / LDS-DMA trunk kernels, unfused conv1,
+    statistics pass instead of the Gram route, materialising PointNet) stays inside the same tolerance."""
+    if name not in case_names():
+        pytest.skip('no such golden case')
+    c, base = get_case(name)
+    m = build_model(c, base, device=DEV)
+    eng = m.engine()
+    for k, v in knobs.items():
+        assert hasattr(eng, k)
+        setattr(eng, k, v)
+    with torch.no_grad():
+        out = m(*to_dev(case_inputs(c)))
+    compare_outputs(out, golden(name), tol=TOL)
