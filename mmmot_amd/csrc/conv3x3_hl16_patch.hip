@@ -87,7 +87,8 @@ __device__ __forceinline__ void pt_row_to_pixel(int g, int i, int& blk, int& y, 
 }
 
 // EXP: timing experiments only (WRONG results unless 0): 1 = no loads in the K loop, 2 = no barriers in
-// the K loop, 3 = no fragment reads in the K loop, 4 = no MFMAs
+// the K loop, 3 = no fragment reads in the K loop, 4 = no MFMAs, 5 = no epilogue at all, 6 = epilogue without
+// the global stores
 // FUSE1: the layer's input is not read from memory but COMPUTED: conv1_1 (3 -> 64, folded BN, ReLU) of the
 // raw crops is evaluated for the 18x18 haloed patch of every tile in the prologue (a 352 x 64 x 32 mini-GEMM on
 // the matrix cores: K = 27 taps*colours padded to 32) and written straight into the two LDS patch buffers
@@ -579,6 +580,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     bgy0[k] = by * BS;
     bgx0[k] = (br - by * nbx) * BS;
   }
+  if constexpr (EXP != 5) {
   __syncthreads();  // every wave is past its last LDS read; no DMA in flight (the last stages drained)
   float* Cs = reinterpret_cast<float*>(smem);
   const int cout8 = Cout >> 3;
@@ -620,8 +622,12 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
         pt_split8(v, hi, lo);
         const long pix = ((long)crop * Hq + (gy >> 1)) * Wq + (gx >> 1);
         u32x4* o = out + (pix * cout8 + (n0 >> 3) + eu) * 2;
-        o[0] = hi;
-        o[1] = lo;
+        if constexpr (EXP != 6) {
+          o[0] = hi;
+          o[1] = lo;
+        } else if (hi[0] == 0x12345678u && lo[1] == 0x9abcdef0u) {
+          o[0] = hi;  // keeps the computation alive without storing
+        }
       }
     }
   } else {
@@ -646,10 +652,15 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
         pt_split8(v, hi, lo);
         const long pix = ((long)crop * H + gy) * W + gx;
         u32x4* o = out + (pix * cout8 + (n0 >> 3) + eu) * 2;
-        o[0] = hi;
-        o[1] = lo;
+        if constexpr (EXP != 6) {
+          o[0] = hi;
+          o[1] = lo;
+        } else if (hi[0] == 0x12345678u && lo[1] == 0x9abcdef0u) {
+          o[0] = hi;  // keeps the computation alive without storing
+        }
       }
     }
+  }
   }
   __syncthreads();  // the staging area is the next tile's patch / ring
   }  // persistent tile loop
@@ -657,7 +668,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
 
 static int g_patch_exp = 0;
 extern "C" int mmmot_set_patch_variant(int v) {
-  if (v < 0 || v > 4) return MMMOT_EINVAL;
+  if (v < 0 || v > 6) return MMMOT_EINVAL;
   g_patch_exp = v;
   return MMMOT_OK;
 }
@@ -695,6 +706,8 @@ static int launch_patch(const void* in, const void* wp, const float* bias, void*
       case 2: return launch_patch_e<BN, BS, POOL, 2>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
       case 3: return launch_patch_e<BN, BS, POOL, 3>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
       case 4: return launch_patch_e<BN, BS, POOL, 4>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
+      case 5: return launch_patch_e<BN, BS, POOL, 5>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
+      case 6: return launch_patch_e<BN, BS, POOL, 6>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
       default: break;
     }
   }

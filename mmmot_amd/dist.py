@@ -51,12 +51,18 @@ def unflatten_results(flat, layout):
     return out
 
 
-def gather_flat(flat, group=None):
+def gather_flat(flat, group=None, equal=False):
     """All-gather variable-length fp32 vectors: returns the list of every rank's vector.
-    One length exchange + one padded all_gather_into_tensor (no per-tensor collectives)."""
+    One length exchange + one padded all_gather_into_tensor (no per-tensor collectives);
+    ``equal=True`` (every rank holds the same number of elements) skips the length exchange and
+    its device-to-host read-back."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return [flat]
     world = dist.get_world_size(group)
+    if equal:
+        out = torch.empty(world * flat.numel(), dtype=flat.dtype, device=flat.device)
+        dist.all_gather_into_tensor(out, flat.contiguous(), group=group)
+        return list(out.view(world, -1).unbind(0))
     n = torch.tensor([flat.numel()], dtype=torch.int64, device=flat.device)
     sizes = torch.empty(world, dtype=torch.int64, device=flat.device)
     dist.all_gather_into_tensor(sizes, n, group=group)
@@ -82,7 +88,7 @@ def gather_results(results, group=None, same_layout=False):
     else:
         layouts = [None] * world
         dist.all_gather_object(layouts, layout, group=group)
-    flats = gather_flat(flat, group)
+    flats = gather_flat(flat, group, equal=same_layout)
     out = []
     for f, l in zip(flats, layouts):
         out += unflatten_results(f, l)

@@ -26,7 +26,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--rounds', type=int, default=5)
     ap.add_argument('--crops', type=int, default=128, help='crops per launch (128 = one cfg3 pair)')
-    ap.add_argument('--variants', default='1,11', help='1 = 128-row tiles, 4 = 256-row tiles, 7..10 = LDS-DMA kernel variants 0..3, 11 = LDS-patch kernel, 12..15 = its timing experiments 1..4 (wrong results)')
+    ap.add_argument('--variants', default='1,11', help='1 = 128-row tiles, 4 = 256-row tiles, 7..10 = LDS-DMA kernel variants 0..3, 11 = LDS-patch kernel, 12..17 = its timing experiments 1..6 (wrong results)')
     args = ap.parse_args()
     ops = HipOps()
     lib = _lib.load()
