@@ -1,7 +1,8 @@
 #!/usr/bin/env python
-"""Throughput of the device image preparation on one MI355X, CPU oracle / Pillow beside it.
+"""(measurement script, not a pytest module; lives under tests/ because it uses the oracle as checker and CPU baseline)
+Throughput of the device image preparation on one MI355X, CPU oracle / Pillow beside it.
 
-    python tools/bench_crops.py [--dets 128] [--size 224] [--steps 50]
+    python tests/perf_crops.py [--dets 128] [--size 224] [--steps 50]
 
 Workload: one KITTI-sized RGB frame resident in HBM, ``--dets`` detections per step (the cfg3 frame pair has
 128), crop boxes 40..300 px.  One JSON line: detections/s, the HBM roofline of the resize kernel (algorithmic

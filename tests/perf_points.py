@@ -1,7 +1,8 @@
 #!/usr/bin/env python
-"""Throughput of the device point-cloud gather on one MI355X, CPU oracle timed beside it.
+"""(measurement script, not a pytest module; lives under tests/ because it uses the oracle as checker and CPU baseline)
+Throughput of the device point-cloud gather on one MI355X, CPU oracle timed beside it.
 
-    python tools/bench_points.py [--points 120000] [--boxes 16] [--sweeps 64] [--steps 20]
+    python tests/perf_points.py [--points 120000] [--boxes 16] [--sweeps 64] [--steps 20]
 
 Workload: ``--sweeps`` KITTI-like sweeps of ``--points`` x 4 floats each, resident in HBM; per sweep the
 reference's two stages (image-frustum filter: 1 polygon, no padding; per-box gather: ``--boxes`` 3D boxes,
