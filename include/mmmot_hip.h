@@ -322,6 +322,20 @@ int mmmot_points_count(const float* pts, int P, int F, const double* planes, int
                        int* cnt, int* split, void* stream);
 int mmmot_points_scatter(const float* pts, int P, int F, const double* planes, int NB, const int* cnt,
                          const int* split, float* out, int Fo, void* stream);
+/* Batched form: NS sweeps (points of sweep s = rows [sweep_row0[s], sweep_row0[s+1]) of pts) and NPOLY polygons
+ * (polygons of sweep s = [poly0[s], poly0[s+1]), at most 256 per sweep) in one launch; filt[s] >= 0 names a polygon
+ * of `planes` every emitted point of sweep s must ALSO be inside (the image frustum of remove_outside_points fused
+ * into the per-box test: same rows, same order as filtering first, no intermediate array).  Host-built tables:
+ * blk_sweep [NBLK] / blk_first [NS] (256-point blocks per sweep), cnt_off [NPOLY] (first counter of each polygon;
+ * polygon totals are stored at cnt[cnt_total + j]; cnt holds cnt_total + NPOLY ints).  split [NPOLY+1] as above. */
+int mmmot_points_count_batched(const float* pts, int F, int NS, int NPOLY, int NBLK, int cnt_total,
+                               const double* planes, const int* blk_sweep, const int* blk_first,
+                               const int* sweep_row0, const int* poly0, const int* filt, const int* cnt_off,
+                               int pad_empty, int* cnt, int* split, void* stream);
+int mmmot_points_scatter_batched(const float* pts, int F, int NS, int NPOLY, int NBLK, int cnt_total,
+                                 const double* planes, const int* blk_sweep, const int* blk_first,
+                                 const int* sweep_row0, const int* poly0, const int* filt, const int* cnt_off,
+                                 const int* cnt, const int* split, float* out, int Fo, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Per-detection image preparation: crop with zero padding -> antialiased bilinear

@@ -96,6 +96,8 @@ SIGNATURES = {
     'mmmot_points_count': [c_f, c_i, c_i, c_f, c_i, c_i, c_f, c_f, c_f],
     'mmmot_points_scatter': [c_f, c_i, c_i, c_f, c_i, c_f, c_f, c_f, c_i, c_f],
     'mmmot_crop_resize_norm': [c_f, c_i, c_i, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f],
+    'mmmot_points_count_batched': [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_f, c_f],
+    'mmmot_points_scatter_batched': [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f],
     'mmmot_selftest_mfma': [c_f, c_f, c_f, c_i, c_f],
 }
 

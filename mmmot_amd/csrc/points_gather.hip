@@ -153,3 +153,153 @@ extern "C" int mmmot_points_scatter(const float* pts, int P, int F, const double
   hipLaunchKernelGGL(pg_pad_kernel, dim3((NB + 63) / 64), dim3(64), 0, s, cnt + (long)NB * nblk, split, NB, out, Fo);
   return mm_check(hipGetLastError());
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Batched variant: many sweeps per launch, and the image-frustum filter fused into the per-box test (a point
+// is emitted for polygon j iff it is inside j AND inside its sweep's filter polygon - the same rows in the same
+// order as filtering first and gathering afterwards, without the intermediate array and its read-back).
+//   blk_sweep [NBLK] : sweep of every 256-point block       blk_first [NS] : first block of every sweep
+//   sweep_row0 [NS+1]: first point of every sweep            poly0 [NS+1]   : first polygon of every sweep
+//   filt [NS]        : index (into planes) of the sweep's filter polygon, or -1
+//   cnt_off [NPOLY]  : first counter of every polygon (its sweep's blocks), totals follow at cnt_total
+// A sweep may have at most PG_MAX_POLY polygons.
+struct PgBatch {
+  const float* pts;
+  const double* planes;
+  const int* blk_sweep;
+  const int* blk_first;
+  const int* sweep_row0;
+  const int* poly0;
+  const int* filt;
+  const int* cnt_off;
+  int F, NS, NPOLY, cnt_total;
+};
+
+__global__ __launch_bounds__(PG_THREADS) void pgb_count_kernel(PgBatch a, int* __restrict__ cnt) {
+  __shared__ double lpl[(PG_MAX_POLY + 1) * 24];
+  __shared__ int lcnt[PG_MAX_POLY];
+  const int s = a.blk_sweep[blockIdx.x];
+  const int b = blockIdx.x - a.blk_first[s];
+  const int p0 = a.poly0[s], np = a.poly0[s + 1] - p0, fi = a.filt[s];
+  for (int i = threadIdx.x; i < np * 24; i += PG_THREADS) lpl[i] = a.planes[(long)p0 * 24 + i];
+  if (fi >= 0 && threadIdx.x < 24) lpl[PG_MAX_POLY * 24 + threadIdx.x] = a.planes[(long)fi * 24 + threadIdx.x];
+  for (int j = threadIdx.x; j < np; j += PG_THREADS) lcnt[j] = 0;
+  __syncthreads();
+  const int i = a.sweep_row0[s] + b * PG_THREADS + threadIdx.x;
+  bool valid = i < a.sweep_row0[s + 1];
+  double x = 0, y = 0, z = 0;
+  if (valid) {
+    x = (double)a.pts[(long)i * a.F + 0];
+    y = (double)a.pts[(long)i * a.F + 1];
+    z = (double)a.pts[(long)i * a.F + 2];
+    if (fi >= 0) valid = pg_inside(x, y, z, &lpl[PG_MAX_POLY * 24]);
+  }
+  const int lane = threadIdx.x & 63;
+  for (int j = 0; j < np; ++j) {
+    const bool in = valid && pg_inside(x, y, z, &lpl[j * 24]);
+    const unsigned long long m = __ballot(in);
+    if (lane == 0 && m) atomicAdd(&lcnt[j], __popcll(m));
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < np; j += PG_THREADS) cnt[a.cnt_off[p0 + j] + b] = lcnt[j];
+}
+
+// per polygon: block counts -> exclusive offsets, total; then the global split over all polygons
+__global__ __launch_bounds__(1024) void pgb_scan_kernel(PgBatch a, int* __restrict__ cnt, int pad_empty,
+                                                        int* __restrict__ split) {
+  for (int j = threadIdx.x; j < a.NPOLY; j += 1024) {
+    int s = 0;  // sweep of polygon j (few sweeps: linear search)
+    while (a.poly0[s + 1] <= j) ++s;
+    const int nblk = (a.sweep_row0[s + 1] - a.sweep_row0[s] + PG_THREADS - 1) / PG_THREADS;
+    int* c = cnt + a.cnt_off[j];
+    int run = 0;
+    for (int b = 0; b < nblk; ++b) {
+      const int v = c[b];
+      c[b] = run;
+      run += v;
+    }
+    cnt[a.cnt_total + j] = run;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int j = 0; j < a.NPOLY; ++j) {
+      split[j] = run;
+      const int tot = cnt[a.cnt_total + j];
+      run += (tot == 0 && pad_empty) ? 1 : tot;
+    }
+    split[a.NPOLY] = run;
+  }
+}
+
+__global__ __launch_bounds__(PG_THREADS) void pgb_scatter_kernel(PgBatch a, const int* __restrict__ cnt,
+                                                                 const int* __restrict__ split, float* __restrict__ out,
+                                                                 int Fo) {
+  __shared__ double lpl[(PG_MAX_POLY + 1) * 24];
+  __shared__ int wcnt[PG_MAX_POLY][PG_THREADS / 64];
+  const int s = a.blk_sweep[blockIdx.x];
+  const int b = blockIdx.x - a.blk_first[s];
+  const int p0 = a.poly0[s], np = a.poly0[s + 1] - p0, fi = a.filt[s];
+  for (int i = threadIdx.x; i < np * 24; i += PG_THREADS) lpl[i] = a.planes[(long)p0 * 24 + i];
+  if (fi >= 0 && threadIdx.x < 24) lpl[PG_MAX_POLY * 24 + threadIdx.x] = a.planes[(long)fi * 24 + threadIdx.x];
+  __syncthreads();
+  const int i = a.sweep_row0[s] + b * PG_THREADS + threadIdx.x;
+  bool valid = i < a.sweep_row0[s + 1];
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (valid) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < a.F) v[c] = a.pts[(long)i * a.F + c];
+  }
+  const double x = (double)v[0], y = (double)v[1], z = (double)v[2];
+  if (valid && fi >= 0) valid = pg_inside(x, y, z, &lpl[PG_MAX_POLY * 24]);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int j = 0; j < np; ++j) {
+    const bool in = valid && pg_inside(x, y, z, &lpl[j * 24]);
+    const unsigned long long m = __ballot(in);
+    if (lane == 0) wcnt[j][wave] = __popcll(m);
+  }
+  __syncthreads();
+  for (int j = 0; j < np; ++j) {
+    const bool in = valid && pg_inside(x, y, z, &lpl[j * 24]);
+    const unsigned long long m = __ballot(in);
+    if (in) {
+      int pos = __popcll(m & ((1ull << lane) - 1ull));
+      for (int w = 0; w < wave; ++w) pos += wcnt[j][w];
+      float* o = out + ((long)split[p0 + j] + cnt[a.cnt_off[p0 + j] + b] + pos) * Fo;
+      o[0] = v[0];
+      o[1] = v[1];
+      o[2] = v[2];
+      if (Fo == 4) o[3] = v[3];
+    }
+  }
+}
+
+extern "C" int mmmot_points_count_batched(const float* pts, int F, int NS, int NPOLY, int NBLK, int cnt_total,
+                                          const double* planes, const int* blk_sweep, const int* blk_first,
+                                          const int* sweep_row0, const int* poly0, const int* filt,
+                                          const int* cnt_off, int pad_empty, int* cnt, int* split, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!pts || !planes || !blk_sweep || !blk_first || !sweep_row0 || !poly0 || !filt || !cnt_off || !cnt || !split)
+    return MMMOT_EINVAL;
+  if ((F != 3 && F != 4) || NS <= 0 || NPOLY <= 0 || NBLK <= 0) return MMMOT_EINVAL;
+  PgBatch a{pts, planes, blk_sweep, blk_first, sweep_row0, poly0, filt, cnt_off, F, NS, NPOLY, cnt_total};
+  hipLaunchKernelGGL(pgb_count_kernel, dim3(NBLK), dim3(PG_THREADS), 0, s, a, cnt);
+  hipLaunchKernelGGL(pgb_scan_kernel, dim3(1), dim3(1024), 0, s, a, cnt, pad_empty, split);
+  return mm_check(hipGetLastError());
+}
+
+extern "C" int mmmot_points_scatter_batched(const float* pts, int F, int NS, int NPOLY, int NBLK, int cnt_total,
+                                            const double* planes, const int* blk_sweep, const int* blk_first,
+                                            const int* sweep_row0, const int* poly0, const int* filt,
+                                            const int* cnt_off, const int* cnt, const int* split, float* out, int Fo,
+                                            void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!pts || !planes || !blk_sweep || !blk_first || !sweep_row0 || !poly0 || !filt || !cnt_off || !cnt || !split || !out)
+    return MMMOT_EINVAL;
+  if ((F != 3 && F != 4) || (Fo != 3 && Fo != F) || NS <= 0 || NPOLY <= 0 || NBLK <= 0) return MMMOT_EINVAL;
+  PgBatch a{pts, planes, blk_sweep, blk_first, sweep_row0, poly0, filt, cnt_off, F, NS, NPOLY, cnt_total};
+  hipLaunchKernelGGL(pgb_scatter_kernel, dim3(NBLK), dim3(PG_THREADS), 0, s, a, cnt, split, out, Fo);
+  hipLaunchKernelGGL(pg_pad_kernel, dim3((NPOLY + 63) / 64), dim3(64), 0, s, cnt + cnt_total, split, NPOLY, out, Fo);
+  return mm_check(hipGetLastError());
+}

@@ -143,3 +143,96 @@ def prep_points(points, info, dets, use_frustum=False, without_reflectivity=Fals
         planes = bbox_frustum_planes(boxes, rect, Trv2c, P2)
     rows, split = gather_points(kept, planes, pad_empty=True, drop_reflectivity=without_reflectivity)
     return {'points': rows, 'points_split': split.tolist()}
+
+
+# ---- batched: many sweeps per launch, image-frustum filter fused into the per-box test -----------------------
+def gather_points_batched(points, sweep_rows, planes, poly_counts, filters=None, pad_empty=True,
+                          drop_reflectivity=False):
+    """points: device fp32 [sum P_s, F] (the sweeps concatenated); sweep_rows: NS + 1 row offsets;
+    planes: float64 [NPOLY(+filters), 6, 4]; poly_counts: polygons per sweep (they are consecutive in ``planes``,
+    at most 256 per sweep); filters: per sweep the index in ``planes`` of a polygon that must also contain every
+    emitted point, or -1.  Returns (rows [Q, Fo] device, split int64 [NPOLY + 1]) with the polygons of all sweeps
+    in order - ONE split read-back for the whole batch."""
+    if not points.is_cuda:
+        raise RuntimeError('gather_points_batched needs a device tensor; there is no CPU fallback')
+    lib = _lib.load()
+    points = points.contiguous()
+    F = int(points.shape[1])
+    Fo = 3 if (drop_reflectivity and F == 4) else F
+    sweep_rows = np.asarray(sweep_rows, dtype=np.int64)
+    NS = len(sweep_rows) - 1
+    poly_counts = np.asarray(poly_counts, dtype=np.int64)
+    if len(poly_counts) != NS or (poly_counts > MAX_POLY).any() or (poly_counts < 1).any():
+        raise ValueError('every sweep needs 1..%d polygons' % MAX_POLY)
+    poly0 = np.concatenate([[0], np.cumsum(poly_counts)])
+    NPOLY = int(poly0[-1])
+    filt = np.full(NS, -1, dtype=np.int64) if filters is None else np.asarray(filters, dtype=np.int64)
+    nblk = (np.diff(sweep_rows) + 255) // 256
+    if (nblk < 1).any():
+        raise ValueError('every sweep needs at least one point')
+    blk_first = np.concatenate([[0], np.cumsum(nblk)])
+    NBLK = int(blk_first[-1])
+    blk_sweep = np.repeat(np.arange(NS), nblk)
+    cnt_off = np.concatenate([[0], np.cumsum(np.repeat(nblk, poly_counts))])
+    cnt_total = int(cnt_off[-1])
+    dev = points.device
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+    d_blk_sweep, d_blk_first, d_rows, d_poly0, d_filt, d_off = (up(blk_sweep), up(blk_first[:-1]), up(sweep_rows),
+                                                                up(poly0), up(filt), up(cnt_off[:-1]))
+    pl = torch.as_tensor(np.ascontiguousarray(planes, dtype=np.float64)).to(dev)
+    cnt = torch.empty(cnt_total + NPOLY, dtype=torch.int32, device=dev)
+    split = torch.empty(NPOLY + 1, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    common = (_ptr(points), F, NS, NPOLY, NBLK, cnt_total, pl.data_ptr(), _iptr(d_blk_sweep), _iptr(d_blk_first),
+              _iptr(d_rows), _iptr(d_poly0), _iptr(d_filt), _iptr(d_off))
+    _lib.check(lib.mmmot_points_count_batched(*common, int(pad_empty), _iptr(cnt), _iptr(split), stream),
+               'mmmot_points_count_batched')
+    h_split = split.cpu().numpy().astype(np.int64)  # the one D2H of the batch
+    out = torch.empty(int(h_split[-1]), Fo, dtype=torch.float32, device=dev)
+    if h_split[-1] > 0:
+        _lib.check(lib.mmmot_points_scatter_batched(*common, _iptr(cnt), _iptr(split), _ptr(out), Fo, stream),
+                   'mmmot_points_scatter_batched')
+    return out, h_split
+
+
+def prep_points_batched(sweeps, infos, dets_list, use_frustum=False, without_reflectivity=False, det_type='3D',
+                        shift_bboxes=None):
+    """``read_and_prep_points`` for a batch of frames in one launch sequence: sweeps = list of device [P_s, F]
+    tensors (or one concatenated tensor plus row offsets as a tuple).  Returns one reference-style dict per frame
+    ({'points': device rows, 'points_split': list}); the rows of all frames live in one device buffer."""
+    if isinstance(sweeps, tuple):
+        points, rows = sweeps
+    else:
+        rows = np.concatenate([[0], np.cumsum([int(s.shape[0]) for s in sweeps])])
+        points = torch.cat(list(sweeps))
+    planes, counts, filt = [], [], []
+    base = 0
+    for i, (info, dets) in enumerate(zip(infos, dets_list)):
+        rect = np.asarray(info['calib/R0_rect']).astype(np.float32)
+        Trv2c = np.asarray(info['calib/Tr_velo_to_cam']).astype(np.float32)
+        P2 = np.asarray(info['calib/P2']).astype(np.float32)
+        if det_type == '3D' and not use_frustum:
+            boxes = np.concatenate([dets['location'], dets['dimensions'],
+                                    np.asarray(dets['rotation_y'])[..., np.newaxis]], axis=1).astype(np.float32)
+            pl = rbbox_planes(boxes, rect, Trv2c)
+        else:
+            sb = None if shift_bboxes is None else shift_bboxes[i]
+            pl = bbox_frustum_planes(np.asarray(sb if sb is not None else dets['bbox']).copy(), rect, Trv2c, P2)
+        planes.append(pl)
+        counts.append(pl.shape[0])
+        base += pl.shape[0]
+    # the image frustums follow the boxes in the plane table
+    for i, info in enumerate(infos):
+        rect = np.asarray(info['calib/R0_rect']).astype(np.float32)
+        Trv2c = np.asarray(info['calib/Tr_velo_to_cam']).astype(np.float32)
+        P2 = np.asarray(info['calib/P2']).astype(np.float32)
+        planes.append(image_frustum_planes(rect, Trv2c, P2, info['img_shape']))
+        filt.append(base + i)
+    out, split = gather_points_batched(points, rows, np.concatenate(planes), counts, filters=filt, pad_empty=True,
+                                       drop_reflectivity=without_reflectivity)
+    res, p0 = [], 0
+    for c in counts:
+        lo, hi = int(split[p0]), int(split[p0 + c])
+        res.append({'points': out[lo:hi], 'points_split': (split[p0:p0 + c + 1] - lo).tolist()})
+        p0 += c
+    return res

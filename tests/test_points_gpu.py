@@ -69,3 +69,32 @@ def test_gather_properties_at_one_million_points():
         assert bool((ids[1:] > ids[:-1]).all())                              # input order kept
         assert bool(inside[ids, j].all())                                    # only inside points
         assert torch.equal(r, pts[ids])                                      # rows copied verbatim
+
+
+def test_batched_gather_equals_per_frame_reference():
+    """All golden frames in ONE launch sequence (image frustum fused into the box test) == the reference's
+    two-stage result per frame, bit for bit."""
+    cases = [load(p) for p in GOLD if not bool(np.load(p)['use_frustum']) and str(np.load(p)['det_type']) == '3D']
+    assert len(cases) >= 2
+    sweeps = [torch.from_numpy(z['points']).cuda() for z, _, _, _ in cases]
+    res = PT.prep_points_batched(sweeps, [i for _, i, _, _ in cases], [d for _, _, d, _ in cases],
+                                 without_reflectivity=False)
+    for (z, info, dets, kw), r in zip(cases, res):
+        ref = z['ref_points'] if not kw['without_reflectivity'] else None
+        assert r['points_split'] == z['ref_split'].tolist()
+        got = r['points'].cpu().numpy()
+        if ref is not None:
+            assert np.array_equal(got, ref)
+        else:  # the fixture dropped the reflectivity column
+            assert np.array_equal(got[:, :3], z['ref_points'])
+
+
+def test_batched_gather_frustum_path_and_many_sweeps():
+    z, info, dets, kw = load([p for p in GOLD if 'frustum' in p][0])
+    n = 9
+    sweeps = [torch.from_numpy(z['points']).cuda() for _ in range(n)]
+    res = PT.prep_points_batched(sweeps, [info] * n, [dets] * n, use_frustum=True, without_reflectivity=True,
+                                 shift_bboxes=[dets['bbox']] * n)
+    for r in res:
+        assert r['points_split'] == z['ref_split'].tolist()
+        assert np.array_equal(r['points'].cpu().numpy(), z['ref_points'])
