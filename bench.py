@@ -66,6 +66,7 @@ def main():
     ap.add_argument('--pairs', type=int, default=4, help='frame pairs per step per GPU')
     ap.add_argument('--cpu-pairs', type=int, default=2, help='timed pairs of the CPU baseline (0 disables)')
     ap.add_argument('--no-gather', action='store_true')
+    ap.add_argument('--graph', action='store_true', help='capture the launch sequence of one step in a hipGraph and replay it')
     ap.add_argument('--trunk', default='f16x3', choices=['f16x3', 'f32'],
                     help="VGG trunk arithmetic: fp16 matrix cores with 3-term hi/lo split (fp32-class), or exact fp32 MFMA")
     args = ap.parse_args()
@@ -105,6 +106,18 @@ def main():
         return res
 
     for _ in range(args.warmup):
+        step()
+    if args.graph:
+        # the C-ABI entry points only launch (no allocation, no synchronisation): the whole step is capturable
+        eager_step = step
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            graph_res = eager_step()
+
+        def step():  # noqa: F811
+            graph.replay()
+            return graph_res
         step()
 
     def barrier():
@@ -154,7 +167,7 @@ def main():
     conv_ms = sum(a[0] for a in dom.values())
     conv_fl = sum(a[1] for a in dom.values())
     n_launch = sum(a[2] for a in dom.values())
-    achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0  # 0 with --graph: replays record no events
 
     # HBM/fabric bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process,
     # so the figure comes from the committed rocprofv3 --pmc passes of this same command (profiles/traffic.json).
@@ -179,7 +192,7 @@ def main():
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.trunk == 'f32' else 'f16x3', 'data': 'synthetic',
         'config': {'workload': '%s: Fusion %s, %s/%s, N=M=%d (%d crops of %dx%d), %d pts/det; %d pairs/step/GPU' % (
             args.workload, fusion, aff, sm, N, N + M, S, S, pts, B), 'pairs_per_step_per_gpu': B, 'trunk': args.trunk,
-            'parallelism': 'sample-sharded x%d, flat all_gather of scores' % world},
+            'parallelism': 'sample-sharded x%d, flat all_gather of scores' % world, 'hipgraph': bool(args.graph)},
         'roofline': {'bound': 'mfma', 'kernel': kname,
                      'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
                      'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_unit': 'bytes/launch (mean)',
