@@ -67,7 +67,7 @@ def main():
     ap.add_argument('--cpu-pairs', type=int, default=2, help='timed pairs of the CPU baseline (0 disables)')
     ap.add_argument('--no-gather', action='store_true')
     ap.add_argument('--graph', action='store_true', help='capture the launch sequence of one step in a hipGraph and replay it')
-    ap.add_argument('--trunk', default='f16x3', choices=['f16x3', 'f32'],
+    ap.add_argument('--trunk', default='f16x3', choices=['f16x3', 'f16q8', 'f32'],
                     help="VGG trunk arithmetic: fp16 matrix cores with 3-term hi/lo split (fp32-class), or exact fp32 MFMA")
     args = ap.parse_args()
 
@@ -159,6 +159,13 @@ def main():
         peak = PEAK_F16_MFMA_TFLOPS / 3.0
         peak_basis = ('%.0f TFLOP/s dense f16 MFMA / 3 MFMAs per algorithmic product (a_hi*w_hi + a_hi*w_lo + '
                       'a_lo*w_hi, fp32 accumulate)' % PEAK_F16_MFMA_TFLOPS)
+    elif args.trunk == 'f16q8':
+        dom = {li: a for li, a in per_layer.items() if li != 0}
+        kname = 'conv3x3_hl16_patch_kernel<Q8> (VGG16-BN trunk layers 2-13, 12 launches/step)'
+        peak = PEAK_F16_MFMA_TFLOPS / 2.0
+        peak_basis = ('%.0f TFLOP/s dense f16 MFMA / 2 f16-MFMA equivalents per algorithmic product (a_hi*w_hi on the '
+                      'f16 cores + both correction terms in one block-scaled fp8 K=64 MFMA at twice the f16 rate)'
+                      % PEAK_F16_MFMA_TFLOPS)
     else:
         dom = per_layer
         kname = 'conv3x3_kernel (VGG16-BN trunk, 13 launches/step)'
@@ -189,7 +196,7 @@ def main():
     out = {
         'metric': METRIC, 'value': round(value, 4), 'unit': 'frame-pairs/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.trunk == 'f32' else 'f16x3', 'data': 'synthetic',
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': args.trunk, 'data': 'synthetic',
         'config': {'workload': '%s: Fusion %s, %s/%s, N=M=%d (%d crops of %dx%d), %d pts/det; %d pairs/step/GPU' % (
             args.workload, fusion, aff, sm, N, N + M, S, S, pts, B), 'pairs_per_step_per_gpu': B, 'trunk': args.trunk,
             'parallelism': 'sample-sharded x%d, flat all_gather of scores' % world, 'hipgraph': bool(args.graph)},

@@ -120,6 +120,21 @@ int mmmot_conv3x3_bn_relu_hl16_patch(const void* in, const void* wp, const float
 int mmmot_conv1_fused_hl16(const float* crops, const void* w1, const float* bias1, float oscale1,
                            const void* w2, const float* bias2, float oscale2, void* out, int L, int H, int W,
                            void* stream);
+/* "hq8" arithmetic (opt-in trunk mode, same reference lines): the two correction terms of the hi/lo split run on
+ * the fp8 matrix cores (one block-scaled K=64 MFMA), 2 instead of 3 fp16-MFMA equivalents per product.
+ *   activation record per 32 channels (128 bytes, like hl16): [32 x fp16 hi | 32 x e4m3(a / 4) | 32 x e4m3((a - hi) * 512)]
+ *   weight record per 32 input channels: [32 x fp16 hi(w') | 32 x e4m3((w' - hi) * 32) | 32 x e4m3(hi / 64)], w' = w * 2^wshift
+ * e4m3 = OCP FP8 E4M3 (max 448).  Relative error of a product ~2^-15 instead of 2^-21 (hl16); end-to-end score
+ * error stays below the 1e-3 budget (tools/study_fp8_correction.py, tests/test_hq8_gpu.py).
+ * Cin % 32 == 0, Cout % 64 == 0, H and W even.  mmmot_hq8_pack/unpack convert n fp32 values (n % 32 == 0). */
+int mmmot_conv3x3_bn_relu_hq8(const void* in, const void* wp, const float* bias, void* out,
+                              int L, int H, int W, int Cin, int Cout, int pool, float oscale, void* stream);
+/* mmmot_conv1_fused_hl16 with conv1_2 in hq8 arithmetic: w1 stays hl16, w2 is hq8 [9][64][64], out is hq8 */
+int mmmot_conv1_fused_hq8(const float* crops, const void* w1, const float* bias1, float oscale1,
+                          const void* w2, const float* bias2, float oscale2, void* out, int L, int H, int W,
+                          void* stream);
+int mmmot_hq8_pack(const float* x, void* y, long n, void* stream);
+int mmmot_hq8_unpack(const void* x, float* y, long n, void* stream);
 int mmmot_set_patch_variant(int v); /* timing experiments of the patch kernel (0 = product; 1..4 give WRONG results) */
 int mmmot_set_dma_variant(int v); /* tuning / experiment knob of the LDS-DMA kernel (0 = default) */
 int mmmot_conv3x3_first_hl16(const float* in, const float* wp, const float* bias, void* out,
@@ -255,7 +270,7 @@ int mmmot_segment_mean(const float* X, int ldx, int C,
                        const int* seg_group, const int* seg_div, int nseg,
                        const float* sc, const float* sh, int ldsc, int relu,
                        float* out, int ldo,
-                       int hl16 /* 1: X rows are in the hl16 split-half format (see below) */,
+                       int hl16 /* 1: X rows are in the hl16 split-half format, 2: hq8 records (C % 32 == 0) */,
                        void* stream);
 
 /* out[omap ? omap[r] : r] = post(act(sum_k f(X[r][k])*w[k] + b)),

@@ -78,6 +78,8 @@ SIGNATURES = {
     'mmmot_conv3x3_bn_relu_hl16_dma': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, c_f],
     'mmmot_conv3x3_bn_relu_hl16_patch': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, c_f],
     'mmmot_conv1_fused_hl16': [c_f, c_f, c_f, ctypes.c_float, c_f, c_f, ctypes.c_float, c_f, c_i, c_i, c_i, c_f],
+    'mmmot_conv3x3_bn_relu_hq8': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, c_f],
+    'mmmot_conv1_fused_hq8': [c_f, c_f, c_f, ctypes.c_float, c_f, c_f, ctypes.c_float, c_f, c_i, c_i, c_i, c_f],
     'mmmot_conv3x3_first_hl16': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
     'mmmot_set_conv_variant': [c_i],
     'mmmot_set_dma_variant': [c_i],
@@ -85,6 +87,8 @@ SIGNATURES = {
     'mmmot_debug_read_phase_timers': [ctypes.POINTER(ctypes.c_ulonglong), c_i],
     'mmmot_hl16_pack': [c_f, c_f, ctypes.c_long, c_f],
     'mmmot_hl16_unpack': [c_f, c_f, ctypes.c_long, c_f],
+    'mmmot_hq8_pack': [c_f, c_f, ctypes.c_long, c_f],
+    'mmmot_hq8_unpack': [c_f, c_f, ctypes.c_long, c_f],
     'mmmot_rowdot': [c_f, c_i, c_i, c_f, ctypes.c_float, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i,
                      ctypes.c_float, c_f, c_f, c_f],
     'mmmot_row_layernorm': [c_f, c_i, c_i, c_f, c_f, ctypes.c_float, c_i, c_f, c_i, c_i, c_f],

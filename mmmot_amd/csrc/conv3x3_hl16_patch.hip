@@ -44,6 +44,35 @@ __device__ __forceinline__ void pt_split8(f32x8 v, u32x4& hi, u32x4& lo) {
   lo = __builtin_bit_cast(u32x4, l);
 }
 
+// hq8 encode of 16 consecutive channels: fp16 hi (two 16-byte pieces), e4m3(a * 2^-2), e4m3((a - hi) * 2^9)
+__device__ __forceinline__ void pt_encode_q8(const float (&v)[16], u32x4& hi0, u32x4& hi1, u32x4& a8, u32x4& l8) {
+  f16x8 h0, h1;
+  float lo[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const float x = fminf(fmaxf(v[e], -65000.f), 65000.f);
+    const _Float16 hh = (_Float16)x;
+    if (e < 8) h0[e] = hh; else h1[e - 8] = hh;
+    lo[e] = __builtin_amdgcn_fmed3f((x - (float)hh) * 512.f, -448.f, 448.f);  // saturates for |x| > 1792 like the a / 4 copy
+  }
+  hi0 = __builtin_bit_cast(u32x4, h0);
+  hi1 = __builtin_bit_cast(u32x4, h1);
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    int pa = 0, pl = 0;
+    const float a0 = __builtin_amdgcn_fmed3f(v[4 * w + 0] * 0.25f, -448.f, 448.f);
+    const float a1 = __builtin_amdgcn_fmed3f(v[4 * w + 1] * 0.25f, -448.f, 448.f);
+    const float a2 = __builtin_amdgcn_fmed3f(v[4 * w + 2] * 0.25f, -448.f, 448.f);
+    const float a3 = __builtin_amdgcn_fmed3f(v[4 * w + 3] * 0.25f, -448.f, 448.f);
+    pa = __builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, pa, false);
+    pa = __builtin_amdgcn_cvt_pk_fp8_f32(a2, a3, pa, true);
+    pl = __builtin_amdgcn_cvt_pk_fp8_f32(lo[4 * w + 0], lo[4 * w + 1], pl, false);
+    pl = __builtin_amdgcn_cvt_pk_fp8_f32(lo[4 * w + 2], lo[4 * w + 3], pl, true);
+    a8[w] = (unsigned)pa;
+    l8[w] = (unsigned)pl;
+  }
+}
+
 __device__ __forceinline__ int pt_swz_b(int r) { return (r >> 1) & 7; }
 __device__ __forceinline__ int pt_swz_a(int py, int px) { return ((px >> 1) + 4 * (py & 1)) & 7; }
 
@@ -101,7 +130,18 @@ struct Fuse1Args {
   float oscale1;       // 2^-shift
 };
 
-template <int BN, int BS, bool POOL, int EXP, bool FUSE1 = false>
+// Q8 ("hq8" arithmetic and storage): the two CORRECTION terms of the hi/lo split run on the fp8 matrix cores.
+// A 32-channel record keeps its 128 bytes but holds [32 x fp16 hi | 32 x e4m3(a * 2^-2) | 32 x e4m3(a_lo * 2^9)]
+// (weights: [fp16 w_hi | e4m3(w_lo * 2^5) | e4m3(w_hi * 2^-6)]); per stage and product: two f16 MFMAs (hi*hi,
+// K = 2 x 16) + ONE v_mfma_scale_f32_32x32x64_f8f6f4 whose 64 k-slots are [a8 . w_lo8 | a_lo8 . w8] with the
+// block scale 2^-3 - 2 instead of 3 f16-MFMA-equivalents per product.  Pieces stay 16 bytes, so loaders, DMA ring
+// and swizzles are unchanged.  Accuracy: tools/study_fp8_correction.py.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+#define Q8_ASHIFT 2      // fp8 copies of activations carry 2^-2 (range up to 1792)
+#define Q8_SCALE_A 124   // E8M0 exponent of the block scale 2^-3 = 2^-11 (lo) * 2^2 (activation copies) * 2^6 (weight copies)
+#define Q8_SCALE_B 127
+
+template <int BN, int BS, bool POOL, int EXP, bool FUSE1 = false, bool Q8 = false>
 __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     const u32x4* __restrict__ in, const u32x4* __restrict__ wp, const float* __restrict__ bias,
     u32x4* __restrict__ out, int L, int H, int W, int Cin, int Cout, int nby, int nbx, int nblk, int ntm, int ntn,
@@ -285,21 +325,24 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     pt_row_to_pixel<BS>(wm * TM + tm, lr, blk, y, x);
     a_base[tm] = (blk * G::PP + y * G::PW + x) * P_ROWB;
 #pragma unroll
-    for (int tx = 0; tx < 3; ++tx) a_sx[tm][tx] = (pt_swz_a(y, x + tx) ^ (2 * h)) << 4;
+    for (int tx = 0; tx < 3; ++tx) a_sx[tm][tx] = (pt_swz_a(y, x + tx) ^ (Q8 ? h : 2 * h)) << 4;  // Q8: fp16 piece 2j+h
   }
   int b_off[TN];  // weight row record + swizzled piece of k-step 0 (k-step 1: ^ 64)
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int r = wn * TN * 32 + tn * 32 + lr;
-    b_off[tn] = r * P_ROWB + (((2 * h) ^ pt_swz_b(r)) << 4);
+    b_off[tn] = r * P_ROWB + ((((Q8 ? h : 2 * h)) ^ pt_swz_b(r)) << 4);
   }
 
   using I0 = std::integral_constant<int, 0>;
   struct Frags {
-    f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+    f16x8 ah[TM], al[TM], bh[TN], bl[TN];  // Q8: ah/al = fp16 hi of k-step 0/1 (same for b); a8/b8 = fp8 operands
+    i32x8 a8[TM], b8[TN];
   };
   constexpr int NPROD = TM * TN;          // products per 16-channel step: 4 / 2
   constexpr int NMMA = 3 * NPROD;         // MFMAs per half stage: 12 / 6
+  constexpr int NMMA1 = Q8 ? 2 * NPROD : NMMA;  // Q8: first half = the fp16 hi*hi MFMAs of both k-steps
+  constexpr int NMMA2 = Q8 ? NPROD : NMMA;      //     second half = one K=64 fp8 MFMA per product
   constexpr int NRD = 2 * TM + 2 * TN;    // ds_read_b128 per half stage: 8 / 6
   // one fragment read: r < 2*TM -> activation row block r/2 (hi, lo); else weight row block (hi, lo)
   auto read_one = [&](Frags& f, auto RC, auto TAPC, auto JC, int pb) {
@@ -310,7 +353,34 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     if constexpr (EXP == 3) {
       if (pb != 0) return;  // only the prologue read (pb == 0) fills the fragments
     }
-    if constexpr (r < 2 * TM) {
+    if constexpr (Q8) {
+      // JC = 0: fp16 fragments of both k-steps (piece 2*js + h); JC = 1: fp8 operands (pieces 4 + 2h + q)
+      constexpr int sel = r % 2;  // k-step (fp16) or 16-byte half q of the 32-byte fp8 fragment
+      if constexpr (r < 2 * TM) {
+        constexpr int tm = r / 2;
+        const int rec = pb + a_base[tm] + (ty * G::PW + tx) * P_ROWB;
+        const int sxo = a_sx[tm][tx] ^ (64 * (ty & 1));
+        if constexpr (j == 0) {
+          const f16x8 v = *reinterpret_cast<const f16x8*>(smem + rec + (sxo ^ (32 * sel)));
+          if constexpr (sel == 0) f.ah[tm] = v; else f.al[tm] = v;
+        } else {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(smem + rec + (sxo ^ 64 ^ ((h ^ (2 * h)) << 4) ^ (16 * sel)));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) f.a8[tm][4 * sel + e] = (int)v[e];
+        }
+      } else {
+        constexpr int tn = (r - 2 * TM) / 2;
+        constexpr int sb = RING0 + (tap % 3) * B_BYTES;
+        if constexpr (j == 0) {
+          const f16x8 v = *reinterpret_cast<const f16x8*>(smem + (b_off[tn] ^ (32 * sel)) + sb);
+          if constexpr (sel == 0) f.bh[tn] = v; else f.bl[tn] = v;
+        } else {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(smem + (b_off[tn] ^ 64 ^ ((h ^ (2 * h)) << 4) ^ (16 * sel)) + sb);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) f.b8[tn][4 * sel + e] = (int)v[e];
+        }
+      }
+    } else if constexpr (r < 2 * TM) {
       constexpr int tm = r / 2;
       // record offsets are multiples of 128 and the swizzled piece offset is < 128: xor 16 flips hi <-> lo
       const int rec = pb + a_base[tm];
@@ -328,12 +398,23 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   };
   // one MFMA of a half stage, term-major so that consecutive MFMAs hit different accumulators:
   // i -> term i / NPROD (lo*hi, hi*lo, hi*hi), product i % NPROD
-  auto mma_one = [&](const Frags& f, auto IC) {
+  auto mma_one = [&](const Frags& f, auto IC, auto HALFC) {
     constexpr int i = decltype(IC)::value;
+    constexpr int half = decltype(HALFC)::value;
     if constexpr (EXP == 4) return;
     constexpr int term = i / NPROD, p = i % NPROD;
     constexpr int tm = p / TN, tn = p % TN;
-    if constexpr (term == 0)
+    if constexpr (Q8) {
+      if constexpr (half == 0) {  // fp16 hi*hi, k-step = term (0 / 1)
+        if constexpr (term == 0)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[tm], f.bh[tn], acc[tm][tn], 0, 0, 0);
+        else
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[tm], f.bl[tn], acc[tm][tn], 0, 0, 0);
+      } else {                    // fp8 correction: K = 64 = [a8 . w_lo8 | a_lo8 . w8], block scale 2^-3
+        acc[tm][tn] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(f.a8[tm], f.b8[tn], acc[tm][tn], 0, 0, 0,
+                                                                      Q8_SCALE_A, 0, Q8_SCALE_B);
+      }
+    } else if constexpr (term == 0)
       acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[tm], f.bh[tn], acc[tm][tn], 0, 0, 0);
     else if constexpr (term == 1)
       acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[tm], f.bl[tn], acc[tm][tn], 0, 0, 0);
@@ -417,15 +498,34 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
           for (int q = 0; q < 4; ++q) {  // unit q of the slab: channels 8q + 4h .. + 3 are registers 4q .. 4q+3
             const f32x4 bq = *reinterpret_cast<const f32x4*>(&B1[nt1 * 32 + 8 * q + 4 * h]);
             f16x4 hi, lo;
+            float vv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               float v = fminf(fmaxf(fmaf(c1[nt1][4 * q + r], fz.oscale1, bq[r]), 0.f), 65000.f);
               if (!inimg) v = 0.f;
+              vv[r] = v;
               hi[r] = (_Float16)v;
               lo[r] = (_Float16)(v - (float)hi[r]);
             }
-            *reinterpret_cast<f16x4*>(smem + pb + (((2 * q) ^ sw) << 4)) = hi;
-            *reinterpret_cast<f16x4*>(smem + pb + (((2 * q + 1) ^ sw) << 4)) = lo;
+            if constexpr (Q8) {
+              // record = [fp16 hi: pieces 0..3 | e4m3(a/4): pieces 4,5 | e4m3(a_lo*512): pieces 6,7]
+              const int rb = (nt1 == 0 ? pcur : pnext) + n * P_ROWB;
+              *reinterpret_cast<f16x4*>(smem + rb + ((q ^ sw) << 4) + 8 * h) = hi;
+              int pa = 0, pl = 0;
+              pa = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(vv[0] * 0.25f, 448.f), fminf(vv[1] * 0.25f, 448.f), pa, false);
+              pa = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(vv[2] * 0.25f, 448.f), fminf(vv[3] * 0.25f, 448.f), pa, true);
+              float ll[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) ll[r] = __builtin_amdgcn_fmed3f((vv[r] - (float)hi[r]) * 512.f, -448.f, 448.f);
+              pl = __builtin_amdgcn_cvt_pk_fp8_f32(ll[0], ll[1], pl, false);
+              pl = __builtin_amdgcn_cvt_pk_fp8_f32(ll[2], ll[3], pl, true);
+              const int bo = 8 * (q & 1) + 4 * h;  // byte of channel 8q + 4h inside its 16-channel piece
+              *reinterpret_cast<int*>(smem + rb + (((4 + (q >> 1)) ^ sw) << 4) + bo) = pa;
+              *reinterpret_cast<int*>(smem + rb + (((6 + (q >> 1)) ^ sw) << 4) + bo) = pl;
+            } else {
+              *reinterpret_cast<f16x4*>(smem + pb + (((2 * q) ^ sw) << 4)) = hi;
+              *reinterpret_cast<f16x4*>(smem + pb + (((2 * q + 1) ^ sw) << 4)) = lo;
+            }
           }
         }
       }
@@ -467,8 +567,8 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     // first half: MFMAs of the first 16-channel step, fragments of the second step read underneath
     auto half1 = [&](auto IC) {
       constexpr int i = decltype(IC)::value;
-      if constexpr (i < NMMA) {
-        mma_one(f0, IC);
+      if constexpr (i < NMMA1) {
+        mma_one(f0, IC, I0{});
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (i < NRD) {
@@ -497,8 +597,8 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     // loads (patch round first, then the weights of stage t+3) issued at three spread-out points
     auto half2 = [&](auto IC) {
       constexpr int i = decltype(IC)::value;
-      if constexpr (i < NMMA) {
-        mma_one(f1, IC);
+      if constexpr (i < NMMA2) {
+        mma_one(f1, IC, std::integral_constant<int, 1>{});
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (i < NRD) {
@@ -507,7 +607,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (EXP != 1) {
-        constexpr int at_patch = (NMMA >= 12) ? 2 : 1, at_b0 = (NMMA >= 12) ? 6 : 4, at_b1 = 10;
+        constexpr int at_patch = (BN == 128) ? 2 : 1, at_b0 = (BN == 128) ? 6 : 4, at_b1 = 10;
         if constexpr (i == at_patch) {
           if constexpr (!FUSE1 && !last && tap < G::PA) issue_patch_round(TAPC, slab + 1, pnext);
           __builtin_amdgcn_sched_barrier(0);
@@ -568,6 +668,15 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   constexpr int RSTEP = 512 / UN;  // 32 / 64
   const int eu = tid % UN, er0 = tid / UN;
   const f32x8 bv = *reinterpret_cast<const f32x8*>(&bias[n0 + eu * 8]);
+  // Q8: thread -> 16 channels (hi = two pieces, fp8 copies = one piece each: 4 stores of 16 bytes per 16 channels)
+  constexpr int UN16 = BN / 16;
+  constexpr int RSTEP16 = 512 / UN16;  // 64 / 128
+  const int eu16 = tid % UN16, er16 = tid / UN16;
+  float bq[16];
+  if constexpr (Q8) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) bq[e] = bias[n0 + eu16 * 16 + e];
+  }
   // blocks of this tile: validity and first pixel (block-local (0,0)) of each
   int bcrop[G::NB], bgy0[G::NB], bgx0[G::NB];
 #pragma unroll
@@ -592,7 +701,59 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
       for (int e = 0; e < 16; ++e)
         Cs[((wm * TM + tm) * 32 + mm_acc_row(e, lane)) * CLD + wn * TN * 32 + tn * 32 + lr] = acc[tm][tn][e];
   __syncthreads();
-  if constexpr (POOL) {
+  if constexpr (Q8) {
+    const int Hq = H >> 1, Wq = W >> 1;
+    constexpr int NITEM = POOL ? P_BM / 4 : P_BM;  // quads or rows
+#pragma unroll
+    for (int i = 0; i < (NITEM + RSTEP16 - 1) / RSTEP16; ++i) {
+      const int it = er16 + i * RSTEP16;
+      if (it < NITEM) {
+        int blk, y, x;
+        if constexpr (POOL) pt_row_to_pixel<BS>(it >> 3, (it & 7) * 4, blk, y, x);
+        else pt_row_to_pixel<BS>(it >> 5, it & 31, blk, y, x);
+        int crop = bcrop[0], gy = bgy0[0] + y, gx = bgx0[0] + x;
+#pragma unroll
+        for (int k = 1; k < G::NB; ++k)
+          if (blk == k) {
+            crop = bcrop[k];
+            gy = bgy0[k] + y;
+            gx = bgx0[k] + x;
+          }
+        if (crop >= 0 && gy < H && gx < W) {
+          float v[16];
+          const float* c = &Cs[(POOL ? it * 4 : it) * CLD + eu16 * 16];
+#pragma unroll
+          for (int e = 0; e < 16; e += 4) {
+            f32x4 w4 = *reinterpret_cast<const f32x4*>(c + e);
+            if constexpr (POOL) {
+#pragma unroll
+              for (int r = 1; r < 4; ++r) {
+                const f32x4 o4 = *reinterpret_cast<const f32x4*>(c + r * CLD + e);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w4[k] = fmaxf(w4[k], o4[k]);
+              }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[e + k] = fmaxf(fmaf(w4[k], oscale, bq[e + k]), 0.f);
+          }
+          u32x4 hi0, hi1, a8, l8;
+          pt_encode_q8(v, hi0, hi1, a8, l8);
+          const long pix = POOL ? ((long)crop * Hq + (gy >> 1)) * Wq + (gx >> 1) : ((long)crop * H + gy) * W + gx;
+          const int c0 = n0 + eu16 * 16;  // first channel: 32-channel block c0 >> 5, 16-channel half (c0 >> 4) & 1
+          u32x4* o = out + (pix * cout8 * 2) + (c0 >> 5) * 8;
+          const int hf = (c0 >> 4) & 1;
+          if constexpr (EXP != 6) {
+            o[2 * hf] = hi0;
+            o[2 * hf + 1] = hi1;
+            o[4 + hf] = a8;
+            o[6 + hf] = l8;
+          } else if (hi0[0] == 0x12345678u && l8[1] == 0x9abcdef0u) {
+            o[0] = hi0;
+          }
+        }
+      }
+    }
+  } else if constexpr (POOL) {
     const int Hq = H >> 1, Wq = W >> 1;
 #pragma unroll
     for (int i = 0; i < (P_BM / 4) / RSTEP; ++i) {
@@ -673,7 +834,7 @@ extern "C" int mmmot_set_patch_variant(int v) {
   return MMMOT_OK;
 }
 
-template <int BN, int BS, bool POOL, int EXP, bool FUSE1 = false>
+template <int BN, int BS, bool POOL, int EXP, bool FUSE1 = false, bool Q8 = false>
 static int launch_patch_e(const void* in, const void* wp, const float* bias, void* out, int L, int H, int W, int Cin,
                         int Cout, float oscale, hipStream_t s, Fuse1Args fz = Fuse1Args{nullptr, nullptr, nullptr, 1.f}) {
   const int nby = (H + BS - 1) / BS, nbx = (W + BS - 1) / BS;
@@ -691,7 +852,7 @@ static int launch_patch_e(const void* in, const void* wp, const float* bias, voi
   const int nitems = ntm * ntn;
   int grid = (n_cu / 8) * 8;                       // one persistent workgroup per CU, whole XCDs
   if (grid > ((nitems + 7) / 8) * 8) grid = ((nitems + 7) / 8) * 8;
-  hipLaunchKernelGGL((conv3x3_hl16_patch_kernel<BN, BS, POOL, EXP, FUSE1>), dim3(grid), dim3(512), 0, s,
+  hipLaunchKernelGGL((conv3x3_hl16_patch_kernel<BN, BS, POOL, EXP, FUSE1, Q8>), dim3(grid), dim3(512), 0, s,
                      (const u32x4*)in, (const u32x4*)wp, bias, (u32x4*)out, L, H, W, Cin, Cout, nby, nbx, nblk, ntm, ntn,
                      oscale, fz);
   return mm_check(hipGetLastError());
@@ -747,4 +908,90 @@ extern "C" int mmmot_conv1_fused_hl16(const float* crops, const void* w1, const 
   if ((H & 1) || (W & 1) || !mm_al16(w1) || !mm_al16(w2) || !mm_al16(out)) return MMMOT_EINVAL;
   Fuse1Args fz{crops, (const u32x4*)w1, bias1, oscale1};
   return launch_patch_e<64, 16, true, 0, true>(nullptr, w2, bias2, out, L, H, W, 64, 64, oscale2, s, fz);
+}
+
+// ---- hq8 arithmetic: same contracts, activations / weights in the hq8 record format (see Q8 above) ----
+template <int BN, int BS>
+static int launch_q8_p(int pool, const void* in, const void* wp, const float* bias, void* out, int L, int H, int W,
+                       int Cin, int Cout, float oscale, hipStream_t s) {
+  return pool ? launch_patch_e<BN, BS, true, 0, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s)
+              : launch_patch_e<BN, BS, false, 0, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
+}
+
+extern "C" int mmmot_conv3x3_bn_relu_hq8(const void* in, const void* wp, const float* bias, void* out, int L, int H,
+                                         int W, int Cin, int Cout, int pool, float oscale, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!in || !wp || !bias || !out || L <= 0 || H <= 0 || W <= 0) return MMMOT_EINVAL;
+  if ((H & 1) || (W & 1) || Cin % 32 != 0 || Cout % 64 != 0) return MMMOT_EINVAL;
+  if (!mm_al16(in) || !mm_al16(wp) || !mm_al16(out)) return MMMOT_EINVAL;
+  if ((long)L * H * W * (Cin / 4) >= (1L << 31) - 64) return MMMOT_EINVAL;
+  const bool big = (H > 8 || W > 8);
+  if (Cout % 128 == 0)
+    return big ? launch_q8_p<128, 16>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s)
+               : launch_q8_p<128, 8>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
+  return big ? launch_q8_p<64, 16>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s)
+             : launch_q8_p<64, 8>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
+}
+
+extern "C" int mmmot_conv1_fused_hq8(const float* crops, const void* w1, const float* bias1, float oscale1,
+                                     const void* w2, const float* bias2, float oscale2, void* out, int L, int H,
+                                     int W, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!crops || !w1 || !bias1 || !w2 || !bias2 || !out || L <= 0 || H <= 0 || W <= 0) return MMMOT_EINVAL;
+  if ((H & 1) || (W & 1) || !mm_al16(w1) || !mm_al16(w2) || !mm_al16(out)) return MMMOT_EINVAL;
+  Fuse1Args fz{crops, (const u32x4*)w1, bias1, oscale1};
+  return launch_patch_e<64, 16, true, 0, true, true>(nullptr, w2, bias2, out, L, H, W, 64, 64, oscale2, s, fz);
+}
+
+// fp32 rows <-> hq8 rows (tests, tools; n % 32 == 0): one thread per 16 channels
+__global__ void hq8_pack_kernel(const float* __restrict__ x, u32x4* __restrict__ y, long n16) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n16) return;
+  float v[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) v[e] = x[i * 16 + e];
+  u32x4 hi0, hi1, a8, l8;
+  pt_encode_q8(v, hi0, hi1, a8, l8);
+  u32x4* o = y + (i >> 1) * 8;
+  const int hf = (int)(i & 1);
+  o[2 * hf] = hi0;
+  o[2 * hf + 1] = hi1;
+  o[4 + hf] = a8;
+  o[6 + hf] = l8;
+}
+
+__global__ void hq8_unpack_kernel(const u32x4* __restrict__ x, float* __restrict__ y, long n16) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n16) return;
+  const u32x4* r = x + (i >> 1) * 8;
+  const int hf = (int)(i & 1);
+  const f16x8 h0 = __builtin_bit_cast(f16x8, r[2 * hf]), h1 = __builtin_bit_cast(f16x8, r[2 * hf + 1]);
+  const u32x4 l8 = r[6 + hf];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const auto p0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)l8[w], false);
+    const auto p1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)l8[w], true);
+    const float lo[4] = {p0[0], p0[1], p1[0], p1[1]};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int e = 4 * w + k;
+      y[i * 16 + e] = (float)(e < 8 ? h0[e] : h1[e - 8]) + lo[k] * (1.f / 512.f);
+    }
+  }
+}
+
+extern "C" int mmmot_hq8_pack(const float* x, void* y, long n, void* stream) {
+  if (!x || !y || n <= 0 || n % 32 != 0 || !mm_al16(x) || !mm_al16(y)) return MMMOT_EINVAL;
+  const long nu = n / 16;
+  hipLaunchKernelGGL(hq8_pack_kernel, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     (u32x4*)y, nu);
+  return mm_check(hipGetLastError());
+}
+
+extern "C" int mmmot_hq8_unpack(const void* x, float* y, long n, void* stream) {
+  if (!x || !y || n <= 0 || n % 32 != 0 || !mm_al16(x) || !mm_al16(y)) return MMMOT_EINVAL;
+  const long nu = n / 16;
+  hipLaunchKernelGGL(hq8_unpack_kernel, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const u32x4*)x, y, nu);
+  return mm_check(hipGetLastError());
 }

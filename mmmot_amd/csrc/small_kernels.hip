@@ -156,7 +156,20 @@ __global__ __launch_bounds__(256) void segment_mean_kernel(
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
   auto ld = [&](int t) -> f32x4 {
     f32x4 v;
-    if (hl16) {
+    if (hl16 == 2) {
+      // hq8 row: 128-byte record per 32 channels = [32 x fp16 hi | 32 x e4m3 (unused here) | 32 x e4m3(lo * 2^9)]
+      const unsigned char* rec = reinterpret_cast<const unsigned char*>(X + ((long)start + (long)t * stride) * ldx) +
+                                 (c >> 5) * 128;
+      typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+      const f16x4 h = *reinterpret_cast<const f16x4*>(rec + 2 * (c & 31));
+      const int l = *reinterpret_cast<const int*>(rec + 96 + (c & 31));
+      const auto p0 = __builtin_amdgcn_cvt_pk_f32_fp8(l, false);
+      const auto p1 = __builtin_amdgcn_cvt_pk_f32_fp8(l, true);
+      v[0] = (float)h[0] + p0[0] * (1.f / 512.f);
+      v[1] = (float)h[1] + p0[1] * (1.f / 512.f);
+      v[2] = (float)h[2] + p1[0] * (1.f / 512.f);
+      v[3] = (float)h[3] + p1[1] * (1.f / 512.f);
+    } else if (hl16) {
       // hl16 row (same bytes as fp32): unit u = c>>3 holds [hi8 | lo8] halves; this lane's 4 channels
       const _Float16* rowp = reinterpret_cast<const _Float16*>(X + ((long)start + (long)t * stride) * ldx);
       typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -206,6 +219,8 @@ extern "C" int mmmot_segment_mean(const float* X, int ldx, int C, const int* seg
                                   int hl16, void* stream) {
   if (!X || !seg_start || !seg_count || !out || nseg <= 0 || C <= 0) return MMMOT_EINVAL;
   if (hl16 && (C % 8 != 0 || ldx % 8 != 0)) return MMMOT_EINVAL;
+  if (hl16 == 2 && (C % 32 != 0 || ldx % 32 != 0)) return MMMOT_EINVAL;
+  if (hl16 < 0 || hl16 > 2) return MMMOT_EINVAL;
   if (C % 4 != 0 || ldx % 4 != 0 || ldo % 4 != 0 || !mm_al16(X) || !mm_al16(out)) return MMMOT_EINVAL;
   if ((sc == nullptr) != (sh == nullptr)) return MMMOT_EINVAL;
   if (sc && (ldsc % 4 != 0 || !mm_al16(sc) || !mm_al16(sh))) return MMMOT_EINVAL;

@@ -24,8 +24,9 @@ EPS = 1e-5  # nn.GroupNorm / nn.BatchNorm default used everywhere in the referen
 class Engine:
     def __init__(self, packed, ops, fusion='A', affinity_op='multiply', softmax_mode='none',
                  neg_threshold=0.0, score_arch='branch_cls', end_mode='avg', trunk='f16x3'):
-        if trunk not in ('f16x3', 'f32'):
-            raise ValueError("trunk must be 'f16x3' (fp16 matrix cores, 3-term split) or 'f32' (exact fp32 MFMA)")
+        if trunk not in ('f16x3', 'f16q8', 'f32'):
+            raise ValueError("trunk must be 'f16x3' (fp16 matrix cores, 3-term split), 'f16q8' (fp16 main term + "
+                             "fp8 correction terms, include/mmmot_hip.h hq8) or 'f32' (exact fp32 MFMA)")
         self.trunk = trunk
         # machine mapping of the hl16 trunk layers (same arithmetic): 'patch' = LDS-resident haloed patch
         # (conv3x3_hl16_patch.hip, fastest), 'tile' = register-staged 128-row tiles, 'dma' = LDS-DMA ring
@@ -39,7 +40,7 @@ class Engine:
         self.pn_gram = os.environ.get('MMMOT_PN_GRAM', '1') != '0'
         # conv1_1 evaluated inside conv1_2's patch prologue (MMMOT_FUSE_CONV1=0: two launches)
         self.fuse_conv1 = os.environ.get('MMMOT_FUSE_CONV1', '1') != '0'
-        self.mlp = trunk  # the 1x1-conv / linear GEMMs follow the same arithmetic choice
+        self.mlp = 'f32' if trunk == 'f32' else 'f16x3'  # the 1x1-conv / linear GEMMs: exact fp32 only with the f32 trunk
         if affinity_op not in PAIR_OPS:
             raise ValueError('unknown affinity_op %r' % (affinity_op,))
         if softmax_mode not in SOFTMAX_MODES and softmax_mode != 'none':
@@ -105,10 +106,11 @@ class Engine:
         """crops [Lt,3,S,S] NCHW (reference contract) -> cat[:, 0:512]."""
         ops, Lt, S = self.ops, plan.Lt, plan.S
         x, H, W = crops, S, S
-        f16 = (self.trunk == 'f16x3')  # activations travel in the hl16 split-half format (same bytes)
+        q8 = (self.trunk == 'f16q8')   # activations travel as hq8 records (fp16 hi + two e4m3 copies, same bytes)
+        f16 = (self.trunk == 'f16x3') or q8  # activations travel in the hl16 split-half format (same bytes)
         vgg = self.P['vgg']
         # conv1_1 + conv1_2 + pool as one launch when the trunk has the VGG16 head (3 -> 64 -> 64, pool)
-        fuse1 = (f16 and self.conv_impl == 'patch' and self.fuse_conv1 and len(vgg) > 1 and vgg[0]['cout'] == 64 and
+        fuse1 = (f16 and (q8 or self.conv_impl == 'patch') and self.fuse_conv1 and len(vgg) > 1 and vgg[0]['cout'] == 64 and
                  vgg[1]['cin'] == 64 and vgg[1]['cout'] == 64 and vgg[1]['pool'] and not vgg[0]['last'] and
                  not vgg[0]['pool'] and H % 2 == 0 and W % 2 == 0)
         for li, cv in enumerate(vgg):
@@ -121,8 +123,18 @@ class Engine:
                 e0.record()
             if fuse1 and li == 1:
                 c0 = vgg[0]
-                ops.conv1_fused_hl16(x, c0['wp16'], c0['bias'], c0['oscale'], cv['wp16'], cv['bias'], cv['oscale'], out,
-                                     Lt, H, W)
+                if q8:
+                    ops.conv1_fused_hq8(x, c0['wp16'], c0['bias'], c0['oscale'], cv['wpq8'], cv['bias'], cv['oscale'],
+                                        out, Lt, H, W)
+                else:
+                    ops.conv1_fused_hl16(x, c0['wp16'], c0['bias'], c0['oscale'], cv['wp16'], cv['bias'],
+                                         cv['oscale'], out, Lt, H, W)
+            elif q8 and li == 0:  # unfused first layer: exact fp32 MFMA, then re-encoded
+                tmp = self.buf('vgg_first32', Lt * H * W, cv['cout'])
+                ops.conv3x3(x, cv['wp'], cv['bias'], tmp, Lt, H, W, cv['cin'], cv['cout'], True, cv['pool'])
+                ops.hq8_pack(tmp, out)
+            elif q8:
+                ops.conv3x3_hq8(x, cv['wpq8'], cv['bias'], out, Lt, H, W, cv['cin'], cv['cout'], cv['pool'], cv['oscale'])
             elif not f16:
                 ops.conv3x3(x, cv['wp'], cv['bias'], out, Lt, H, W, cv['cin'], cv['cout'], li == 0, cv['pool'])
             elif li == 0:
@@ -137,7 +149,7 @@ class Engine:
             x, H, W = out, Ho, Wo
             if cv['last']:
                 self._stash('vgg_stage%d' % cv['stage'], x)
-                self._skippool(plan, cv['stage'], x, H * W, cv['cout'], cat, hl16=f16)
+                self._skippool(plan, cv['stage'], x, H * W, cv['cout'], cat, hl16=2 if q8 else f16)
 
     def _skippool(self, plan, s, x, hw, C, cat, hl16=False):
         """reference modules/appear_net.py:9-32 for stage s -> cat[:, 128 s : 128 (s+1)]."""

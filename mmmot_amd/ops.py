@@ -85,6 +85,24 @@ class HipOps:
                                              _ptr(bias2), float(oscale2), _ptr(out), L, H, W, self._stream())
         _lib.check(st, 'mmmot_conv1_fused_hl16')
 
+    def conv3x3_hq8(self, inp, wp, bias, out, L, H, W, Cin, Cout, pool, oscale):
+        """conv3x3_hl16_patch in hq8 arithmetic: activations / weights are hq8 records (pack.to_hq8_act / to_hq8_w)."""
+        st = self.lib.mmmot_conv3x3_bn_relu_hq8(_ptr(inp), _ptr(wp), _ptr(bias), _ptr(out), L, H, W, Cin, Cout,
+                                                int(pool), float(oscale), self._stream())
+        _lib.check(st, 'mmmot_conv3x3_bn_relu_hq8')
+
+    def conv1_fused_hq8(self, crops, w1, bias1, oscale1, w2, bias2, oscale2, out, L, H, W):
+        """conv1_fused_hl16 with conv1_2 in hq8 arithmetic (w1 hl16, w2 hq8, out hq8)."""
+        st = self.lib.mmmot_conv1_fused_hq8(_ptr(crops), _ptr(w1), _ptr(bias1), float(oscale1), _ptr(w2),
+                                            _ptr(bias2), float(oscale2), _ptr(out), L, H, W, self._stream())
+        _lib.check(st, 'mmmot_conv1_fused_hq8')
+
+    def hq8_pack(self, x, y):
+        _lib.check(self.lib.mmmot_hq8_pack(_ptr(x), _ptr(y), x.numel(), self._stream()), 'mmmot_hq8_pack')
+
+    def hq8_unpack(self, x, y):
+        _lib.check(self.lib.mmmot_hq8_unpack(_ptr(x), _ptr(y), y.numel(), self._stream()), 'mmmot_hq8_unpack')
+
     def conv3x3_first_hl16(self, inp, wp, bias, out, L, H, W, Cout):
         st = self.lib.mmmot_conv3x3_first_hl16(_ptr(inp), _ptr(wp), _ptr(bias), _ptr(out), L, H, W, Cout,
                                                self._stream())

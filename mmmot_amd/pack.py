@@ -53,6 +53,52 @@ def from_hl16(y):
     return (u[..., 0, :] + u[..., 1, :]).reshape(*y.shape[:-1], C)
 
 
+def _e4m3(x):
+    """fp64 -> OCP FP8 E4M3 (saturating at +-448), returned as uint8 codes"""
+    return x.clamp(-448.0, 448.0).to(torch.float32).to(torch.float8_e4m3fn).view(torch.uint8)
+
+
+def _hq8_records(hi, p4, p6):
+    """hi fp16 [..., C], p4 / p6 uint8 e4m3 codes [..., C] -> fp32-typed [..., C] whose bytes are the hq8 records
+    of include/mmmot_hip.h: per 32 channels [32 x fp16 | 32 x e4m3 (p4) | 32 x e4m3 (p6)]"""
+    lead, C = hi.shape[:-1], hi.shape[-1]
+    assert C % 32 == 0
+    rec = torch.cat([hi.contiguous().view(torch.uint8).reshape(*lead, C // 32, 64), p4.reshape(*lead, C // 32, 32),
+                     p6.reshape(*lead, C // 32, 32)], dim=-1).contiguous()
+    return rec.view(torch.float32).reshape(*lead, C)
+
+
+def to_hq8_act(x):
+    """[..., C] activations -> hq8 records [fp16 hi | e4m3(x / 4) | e4m3((x - hi) * 512)] (C % 32 == 0)."""
+    x = x.detach().to('cpu', torch.float64).clamp(-65000.0, 65000.0)
+    hi = x.to(torch.float16)
+    return _hq8_records(hi, _e4m3(x * 0.25), _e4m3((x - hi.to(torch.float64)) * 512.0))
+
+
+def to_hq8_w(w):
+    """[..., Cin] weights ALREADY scaled by 2^shift (hl16_weight_shift) -> hq8 weight records
+    [fp16 hi | e4m3((w - hi) * 32) | e4m3(hi / 64)]."""
+    w = w.detach().to('cpu', torch.float64)
+    hi = w.to(torch.float16)
+    return _hq8_records(hi, _e4m3((w - hi.to(torch.float64)) * 32.0), _e4m3(hi.to(torch.float64) / 64.0))
+
+
+def hq8_parts(y):
+    """hq8 records (fp32-typed [..., C]) -> (hi, p4, p6) decoded to fp64 [..., C] (no scaling applied)"""
+    C = y.shape[-1]
+    rec = y.detach().cpu().contiguous().view(torch.uint8).reshape(*y.shape[:-1], C // 32, 128)
+    hi = rec[..., :64].contiguous().view(torch.float16).to(torch.float64).reshape(*y.shape[:-1], C)
+    p4 = rec[..., 64:96].contiguous().view(torch.float8_e4m3fn).to(torch.float32).to(torch.float64)
+    p6 = rec[..., 96:128].contiguous().view(torch.float8_e4m3fn).to(torch.float32).to(torch.float64)
+    return hi, p4.reshape(*y.shape[:-1], C), p6.reshape(*y.shape[:-1], C)
+
+
+def from_hq8_act(y):
+    """value a consumer of an hq8 activation tensor sees outside the convolutions: hi + e4m3 lo * 2^-9 (fp32)"""
+    hi, _, p6 = hq8_parts(y)
+    return (hi + p6 / 512.0).to(torch.float32)
+
+
 def hl16_weight_shift(w):
     """Power-of-two pre-scale that puts max|w| near 2^14 so the lo halves stay in fp16's normal range."""
     import math
@@ -127,6 +173,8 @@ def pack_weights(sd, fusion, device, eps=1e-5):
                     shift = hl16_weight_shift(wp)
                     cv['wp16'] = to_hl16(wp * (2.0 ** shift)).contiguous().to(device)
                     cv['oscale'] = 2.0 ** (-shift)
+                    if cin != 3:  # hq8 copy (opt-in trunk mode 'f16q8'), same 2^shift scaling
+                        cv['wpq8'] = to_hq8_w(wp * (2.0 ** shift)).contiguous().to(device)
                 convs.append(cv)
         P['vgg'] = convs
         heads = []

@@ -74,6 +74,40 @@ class TorchOps:
         self.conv3x3(crops, w1f, bias1, tmp, L, H, W, 3, 64, True, False)
         self.conv3x3_hl16(to_hl16(tmp), w2, bias2, out, L, H, W, 64, 64, True, oscale2)
 
+    def _conv_hq8(self, x, wp, bias, L, H, W, Cin, Cout, pool, oscale):
+        """the hq8 arithmetic: hi*hi + 2^-3 (a8 * w_lo8 + a_lo8 * w8), x = decoded parts (hi, a8, al8) NHWC"""
+        from mmmot_amd.pack import hq8_parts
+        wh, wl8, w8 = [t.reshape(3, 3, Cout, Cin).permute(2, 3, 0, 1).to(self.dtype) for t in hq8_parts(wp.reshape(9 * Cout, Cin))]
+        ah, a8, al8 = [t.reshape(L, H, W, Cin).permute(0, 3, 1, 2).to(self.dtype) for t in x]
+        cv = torch.nn.functional.conv2d
+        y = cv(ah, wh, None, padding=1) + 0.125 * (cv(a8, wl8, None, padding=1) + cv(al8, w8, None, padding=1))
+        y = torch.relu(y * oscale + bias.to(self.dtype).view(1, -1, 1, 1))
+        if pool:
+            y = torch.nn.functional.max_pool2d(y, 2, 2)
+        return y.permute(0, 2, 3, 1).reshape(-1, Cout)
+
+    def conv3x3_hq8(self, inp, wp, bias, out, L, H, W, Cin, Cout, pool, oscale):
+        from mmmot_amd.pack import hq8_parts, to_hq8_act
+        x = hq8_parts(inp.reshape(-1)[:L * H * W * Cin].view(L * H * W, Cin))
+        rows = self._conv_hq8(x, wp, bias, L, H, W, Cin, Cout, pool, oscale)
+        out.reshape(-1)[:rows.numel()].view(-1, Cout).copy_(to_hq8_act(rows))
+
+    def conv1_fused_hq8(self, crops, w1, bias1, oscale1, w2, bias2, oscale2, out, L, H, W):
+        from mmmot_amd.pack import from_hl16, hq8_parts, to_hq8_act
+        w1f = from_hl16(w1.reshape(64, 32)) * oscale1
+        tmp = torch.zeros(L * H * W, 64)
+        self.conv3x3(crops, w1f, bias1, tmp, L, H, W, 3, 64, True, False)
+        rows = self._conv_hq8(hq8_parts(to_hq8_act(tmp)), w2, bias2, L, H, W, 64, 64, True, oscale2)
+        out.reshape(-1)[:rows.numel()].view(-1, 64).copy_(to_hq8_act(rows))
+
+    def hq8_pack(self, x, y):
+        from mmmot_amd.pack import to_hq8_act
+        y.reshape(-1).copy_(to_hq8_act(x.reshape(-1, 32)).reshape(-1))
+
+    def hq8_unpack(self, x, y):
+        from mmmot_amd.pack import from_hq8_act
+        y.reshape(-1).copy_(from_hq8_act(x.reshape(-1, 32)).reshape(-1))
+
     def conv3x3_first_hl16(self, inp, wp, bias, out, L, H, W, Cout):
         from mmmot_amd.pack import to_hl16
         tmp = torch.zeros(L * H * W, Cout)
@@ -185,7 +219,10 @@ class TorchOps:
             sh[g, :C] = (beta.double() - s1.repeat_interleave(CG) * scv).float()
 
     def segment_mean(self, X, C, segs, out, sc=None, sh=None, relu=False, use_group=True, hl16=False):
-        if hl16:
+        if int(hl16) == 2:
+            from mmmot_amd.pack import from_hq8_act
+            X = from_hq8_act(X[:, :C].contiguous())
+        elif hl16:
             from mmmot_amd.pack import from_hl16
             X = from_hl16(X[:, :C].contiguous())
         for s in range(segs.n):
