@@ -67,7 +67,7 @@ def main():
     ap.add_argument('--cpu-pairs', type=int, default=2, help='timed pairs of the CPU baseline (0 disables)')
     ap.add_argument('--no-gather', action='store_true')
     ap.add_argument('--graph', action='store_true', help='capture the launch sequence of one step in a hipGraph and replay it')
-    ap.add_argument('--trunk', default='f16x3', choices=['f16x3', 'f16q8', 'f32'],
+    ap.add_argument('--trunk', default='f16q8', choices=['f16q8', 'f16x3', 'f32'],
                     help="VGG trunk arithmetic: fp16 matrix cores with 3-term hi/lo split (fp32-class), or exact fp32 MFMA")
     args = ap.parse_args()
 

@@ -914,6 +914,11 @@ extern "C" int mmmot_conv1_fused_hl16(const float* crops, const void* w1, const 
 template <int BN, int BS>
 static int launch_q8_p(int pool, const void* in, const void* wp, const float* bias, void* out, int L, int H, int W,
                        int Cin, int Cout, float oscale, hipStream_t s) {
+  if constexpr (BN == 128 && BS == 16) {  // timing experiments (wrong results), unpooled 128-channel tiles only
+    if (!pool && g_patch_exp == 3) return launch_patch_e<BN, BS, false, 3, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
+    if (!pool && g_patch_exp == 4) return launch_patch_e<BN, BS, false, 4, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
+    if (!pool && g_patch_exp == 6) return launch_patch_e<BN, BS, false, 6, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
+  }
   return pool ? launch_patch_e<BN, BS, true, 0, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s)
               : launch_patch_e<BN, BS, false, 0, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
 }

@@ -23,7 +23,8 @@ EPS = 1e-5  # nn.GroupNorm / nn.BatchNorm default used everywhere in the referen
 
 class Engine:
     def __init__(self, packed, ops, fusion='A', affinity_op='multiply', softmax_mode='none',
-                 neg_threshold=0.0, score_arch='branch_cls', end_mode='avg', trunk='f16x3'):
+                 neg_threshold=0.0, score_arch='branch_cls', end_mode='avg', trunk=None):
+        trunk = trunk or os.environ.get('MMMOT_TRUNK', 'f16q8')
         if trunk not in ('f16x3', 'f16q8', 'f32'):
             raise ValueError("trunk must be 'f16x3' (fp16 matrix cores, 3-term split), 'f16q8' (fp16 main term + "
                              "fp8 correction terms, include/mmmot_hip.h hq8) or 'f32' (exact fp32 MFMA)")

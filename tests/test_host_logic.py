@@ -14,12 +14,15 @@ from mmmot_amd.plan import BatchPlan, RowTiles
 from mmmot_amd.weights import gen_tensor
 
 
+@pytest.mark.parametrize('trunk,tol', [('f16q8', 5e-4), ('f16x3', 2e-4)])
 @pytest.mark.parametrize('name', case_names(light_only=True))
-def test_engine_schedule_matches_golden(name):
+def test_engine_schedule_matches_golden(name, trunk, tol):
+    """both trunk arithmetics (default f16q8: correction terms in e4m3; f16x3: fp32-class) through the emulated C-ABI"""
     c, base = get_case(name)
     m = build_model(c, base, ops=TorchOps())
+    m.set_trunk(trunk)
     out = m(*case_inputs(c))
-    compare_outputs(out, golden(name), tol=2e-4)
+    compare_outputs(out, golden(name), tol=tol)
 
 
 def test_batched_plan_equals_single_samples():
@@ -42,6 +45,7 @@ def test_batched_plan_equals_single_samples():
 def test_single_modality_rows():
     c, base = get_case('s2_C_multiply_none')
     m = build_model(c, base, ops=TorchOps())
+    m.set_trunk('f16x3')  # fp32-class arithmetic: the tolerance below checks the row logic, not the trunk
     dets, info, ds = case_inputs(c)
     g = golden(c['name'])
     out0 = m.forward_rows(dets, info, ds, rows=(0,))

@@ -21,8 +21,8 @@ def to_dev(ins):
 @pytest.mark.parametrize('trunk', ['f16x3', 'f32'])
 @pytest.mark.parametrize('name', case_names())
 def test_hip_forward_matches_reference_golden(name, trunk):
-    """trunk='f16x3': VGG on the fp16 matrix cores (3-term hi/lo split, the default);
-    trunk='f32': exact fp32 MFMA everywhere."""
+    """trunk='f16x3': VGG on the fp16 matrix cores (3-term hi/lo split); trunk='f32': exact fp32 MFMA everywhere;
+    the default 'f16q8' (correction terms on the fp8 cores) is covered by tests/test_hq8_gpu.py."""
     c, base = get_case(name)
     m = build_model(c, base, device=DEV)
     m.set_trunk(trunk)
@@ -49,8 +49,11 @@ def test_stage_checkpoints_match_golden():
     assert np.abs(F - g['feats']).max() < 5e-4
 
 
-def test_submodule_forwards_match_golden():
-    """The reference's module API, one module at a time (same names / argument meaning)."""
+@pytest.mark.parametrize('trunk,itol', [('f16q8', TOL), ('f16x3', 2e-4)])
+def test_submodule_forwards_match_golden(trunk, itol, monkeypatch):
+    """The reference's module API, one module at a time (same names / argument meaning).  The intermediate
+    features are held to a tighter tolerance than the outputs with the fp32-class trunk."""
+    monkeypatch.setenv('MMMOT_TRUNK', trunk)  # stand-alone sub-module engines read the process default
     c, base = get_case('s2_B_multiply_none')
     m = build_model(c, base, device=DEV)
     g = golden(c['name'])
@@ -61,9 +64,9 @@ def test_submodule_forwards_match_golden():
         feats = m.fusion_module(torch.cat([app, pts], dim=-1).t().unsqueeze(0))
         N = c['N']
         link, new, end = m.w_link(feats[:, :, :N].contiguous(), feats[:, :, N:].contiguous())
-    assert np.abs(app.cpu().numpy() - g['appearance']).max() < 2e-4
+    assert np.abs(app.cpu().numpy() - g['appearance']).max() < itol
     assert np.abs(pts.cpu().numpy() - g['point']).max() < 2e-4
-    assert np.abs(feats.cpu().numpy() - g['feats']).max() < 5e-4
+    assert np.abs(feats.cpu().numpy() - g['feats']).max() < 2.5 * itol
     assert np.abs(link.squeeze(1).cpu().numpy() - g['link0']).max() < TOL      # softmax_mode none: raw logits
     assert np.abs(new.cpu().numpy() - g['new'][:, N:]).max() < TOL
     assert np.abs(end.cpu().numpy() - g['end'][:, :N]).max() < TOL
@@ -164,6 +167,7 @@ def test_alternative_engine_paths_match_golden(name, knobs):
         pytest.skip('no such golden case')
     c, base = get_case(name)
     m = build_model(c, base, device=DEV)
+    m.set_trunk('f16x3')  # the knobs select machine mappings of the hl16 arithmetic
     eng = m.engine()
     for k, v in knobs.items():
         assert hasattr(eng, k)

@@ -14,7 +14,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mmmot_amd import _lib  # noqa: E402
 from mmmot_amd.ops import HipOps  # noqa: E402
-from mmmot_amd.pack import hl16_weight_shift, to_hl16  # noqa: E402
+from mmmot_amd.pack import hl16_weight_shift, to_hl16, to_hq8_w  # noqa: E402
 
 LAYERS = [  # (L, H, W, Cin, Cout, pool) at cfg3 (128 crops of 128x128)
     (128, 128, 128, 64, 64, 1), (128, 64, 64, 128, 128, 1), (128, 32, 32, 256, 256, 0), (128, 16, 16, 512, 512, 0),
@@ -26,7 +26,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--rounds', type=int, default=5)
     ap.add_argument('--crops', type=int, default=128, help='crops per launch (128 = one cfg3 pair)')
-    ap.add_argument('--variants', default='1,11', help='1 = 128-row tiles, 4 = 256-row tiles, 7..10 = LDS-DMA kernel variants 0..3, 11 = LDS-patch kernel, 12..17 = its timing experiments 1..6 (wrong results)')
+    ap.add_argument('--variants', default='1,11', help='1 = 128-row tiles, 4 = 256-row tiles, 7..10 = LDS-DMA kernel variants 0..3, 11 = LDS-patch kernel, 12..17 = its timing experiments 1..6 (wrong results), 21 = hq8 arithmetic (f16q8 trunk), 24/25/27 = its experiments 3/4/6')
     args = ap.parse_args()
     ops = HipOps()
     lib = _lib.load()
@@ -40,6 +40,8 @@ def main():
         w = torch.randn(9, Cout, Cin, generator=g) * (2.0 / (9 * Cin)) ** 0.5
         shift = hl16_weight_shift(w)
         w16 = to_hl16(w.double() * 2.0 ** shift).cuda()
+        xq8, wq8 = torch.empty_like(x), to_hq8_w(w.double() * 2.0 ** shift).cuda()
+        ops.hq8_pack(x, xq8)
         bias = torch.zeros(Cout).cuda()
         Ho, Wo = (H // 2, W // 2) if pool else (H, W)
         out = torch.empty(L * Ho * Wo, Cout).cuda()
@@ -52,7 +54,10 @@ def main():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 out.fill_(float('nan'))
                 e0.record()
-                if v >= 11:  # LDS-resident patch kernel (12..15: timing experiments, unpooled 128-channel tiles only)
+                if v >= 21:  # hq8 arithmetic of the patch kernel (different results by design)
+                    lib.mmmot_set_patch_variant(v - 21)
+                    ops.conv3x3_hq8(xq8, wq8, bias, out, L, H, W, Cin, Cout, bool(pool), 2.0 ** -shift)
+                elif v >= 11:  # LDS-resident patch kernel (12..15: timing experiments, unpooled 128-channel tiles only)
                     lib.mmmot_set_patch_variant(v - 11)
                     ops.conv3x3_hl16_patch(x16, w16, bias, out, L, H, W, Cin, Cout, bool(pool), 2.0 ** -shift)
                 elif v >= 7:  # LDS-DMA producer/consumer kernel (its own entry point)
@@ -65,7 +70,7 @@ def main():
                     if ref is None:
                         ref = out.clone()
                     else:
-                        if v == 10 or v >= 12:
+                        if v == 10 or v >= 12:  # (and the hq8 variants: other arithmetic)
                             pass  # ASKIP timing experiment: results are wrong by construction
                         elif v >= 7:  # different K order (32-channel slabs): fp32 rounding differs, values must not
                             a, b = torch.empty_like(out), torch.empty_like(out)
