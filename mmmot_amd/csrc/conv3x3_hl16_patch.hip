@@ -742,7 +742,13 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
           const int c0 = n0 + eu16 * 16;  // first channel: 32-channel block c0 >> 5, 16-channel half (c0 >> 4) & 1
           u32x4* o = out + (pix * cout8 * 2) + (c0 >> 5) * 8;
           const int hf = (c0 >> 4) & 1;
-          if constexpr (EXP != 6) {
+          if constexpr (EXP == 7) {  // timing experiment: same bytes, 128 contiguous bytes per row and instruction
+            u32x4* o7 = out + (pix * cout8 * 2) + (n0 >> 5) * 8 + eu16;
+            o7[0] = hi0;
+            o7[UN16] = hi1;
+            o7[2 * UN16] = a8;
+            o7[3 * UN16] = l8;
+          } else if constexpr (EXP != 6) {
             o[2 * hf] = hi0;
             o[2 * hf + 1] = hi1;
             o[4 + hf] = a8;
@@ -829,7 +835,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
 
 static int g_patch_exp = 0;
 extern "C" int mmmot_set_patch_variant(int v) {
-  if (v < 0 || v > 6) return MMMOT_EINVAL;
+  if (v < 0 || v > 7) return MMMOT_EINVAL;
   g_patch_exp = v;
   return MMMOT_OK;
 }
@@ -918,6 +924,7 @@ static int launch_q8_p(int pool, const void* in, const void* wp, const float* bi
     if (!pool && g_patch_exp == 3) return launch_patch_e<BN, BS, false, 3, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
     if (!pool && g_patch_exp == 4) return launch_patch_e<BN, BS, false, 4, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
     if (!pool && g_patch_exp == 6) return launch_patch_e<BN, BS, false, 6, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
+    if (!pool && g_patch_exp == 7) return launch_patch_e<BN, BS, false, 7, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
   }
   return pool ? launch_patch_e<BN, BS, true, 0, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s)
               : launch_patch_e<BN, BS, false, 0, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
