@@ -73,6 +73,16 @@ __device__ __forceinline__ void pt_encode_q8(const float (&v)[16], u32x4& hi0, u
   }
 }
 
+// EXP == 9: phase timestamps of thread 0 (shader clock), summed over items: [0] decode..loads issued, [1] prologue
+// wait, [2] K loop, [3] accumulators -> LDS, [4] encode + stores issued, [5] closing barrier, [7] items
+__device__ unsigned long long pt_dbg[8];
+#define PT_STAMP(i)                                                                  \
+  if constexpr (EXP == 9 || EXP == 10) {                                             \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();                    \
+    if (threadIdx.x == 0 && (i) >= 0) atomicAdd(&pt_dbg[(i) < 0 ? 0 : (i)], now_ - tprev_); \
+    tprev_ = now_;                                                                   \
+  }
+
 __device__ __forceinline__ int pt_swz_b(int r) { return (r >> 1) & 7; }
 __device__ __forceinline__ int pt_swz_a(int py, int px) { return ((px >> 1) + 4 * (py & 1)) & 7; }
 
@@ -231,9 +241,55 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
       rawv[k] = v;
     }
   };
+  // patch source offsets of one tile (16-byte units, without the slab term; ~0u = zero page).  Round k moves pieces
+  // [k*512 + wave*64, +64) (k < FULL) or, in the partial round, [FULL*512 + wave*RL, +RL); piece p = (patch pixel
+  // n = p >> 3, LDS slot c' = p & 7) holds the logical piece c' ^ swz_a(py, px) of that pixel's 128-byte slab
+  // record.  The block -> (crop, by, bx) divisions are wave-uniform (scalar unit); the table of the NEXT tile is
+  // computed while the slower waves still issue their stores, ahead of the closing barrier of the tile.
+  unsigned poff[G::PA];
+  auto compute_poff = [&](int mtile) {
+    const int nbpc_ = nby * nbx, cin16 = (Cin >> 3) * 2;
+    int kcrop[G::NB], kgy0[G::NB], kgx0[G::NB];
+#pragma unroll
+    for (int q = 0; q < G::NB; ++q) {
+      const int b = mtile * G::NB + q;  // uniform
+      const int crop = b / nbpc_, br = b - crop * nbpc_;
+      const int by = br / nbx;
+      kcrop[q] = (b < nblk) ? crop : -1;
+      kgy0[q] = by * BS - 1;
+      kgx0[q] = (br - by * nbx) * BS - 1;
+    }
+#pragma unroll
+    for (int k = 0; k < G::PA; ++k) {
+      const int p = (k < G::FULL) ? (k * 8 + wave) * 64 + lane : G::FULL * 512 + wave * G::RL + lane;
+      unsigned off = ~0u;
+      if (k < G::FULL || lane < G::RL) {
+        const int n = p >> 3, c = p & 7;
+        const int blk = n / G::PP;
+        const int rem = n - blk * G::PP;
+        const int py = rem / G::PW, px = rem - py * G::PW;
+        int crop = kcrop[0], gy = kgy0[0] + py, gx = kgx0[0] + px;
+#pragma unroll
+        for (int q = 1; q < G::NB; ++q)
+          if (blk == q) {
+            crop = kcrop[q];
+            gy = kgy0[q] + py;
+            gx = kgx0[q] + px;
+          }
+        if (crop >= 0 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+          off = (unsigned)(((crop * H + gy) * W + gx) * cin16 + (c ^ pt_swz_a(py, px)));
+      }
+      poff[k] = off;
+    }
+  };
+  int mt = 0, nt = 0;
+  if ((int)(blockIdx.x >> 3) < clen) {
+    decode_item(blockIdx.x >> 3, mt, nt);
+    if constexpr (!FUSE1) compute_poff(mt);
+  }
   for (int item = blockIdx.x >> 3; item < clen; item += gridDim.x >> 3) {
-  int mt, nt;
-  decode_item(item, mt, nt);
+  unsigned long long tprev_ = 0;
+  PT_STAMP(-1)
   const int n0 = nt * BN;
   const int cin8 = Cin >> 3;
   const int nslab = Cin >> 5;
@@ -254,26 +310,6 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   // patch: round k moves pieces [k*512 + wave*64, +64) (k < FULL) or, in the partial round,
   // [FULL*512 + wave*RL, +RL); piece p = (patch pixel n = p >> 3, LDS slot c' = p & 7) holds the
   // logical piece c' ^ swz_a(py, px) of that pixel's 128-byte slab record.
-  unsigned poff[G::PA];  // source offset in 16-byte units (without the slab term); ~0u = zero page
-#pragma unroll
-  for (int k = 0; k < G::PA; ++k) {
-    const int p = (k < G::FULL) ? (k * 8 + wave) * 64 + lane : G::FULL * 512 + wave * G::RL + lane;
-    unsigned off = ~0u;
-    if (k < G::FULL || lane < G::RL) {
-      const int n = p >> 3, c = p & 7;
-      const int blk = n / G::PP;
-      const int rem = n - blk * G::PP;
-      const int py = rem / G::PW, px = rem - py * G::PW;
-      const int b = mt * G::NB + blk;
-      const int crop = b / nbpc;
-      const int br = b - crop * nbpc;
-      const int by = br / nbx, bx = br - by * nbx;
-      const int gy = by * BS + py - 1, gx = bx * BS + px - 1;
-      if (b < nblk && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
-        off = (unsigned)(((crop * H + gy) * W + gx) * (cin8 * 2) + (c ^ pt_swz_a(py, px)));
-    }
-    poff[k] = off;
-  }
   const u32x4* zsrc = pt_zero_page + (lane & 15);
   // weights: instruction (wave * NBL + b) covers 8 rows of the tile; lane = (row in 8, slot in row)
   const int rsub = lane >> 3, slot8 = lane & 7;
@@ -459,7 +495,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     // mask) is done once per lane.  11 pixel tiles of 32: waves take g = wave, wave + 8. ----
     const float* B1 = reinterpret_cast<const float*>(smem + RAW_OFF + 4800);  // conv1_1 bias [64] (staged above)
 #pragma nounroll
-    for (int g = wave; g < 11; g += 8) {
+    for (int g = wave; g < (EXP == 8 ? 0 : 11); g += 8) {  // EXP 8: timing experiment without the conv1_1 prologue
       const int n = g * 32 + lr;  // this lane's patch pixel
       const int ppy = n / 18, ppx = n - ppy * 18;
       const int rbase = ppy * 20 + ppx;  // window position of tap (0,0)
@@ -543,8 +579,10 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     issue_b(0, 0, 0);
     issue_b(1, 0, 1);
     issue_b(2, 0, 2);
+    PT_STAMP(0)
     pt_wait_vm<2 * NBL>();  // patch + weight stage 0 landed (this wave's part)
     __builtin_amdgcn_s_barrier();
+    PT_STAMP(1)
   }
   Frags f0, f1;
   read_frags(f0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, pcur);
@@ -691,6 +729,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   }
   if constexpr (EXP != 5) {
   __syncthreads();  // every wave is past its last LDS read; no DMA in flight (the last stages drained)
+  PT_STAMP(2)
   float* Cs = reinterpret_cast<float*>(smem);
   const int cout8 = Cout >> 3;
 #pragma unroll
@@ -701,6 +740,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
       for (int e = 0; e < 16; ++e)
         Cs[((wm * TM + tm) * 32 + mm_acc_row(e, lane)) * CLD + wn * TN * 32 + tn * 32 + lr] = acc[tm][tn][e];
   __syncthreads();
+  PT_STAMP(3)
   if constexpr (Q8) {
     const int Hq = H >> 1, Wq = W >> 1;
     constexpr int NITEM = POOL ? P_BM / 4 : P_BM;  // quads or rows
@@ -748,7 +788,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
             o7[UN16] = hi1;
             o7[2 * UN16] = a8;
             o7[3 * UN16] = l8;
-          } else if constexpr (EXP != 6) {
+          } else if constexpr (EXP != 6 && EXP != 10) {
             o[2 * hf] = hi0;
             o[2 * hf + 1] = hi1;
             o[4 + hf] = a8;
@@ -829,13 +869,35 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     }
   }
   }
+  PT_STAMP(4)
+  {
+    const int nitem_ = item + (gridDim.x >> 3);
+    if (nitem_ < clen) {
+      decode_item(nitem_, mt, nt);  // (the epilogue's block tables above were built from the old mt)
+      if constexpr (!FUSE1) compute_poff(mt);
+    }
+  }
   __syncthreads();  // the staging area is the next tile's patch / ring
+  PT_STAMP(5)
+  if constexpr (EXP == 9 || EXP == 10) {
+    if (threadIdx.x == 0) atomicAdd(&pt_dbg[7], 1ull);
+  }
   }  // persistent tile loop
+}
+
+extern "C" int mmmot_debug_read_patch_timers(unsigned long long* out8, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(pt_dbg), 8 * sizeof(unsigned long long));
+  if (e != hipSuccess) return (int)e;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(pt_dbg), z, sizeof(z));
+  }
+  return mm_check(e);
 }
 
 static int g_patch_exp = 0;
 extern "C" int mmmot_set_patch_variant(int v) {
-  if (v < 0 || v > 7) return MMMOT_EINVAL;
+  if (v < 0 || v > 10) return MMMOT_EINVAL;
   g_patch_exp = v;
   return MMMOT_OK;
 }
@@ -925,6 +987,8 @@ static int launch_q8_p(int pool, const void* in, const void* wp, const float* bi
     if (!pool && g_patch_exp == 4) return launch_patch_e<BN, BS, false, 4, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
     if (!pool && g_patch_exp == 6) return launch_patch_e<BN, BS, false, 6, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
     if (!pool && g_patch_exp == 7) return launch_patch_e<BN, BS, false, 7, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
+    if (!pool && g_patch_exp == 9) return launch_patch_e<BN, BS, false, 9, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
+    if (!pool && g_patch_exp == 10) return launch_patch_e<BN, BS, false, 10, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
   }
   return pool ? launch_patch_e<BN, BS, true, 0, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s)
               : launch_patch_e<BN, BS, false, 0, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
@@ -952,6 +1016,9 @@ extern "C" int mmmot_conv1_fused_hq8(const float* crops, const void* w1, const f
   if (!crops || !w1 || !bias1 || !w2 || !bias2 || !out || L <= 0 || H <= 0 || W <= 0) return MMMOT_EINVAL;
   if ((H & 1) || (W & 1) || !mm_al16(w1) || !mm_al16(w2) || !mm_al16(out)) return MMMOT_EINVAL;
   Fuse1Args fz{crops, (const u32x4*)w1, bias1, oscale1};
+  if (g_patch_exp == 4) return launch_patch_e<64, 16, true, 4, true, true>(nullptr, w2, bias2, out, L, H, W, 64, 64, oscale2, s, fz);
+  if (g_patch_exp == 6) return launch_patch_e<64, 16, true, 6, true, true>(nullptr, w2, bias2, out, L, H, W, 64, 64, oscale2, s, fz);
+  if (g_patch_exp == 8) return launch_patch_e<64, 16, true, 8, true, true>(nullptr, w2, bias2, out, L, H, W, 64, 64, oscale2, s, fz);
   return launch_patch_e<64, 16, true, 0, true, true>(nullptr, w2, bias2, out, L, H, W, 64, 64, oscale2, s, fz);
 }
 
