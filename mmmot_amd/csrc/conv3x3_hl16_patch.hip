@@ -91,6 +91,11 @@ __device__ __forceinline__ void pt_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// workgroup barrier that orders LDS accesses only (no vmcnt drain)
+__device__ __forceinline__ void pt_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ void pt_dma16(const u32x4* src, unsigned char* dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -165,12 +170,30 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   constexpr int B_BYTES = BN * P_ROWB;     // 16 / 8 KB per (tap, slab) weight tile
   constexpr int NBL = BN / 64;             // weight DMA instructions per wave per stage: 2 / 1
   constexpr int CLD = BN + 4;
+  // LDS map: [patch buffer 0 | patch buffer 1 | weight ring (3 slots) | FUSE1: raw window].  The K loop is ONE
+  // stream across the tiles of a workgroup: during the last slab of a tile the first patch slab of the NEXT tile
+  // is fetched into the free patch buffer and the ring continues with the next tile's weight stages 0..2
+  // ("transition" slab), so a tile has no load prologue.  (A CU pulls only ~5-8 B/clk from HBM - latency x
+  // outstanding misses - so the 41 KB first slab plus three weight stages cost 15-20 k cycles when nothing runs
+  // beside them: tools/patch_phase_timers.py.)  The epilogue therefore stages the accumulators through the
+  // patch buffer the K loop has just finished with, in NCH row chunks, and leaves the other buffer and the ring
+  // alone.  FUSE1 computes its patches (both buffers live all along): no transition, staging from offset 0.
+  constexpr int P0_OFF = 0;
+  constexpr int P1_OFF = G::BYTES;
   constexpr int RING0 = 2 * G::BYTES;
   constexpr int LOOP_BYTES = RING0 + 3 * B_BYTES;
-  constexpr int EPI_BYTES = P_BM * CLD * 4;
   constexpr int RAW_OFF = LOOP_BYTES;                      // FUSE1: raw input window [3][20][20] fp32
   constexpr int RAW_BYTES = FUSE1 ? 3 * 20 * 20 * 4 + 256 : 0;  // + conv1_1 bias [64]
-  constexpr int SMEM = (LOOP_BYTES + RAW_BYTES) > EPI_BYTES ? (LOOP_BYTES + RAW_BYTES) : EPI_BYTES;
+  constexpr int NCH = FUSE1 ? 1 : (P_BM / 2 * CLD * 4 <= G::BYTES) ? 2 : 4;
+  constexpr int RCH = P_BM / NCH;                          // tile rows per epilogue chunk
+  static_assert(FUSE1 ? (P_BM * CLD * 4 <= LOOP_BYTES) : (RCH * CLD * 4 <= G::BYTES), "epilogue staging does not fit");
+  // STREAM: tiles are chained through transition slabs.  The successor's patch source table is made during the
+  // tile's own prologue (low register pressure) and parked in LDS: [PA][512] words behind the ring.  The 8x8-block
+  // variants have no room for it (and run 1-2 tiles per workgroup): they keep a load prologue per tile.
+  constexpr bool STREAM = !FUSE1 && G::NB == 1;
+  constexpr int POFF_OFF = LOOP_BYTES + RAW_BYTES;
+  constexpr int SMEM = POFF_OFF + (STREAM ? G::PA * 512 * 4 : 0);
+  static_assert(SMEM <= 160 * 1024, "LDS budget");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
 
   const int tid = threadIdx.x;
@@ -247,46 +270,69 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   // record.  The block -> (crop, by, bx) divisions are wave-uniform (scalar unit); the table of the NEXT tile is
   // computed while the slower waves still issue their stores, ahead of the closing barrier of the tile.
   unsigned poff[G::PA];
-  auto compute_poff = [&](int mtile) {
-    const int nbpc_ = nby * nbx, cin16 = (Cin >> 3) * 2;
-    int kcrop[G::NB], kgy0[G::NB], kgx0[G::NB];
+  struct TileBlocks {
+    int crop[G::NB], gy0[G::NB], gx0[G::NB];  // wave-uniform: crop (-1: no such block) and patch origin of each block
+  };
+  auto tile_blocks = [&](int mtile, TileBlocks& tb) {
+    const int nbpc_ = nby * nbx;
 #pragma unroll
     for (int q = 0; q < G::NB; ++q) {
-      const int b = mtile * G::NB + q;  // uniform
+      const int b = mtile * G::NB + q;
       const int crop = b / nbpc_, br = b - crop * nbpc_;
       const int by = br / nbx;
-      kcrop[q] = (b < nblk) ? crop : -1;
-      kgy0[q] = by * BS - 1;
-      kgx0[q] = (br - by * nbx) * BS - 1;
+      tb.crop[q] = (b < nblk) ? crop : -1;
+      tb.gy0[q] = by * BS - 1;
+      tb.gx0[q] = (br - by * nbx) * BS - 1;
     }
+  };
+  auto poff_round = [&](auto KC, const TileBlocks& tb) -> unsigned {
+    constexpr int k = decltype(KC)::value;
+    const int cin16 = (Cin >> 3) * 2;
+    // the lane id is laundered: otherwise the lane-only part of every round (pixel, swizzle) is hoisted out of
+    // the tile loop and stays live across the K loop (+20 VGPRs at its register peak)
+    int lane_ = lane;
+    asm volatile("" : "+v"(lane_));
+    const int p = (k < G::FULL) ? (k * 8 + wave) * 64 + lane_ : G::FULL * 512 + wave * G::RL + lane_;
+    unsigned off = ~0u;
+    if (k < G::FULL || lane_ < G::RL) {
+      const int n = p >> 3, c = p & 7;
+      const int blk = n / G::PP;
+      const int rem = n - blk * G::PP;
+      const int py = rem / G::PW, px = rem - py * G::PW;
+      int crop = tb.crop[0], gy = tb.gy0[0] + py, gx = tb.gx0[0] + px;
 #pragma unroll
-    for (int k = 0; k < G::PA; ++k) {
-      const int p = (k < G::FULL) ? (k * 8 + wave) * 64 + lane : G::FULL * 512 + wave * G::RL + lane;
-      unsigned off = ~0u;
-      if (k < G::FULL || lane < G::RL) {
-        const int n = p >> 3, c = p & 7;
-        const int blk = n / G::PP;
-        const int rem = n - blk * G::PP;
-        const int py = rem / G::PW, px = rem - py * G::PW;
-        int crop = kcrop[0], gy = kgy0[0] + py, gx = kgx0[0] + px;
-#pragma unroll
-        for (int q = 1; q < G::NB; ++q)
-          if (blk == q) {
-            crop = kcrop[q];
-            gy = kgy0[q] + py;
-            gx = kgx0[q] + px;
-          }
-        if (crop >= 0 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
-          off = (unsigned)(((crop * H + gy) * W + gx) * cin16 + (c ^ pt_swz_a(py, px)));
-      }
-      poff[k] = off;
+      for (int q = 1; q < G::NB; ++q)
+        if (blk == q) {
+          crop = tb.crop[q];
+          gy = tb.gy0[q] + py;
+          gx = tb.gx0[q] + px;
+        }
+      if (crop >= 0 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+        off = (unsigned)(((crop * H + gy) * W + gx) * cin16 + (c ^ pt_swz_a(py, px)));
     }
+    return off;
+  };
+  auto compute_poff = [&](int mtile) {
+    TileBlocks tb;
+    tile_blocks(mtile, tb);
+    poff[0] = poff_round(std::integral_constant<int, 0>{}, tb);
+    poff[1] = poff_round(std::integral_constant<int, 1>{}, tb);
+    poff[2] = poff_round(std::integral_constant<int, 2>{}, tb);
+    poff[3] = poff_round(std::integral_constant<int, 3>{}, tb);
+    poff[4] = poff_round(std::integral_constant<int, 4>{}, tb);
+    poff[5] = poff_round(std::integral_constant<int, 5>{}, tb);
+    if constexpr (G::PA > 6) poff[6] = poff_round(std::integral_constant<int, 6>{}, tb);
   };
   int mt = 0, nt = 0;
   if ((int)(blockIdx.x >> 3) < clen) {
     decode_item(blockIdx.x >> 3, mt, nt);
     if constexpr (!FUSE1) compute_poff(mt);
   }
+  const u32x4* wbase = wp + (long)(nt * BN) * ((Cin >> 3) * 2);  // weight rows of this tile's channel tile
+  const u32x4* wbase_next = wbase;
+  bool primed = false;  // this tile's patch slab 0 and weight stages 0..2 were streamed in by the previous tile
+  int pcur = P0_OFF;    // patch buffer of the current slab (byte offset in smem)
+  int pnext = P1_OFF;   // patch buffer being filled for the next slab (of this tile or the next one)
   for (int item = blockIdx.x >> 3; item < clen; item += gridDim.x >> 3) {
   unsigned long long tprev_ = 0;
   PT_STAMP(-1)
@@ -320,7 +366,6 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     boffl[b] = (unsigned)(brw * (cin8 * 2) + (slot8 ^ pt_swz_b(brw)));
   }
   const long tapstride_w = (long)Cout * cin8 * 2;
-  const u32x4* wbase = wp + (long)n0 * (cin8 * 2);
 
   auto issue_patch_round = [&](auto KC, int slab, int pbuf) {  // pbuf: byte offset of the patch buffer in smem
     constexpr int k = decltype(KC)::value;
@@ -332,12 +377,12 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     }
   };
   // weight DMA instruction b (0..NBL-1) of stage (tap, slab) into ring slot `ringslot`
-  auto issue_b1 = [&](auto BC, int tap, int slab, int ringslot) {
+  auto issue_b1 = [&](auto BC, const u32x4* base, int tap, int slab, int ringslot) {
     constexpr int b = decltype(BC)::value;
     if constexpr (b < NBL) {
       // wave-uniform base, laundered through readfirstlane so that it stays in scalar registers and is
       // not re-associated with the lane offsets into nine hoisted 64-bit lane values
-      const unsigned long ubl = (unsigned long)(wbase + ((long)tap * tapstride_w + slab * 8));
+      const unsigned long ubl = (unsigned long)(base + ((long)tap * tapstride_w + slab * 8));
       const unsigned ub_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(ubl >> 32));
       const unsigned ub_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ubl);
       const u32x4* ub = (const u32x4*)(((unsigned long)ub_hi << 32) | (unsigned long)ub_lo);
@@ -345,8 +390,21 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     }
   };
   auto issue_b = [&](int tap, int slab, int ringslot) {
-    issue_b1(std::integral_constant<int, 0>{}, tap, slab, ringslot);
-    issue_b1(std::integral_constant<int, 1>{}, tap, slab, ringslot);
+    issue_b1(std::integral_constant<int, 0>{}, wbase, tap, slab, ringslot);
+    issue_b1(std::integral_constant<int, 1>{}, wbase, tap, slab, ringslot);
+  };
+  // first tile of a workgroup: patch slab 0 -> buffer pbuf, weight stages 0..2 (poff / wbase are current)
+  auto issue_tile_head = [&](int pbuf) {
+    issue_patch_round(std::integral_constant<int, 0>{}, 0, pbuf);
+    issue_patch_round(std::integral_constant<int, 1>{}, 0, pbuf);
+    issue_patch_round(std::integral_constant<int, 2>{}, 0, pbuf);
+    issue_patch_round(std::integral_constant<int, 3>{}, 0, pbuf);
+    issue_patch_round(std::integral_constant<int, 4>{}, 0, pbuf);
+    issue_patch_round(std::integral_constant<int, 5>{}, 0, pbuf);
+    if constexpr (G::PA > 6) issue_patch_round(std::integral_constant<int, 6>{}, 0, pbuf);
+    issue_b(0, 0, 0);
+    issue_b(1, 0, 1);
+    issue_b(2, 0, 2);
   };
 
   // ---------------- fragment read state --------------------------------------------------------------
@@ -471,9 +529,28 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   };
 
   // ---------------- prologue: patch(slab 0), weight stages 0..2 --------------------------------------
-  int pcur = 0;          // patch buffer of the current slab (byte offset in smem)
-  int pnext = G::BYTES;  // patch buffer being filled for the next slab
   static_assert(G::BYTES % 256 == 0 && RING0 % 256 == 0 && B_BYTES % 256 == 0, "hi/lo xor addressing");
+  const int nitem_ = item + (gridDim.x >> 3);
+  const bool has_next = nitem_ < clen;
+  int mt_next = 0, nt_next = 0;
+  if (has_next) decode_item(nitem_, mt_next, nt_next);
+  if constexpr (STREAM) {
+    if (has_next) {
+      TileBlocks tb;
+      tile_blocks(mt_next, tb);
+      unsigned* pk = reinterpret_cast<unsigned*>(smem + POFF_OFF) + tid;
+      pk[0 * 512] = poff_round(std::integral_constant<int, 0>{}, tb);
+      pk[1 * 512] = poff_round(std::integral_constant<int, 1>{}, tb);
+      pk[2 * 512] = poff_round(std::integral_constant<int, 2>{}, tb);
+      pk[3 * 512] = poff_round(std::integral_constant<int, 3>{}, tb);
+      pk[4 * 512] = poff_round(std::integral_constant<int, 4>{}, tb);
+      pk[5 * 512] = poff_round(std::integral_constant<int, 5>{}, tb);
+      if constexpr (G::PA > 6) pk[6 * 512] = poff_round(std::integral_constant<int, 6>{}, tb);
+    }
+  } else {
+    pcur = P0_OFF;
+    pnext = P1_OFF;
+  }
   if constexpr (FUSE1) {
     issue_b(0, 0, 0);  // conv1_2's weight ring flies while the patch is computed
     issue_b(1, 0, 1);
@@ -569,19 +646,12 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     pt_wait_vm<2 * NBL>();  // weight stage 0 landed (this wave's part)
     __syncthreads();        // both patch slabs are complete
   } else {
-    issue_patch_round(std::integral_constant<int, 0>{}, 0, pcur);
-    issue_patch_round(std::integral_constant<int, 1>{}, 0, pcur);
-    issue_patch_round(std::integral_constant<int, 2>{}, 0, pcur);
-    issue_patch_round(std::integral_constant<int, 3>{}, 0, pcur);
-    issue_patch_round(std::integral_constant<int, 4>{}, 0, pcur);
-    issue_patch_round(std::integral_constant<int, 5>{}, 0, pcur);
-    if constexpr (G::PA > 6) issue_patch_round(std::integral_constant<int, 6>{}, 0, pcur);
-    issue_b(0, 0, 0);
-    issue_b(1, 0, 1);
-    issue_b(2, 0, 2);
-    PT_STAMP(0)
-    pt_wait_vm<2 * NBL>();  // patch + weight stage 0 landed (this wave's part)
-    __builtin_amdgcn_s_barrier();
+    if (!primed) {  // first tile of this workgroup
+      issue_tile_head(pcur);
+      PT_STAMP(0)
+      pt_wait_vm<2 * NBL>();  // patch + weight stage 0 landed (this wave's part)
+      __builtin_amdgcn_s_barrier();
+    }
     PT_STAMP(1)
   }
   Frags f0, f1;
@@ -591,9 +661,15 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   // barrier of stage t (its ring slot was last read by stage t); the patch of the next slab is issued
   // round by round in taps 0..PA-1, BEFORE the weights of the same stage so that the counted vmcnt of
   // a later barrier retires it as well.
-  auto stage = [&](auto TAPC, auto LASTC, int slab) {
+  // MODE 0: a slab with something to prefetch - patch slab `pslab` (of the tile poff describes) and, once the
+  // weight stream passes tap 8, weights (wb2, slab ws2).  Interior slab: pslab = ws2 = slab + 1, wb2 = wbase.
+  // Transition slab (last slab of a tile that has a successor): poff = the successor's table, pslab = ws2 = 0,
+  // wb2 = the successor's weights - the same code, so every counted vmcnt is the interior one.
+  // MODE 1: last slab of the workgroup's last tile (nothing to prefetch).
+  auto stage = [&](auto TAPC, auto MODEC, int slab, int pslab, const u32x4* wb2, int ws2) {
     constexpr int tap = decltype(TAPC)::value;
-    constexpr bool last = decltype(LASTC)::value;
+    constexpr int MODE = decltype(MODEC)::value;
+    constexpr bool last = (MODE == 1);
     // loads this wave issued one stage earlier (they may stay in flight across this stage's barrier)
     constexpr int ptap = (tap + 8) % 9;  // tap of the previous stage
     constexpr int prev_issued =
@@ -641,19 +717,19 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
       }
       if constexpr (i < NRD) {
         if constexpr (tap < 8) read_one(f0, IC, std::integral_constant<int, (tap + 1) % 9>{}, I0{}, pcur);
-        else if constexpr (!last) read_one(f0, IC, I0{}, I0{}, pnext);
+        else if constexpr (MODE == 0) read_one(f0, IC, I0{}, I0{}, pnext);
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (EXP != 1) {
         constexpr int at_patch = (BN == 128) ? 2 : 1, at_b0 = (BN == 128) ? 6 : 4, at_b1 = 10;
         if constexpr (i == at_patch) {
-          if constexpr (!FUSE1 && !last && tap < G::PA) issue_patch_round(TAPC, slab + 1, pnext);
+          if constexpr (!FUSE1 && !last && tap < G::PA) issue_patch_round(TAPC, pslab, pnext);
           __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (i == at_b0 || (i == at_b1 && NBL > 1)) {
           using BI = std::integral_constant<int, (i == at_b0) ? 0 : 1>;
-          if constexpr (!last) issue_b1(BI{}, (tap + 3) % 9, slab + (tap + 3) / 9, tap % 3);
-          else if constexpr (tap + 3 <= 8) issue_b1(BI{}, tap + 3, slab, tap % 3);
+          if constexpr (tap + 3 <= 8) issue_b1(BI{}, wbase, tap + 3, slab, tap % 3);
+          else if constexpr (MODE == 0) issue_b1(BI{}, wb2, tap + 3 - 9, ws2, tap % 3);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -671,33 +747,44 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     half2(std::integral_constant<int, 10>{});
     half2(std::integral_constant<int, 11>{});
   };
-  auto slab_body = [&](auto LASTC, int slab) {
-    stage(std::integral_constant<int, 0>{}, LASTC, slab);
-    stage(std::integral_constant<int, 1>{}, LASTC, slab);
-    stage(std::integral_constant<int, 2>{}, LASTC, slab);
-    stage(std::integral_constant<int, 3>{}, LASTC, slab);
-    stage(std::integral_constant<int, 4>{}, LASTC, slab);
-    stage(std::integral_constant<int, 5>{}, LASTC, slab);
-    stage(std::integral_constant<int, 6>{}, LASTC, slab);
-    stage(std::integral_constant<int, 7>{}, LASTC, slab);
-    stage(std::integral_constant<int, 8>{}, LASTC, slab);
+  auto slab_body = [&](auto LASTC, int slab, int pslab, const u32x4* wb2, int ws2) {
+    stage(std::integral_constant<int, 0>{}, LASTC, slab, pslab, wb2, ws2);
+    stage(std::integral_constant<int, 1>{}, LASTC, slab, pslab, wb2, ws2);
+    stage(std::integral_constant<int, 2>{}, LASTC, slab, pslab, wb2, ws2);
+    stage(std::integral_constant<int, 3>{}, LASTC, slab, pslab, wb2, ws2);
+    stage(std::integral_constant<int, 4>{}, LASTC, slab, pslab, wb2, ws2);
+    stage(std::integral_constant<int, 5>{}, LASTC, slab, pslab, wb2, ws2);
+    stage(std::integral_constant<int, 6>{}, LASTC, slab, pslab, wb2, ws2);
+    stage(std::integral_constant<int, 7>{}, LASTC, slab, pslab, wb2, ws2);
+    stage(std::integral_constant<int, 8>{}, LASTC, slab, pslab, wb2, ws2);
   };
-  for (int slab = 0; slab < nslab - 1; ++slab) {
-    slab_body(std::false_type{}, slab);
-    const int t = pcur;
-    pcur = pnext;
-    pnext = t;
+  // slabs 0 .. nslab-2 are interior; the last one is a transition slab when the tile has a successor
+  const bool chain = STREAM && has_next;
+  if (chain) wbase_next = wp + (long)(nt_next * BN) * (cin8 * 2);
+  const int nloop = chain ? nslab : nslab - 1;
+  for (int slab = 0; slab < nloop; ++slab) {
+    const bool trans = (slab == nslab - 1);
+    if constexpr (STREAM) {
+      if (trans) {  // the successor's table replaces this tile's (dead: its last patch slab was requested a slab ago)
+        const unsigned* pk = reinterpret_cast<const unsigned*>(smem + POFF_OFF) + tid;
+#pragma unroll
+        for (int k = 0; k < G::PA; ++k) poff[k] = pk[k * 512];
+      }
+    }
+    slab_body(std::integral_constant<int, 0>{}, slab, trans ? 0 : slab + 1, trans ? wbase_next : wbase,
+              trans ? 0 : slab + 1);
+    if (!trans) {
+      const int t = pcur;
+      pcur = pnext;
+      pnext = t;
+    }
   }
-  slab_body(std::true_type{}, nslab - 1);
+  if (!chain) slab_body(std::integral_constant<int, 1>{}, nslab - 1, 0, wbase, 0);
+  primed = chain;
 
   if constexpr (FUSE1) {
-    const int nitem = item + (gridDim.x >> 3);
-    raw_ready = nitem < clen;
-    if (raw_ready) {
-      int mt2, nt2;
-      decode_item(nitem, mt2, nt2);
-      fetch_raw(mt2);
-    }
+    raw_ready = has_next;
+    if (raw_ready) fetch_raw(mt_next);
   }
   // ---- epilogue: accumulators -> LDS fp32 [256][BN+4] -> pool/bias/relu/split -> hl16 -------------
   // thread -> fixed channel unit u (8 channels) and rows r0, r0 + RSTEP, ...: bias is loaded once, before
@@ -728,26 +815,36 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     bgx0[k] = (br - by * nbx) * BS;
   }
   if constexpr (EXP != 5) {
-  __syncthreads();  // every wave is past its last LDS read; no DMA in flight (the last stages drained)
+  // barriers of the epilogue order LDS traffic only (lgkmcnt): a __syncthreads() would also drain vmcnt, i.e.
+  // wait for the successor's loads and for this tile's own global stores
+  pt_lds_barrier();  // every wave is past its last read of the buffer that becomes the staging area
   PT_STAMP(2)
-  float* Cs = reinterpret_cast<float*>(smem);
+  float* Cs = reinterpret_cast<float*>(smem + (FUSE1 ? 0 : pcur));
   const int cout8 = Cout >> 3;
 #pragma unroll
-  for (int tm = 0; tm < TM; ++tm)
+  for (int ch = 0; ch < NCH; ++ch) {
+  if (ch > 0) pt_lds_barrier();  // the previous chunk has been read by everyone
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
+  for (int tm = 0; tm < TM; ++tm) {
+    const int rb = wm * TM + tm;  // 32-row block of the tile (wave-uniform)
+    if (rb / (8 / NCH) == ch) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e)
-        Cs[((wm * TM + tm) * 32 + mm_acc_row(e, lane)) * CLD + wn * TN * 32 + tn * 32 + lr] = acc[tm][tn][e];
-  __syncthreads();
-  PT_STAMP(3)
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          Cs[((rb % (8 / NCH)) * 32 + mm_acc_row(e, lane)) * CLD + wn * TN * 32 + tn * 32 + lr] = acc[tm][tn][e];
+    }
+  }
+  pt_lds_barrier();
+  if (ch == 0) { PT_STAMP(3) }
   if constexpr (Q8) {
     const int Hq = H >> 1, Wq = W >> 1;
-    constexpr int NITEM = POOL ? P_BM / 4 : P_BM;  // quads or rows
+    constexpr int NITEM = (POOL ? P_BM / 4 : P_BM) / NCH;  // quads or rows of one chunk
 #pragma unroll
     for (int i = 0; i < (NITEM + RSTEP16 - 1) / RSTEP16; ++i) {
-      const int it = er16 + i * RSTEP16;
-      if (it < NITEM) {
+      const int itl = er16 + i * RSTEP16;  // chunk-local
+      const int it = ch * NITEM + itl;
+      if (itl < NITEM) {
         int blk, y, x;
         if constexpr (POOL) pt_row_to_pixel<BS>(it >> 3, (it & 7) * 4, blk, y, x);
         else pt_row_to_pixel<BS>(it >> 5, it & 31, blk, y, x);
@@ -761,7 +858,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
           }
         if (crop >= 0 && gy < H && gx < W) {
           float v[16];
-          const float* c = &Cs[(POOL ? it * 4 : it) * CLD + eu16 * 16];
+          const float* c = &Cs[(POOL ? itl * 4 : itl) * CLD + eu16 * 16];
 #pragma unroll
           for (int e = 0; e < 16; e += 4) {
             f32x4 w4 = *reinterpret_cast<const f32x4*>(c + e);
@@ -801,9 +898,12 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     }
   } else if constexpr (POOL) {
     const int Hq = H >> 1, Wq = W >> 1;
+    constexpr int NQ = (P_BM / 4) / NCH;  // quads of one chunk
 #pragma unroll
-    for (int i = 0; i < (P_BM / 4) / RSTEP; ++i) {
-      const int qd = er0 + i * RSTEP;
+    for (int i = 0; i < (NQ + RSTEP - 1) / RSTEP; ++i) {
+      const int qdl = er0 + i * RSTEP;  // chunk-local
+      const int qd = ch * NQ + qdl;
+      if (qdl >= NQ) continue;
       int blk, y, x;
       pt_row_to_pixel<BS>(qd >> 3, (qd & 7) * 4, blk, y, x);
       int crop = bcrop[0], gy = bgy0[0] + y, gx = bgx0[0] + x;
@@ -815,7 +915,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
           gx = bgx0[k] + x;
         }
       if (crop >= 0 && gy < H && gx < W) {
-        const float* c = &Cs[(qd * 4) * CLD + eu * 8];
+        const float* c = &Cs[(qdl * 4) * CLD + eu * 8];
         f32x8 v = *reinterpret_cast<const f32x8*>(c);
 #pragma unroll
         for (int r = 1; r < 4; ++r) {
@@ -839,8 +939,9 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     }
   } else {
 #pragma unroll
-    for (int i = 0; i < P_BM / RSTEP; ++i) {
-      const int r = er0 + i * RSTEP;
+    for (int i = 0; i < RCH / RSTEP; ++i) {
+      const int rl = er0 + i * RSTEP;  // chunk-local
+      const int r = ch * RCH + rl;
       int blk, y, x;
       pt_row_to_pixel<BS>(r >> 5, r & 31, blk, y, x);
       int crop = bcrop[0], gy = bgy0[0] + y, gx = bgx0[0] + x;
@@ -852,7 +953,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
           gx = bgx0[k] + x;
         }
       if (crop >= 0 && gy < H && gx < W) {
-        f32x8 v = *reinterpret_cast<const f32x8*>(&Cs[r * CLD + eu * 8]);
+        f32x8 v = *reinterpret_cast<const f32x8*>(&Cs[rl * CLD + eu * 8]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], oscale, bv[e]), 0.f);
         u32x4 hi, lo;
@@ -868,16 +969,24 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
       }
     }
   }
+  }  // chunks
   }
   PT_STAMP(4)
-  {
-    const int nitem_ = item + (gridDim.x >> 3);
-    if (nitem_ < clen) {
-      decode_item(nitem_, mt, nt);  // (the epilogue's block tables above were built from the old mt)
-      if constexpr (!FUSE1) compute_poff(mt);
+  mt = mt_next;
+  nt = nt_next;
+  wbase = wbase_next;
+  if constexpr (STREAM) {  // the successor's slab 0 sits in pnext
+    const int t = pcur;
+    pcur = pnext;
+    pnext = t;
+  } else if constexpr (!FUSE1) {
+    if (has_next) {
+      wbase = wp + (long)(nt_next * BN) * (cin8 * 2);
+      compute_poff(mt_next);
     }
   }
-  __syncthreads();  // the staging area is the next tile's patch / ring
+  if constexpr (FUSE1) __syncthreads();  // the staging area is overwritten by the next tile's prologue (raw window: vmcnt)
+  else pt_lds_barrier();                 // the staging area is the successor's next patch buffer
   PT_STAMP(5)
   if constexpr (EXP == 9 || EXP == 10) {
     if (threadIdx.x == 0) atomicAdd(&pt_dbg[7], 1ull);
