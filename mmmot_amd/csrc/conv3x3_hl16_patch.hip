@@ -184,9 +184,12 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   constexpr int LOOP_BYTES = RING0 + 3 * B_BYTES;
   constexpr int RAW_OFF = LOOP_BYTES;                      // FUSE1: raw input window [3][20][20] fp32
   constexpr int RAW_BYTES = FUSE1 ? 3 * 20 * 20 * 4 + 256 : 0;  // + conv1_1 bias [64]
-  constexpr int NCH = FUSE1 ? 1 : (P_BM / 2 * CLD * 4 <= G::BYTES) ? 2 : 4;
-  constexpr int RCH = P_BM / NCH;                          // tile rows per epilogue chunk
-  static_assert(FUSE1 ? (P_BM * CLD * 4 <= LOOP_BYTES) : (RCH * CLD * 4 <= G::BYTES), "epilogue staging does not fit");
+  // pooled layers take the 2x2 maximum in registers (the four pixels of a window are four consecutive accumulator
+  // registers of one lane: quad-ordered rows) and stage the 64 pooled rows only - one chunk
+  constexpr int SROWS = POOL ? P_BM / 4 : P_BM;            // staged rows per tile
+  constexpr int NCH = (FUSE1 || POOL) ? 1 : (SROWS / 2 * CLD * 4 <= G::BYTES) ? 2 : 4;
+  constexpr int RCH = SROWS / NCH;                         // staged rows per epilogue chunk
+  static_assert(FUSE1 ? (SROWS * CLD * 4 <= LOOP_BYTES) : (RCH * CLD * 4 <= G::BYTES), "epilogue staging does not fit");
   // STREAM: tiles are chained through transition slabs.  The successor's patch source table is made during the
   // tile's own prologue (low register pressure) and parked in LDS: [PA][512] words behind the ring.  The 8x8-block
   // variants have no room for it (and run 1-2 tiles per workgroup): they keep a load prologue per tile.
@@ -827,7 +830,17 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const int rb = wm * TM + tm;  // 32-row block of the tile (wave-uniform)
-    if (rb / (8 / NCH) == ch) {
+    if constexpr (POOL) {
+      // quad q = 2j + h of the 32-row block holds rows 8j + 4h .. + 3 = accumulator registers 4j .. 4j + 3
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float m = fmaxf(fmaxf(acc[tm][tn][4 * j], acc[tm][tn][4 * j + 1]),
+                                fmaxf(acc[tm][tn][4 * j + 2], acc[tm][tn][4 * j + 3]));
+          Cs[(rb * 8 + 2 * j + h) * CLD + wn * TN * 32 + tn * 32 + lr] = m;
+        }
+    } else if (rb / (8 / NCH) == ch) {
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -839,7 +852,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   if (ch == 0) { PT_STAMP(3) }
   if constexpr (Q8) {
     const int Hq = H >> 1, Wq = W >> 1;
-    constexpr int NITEM = (POOL ? P_BM / 4 : P_BM) / NCH;  // quads or rows of one chunk
+    constexpr int NITEM = RCH;  // quads (pooled) or rows of one chunk
 #pragma unroll
     for (int i = 0; i < (NITEM + RSTEP16 - 1) / RSTEP16; ++i) {
       const int itl = er16 + i * RSTEP16;  // chunk-local
@@ -858,18 +871,10 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
           }
         if (crop >= 0 && gy < H && gx < W) {
           float v[16];
-          const float* c = &Cs[(POOL ? itl * 4 : itl) * CLD + eu16 * 16];
+          const float* c = &Cs[itl * CLD + eu16 * 16];
 #pragma unroll
           for (int e = 0; e < 16; e += 4) {
-            f32x4 w4 = *reinterpret_cast<const f32x4*>(c + e);
-            if constexpr (POOL) {
-#pragma unroll
-              for (int r = 1; r < 4; ++r) {
-                const f32x4 o4 = *reinterpret_cast<const f32x4*>(c + r * CLD + e);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) w4[k] = fmaxf(w4[k], o4[k]);
-              }
-            }
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(c + e);
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[e + k] = fmaxf(fmaf(w4[k], oscale, bq[e + k]), 0.f);
           }
@@ -898,7 +903,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     }
   } else if constexpr (POOL) {
     const int Hq = H >> 1, Wq = W >> 1;
-    constexpr int NQ = (P_BM / 4) / NCH;  // quads of one chunk
+    constexpr int NQ = RCH;  // quads of the (single) chunk
 #pragma unroll
     for (int i = 0; i < (NQ + RSTEP - 1) / RSTEP; ++i) {
       const int qdl = er0 + i * RSTEP;  // chunk-local
@@ -915,14 +920,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
           gx = bgx0[k] + x;
         }
       if (crop >= 0 && gy < H && gx < W) {
-        const float* c = &Cs[(qdl * 4) * CLD + eu * 8];
-        f32x8 v = *reinterpret_cast<const f32x8*>(c);
-#pragma unroll
-        for (int r = 1; r < 4; ++r) {
-          const f32x8 w2 = *reinterpret_cast<const f32x8*>(c + r * CLD);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], w2[e]);
-        }
+        f32x8 v = *reinterpret_cast<const f32x8*>(&Cs[qdl * CLD + eu * 8]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], oscale, bv[e]), 0.f);
         u32x4 hi, lo;
