@@ -24,4 +24,6 @@ done
 cd $R
 timeout 900 python -m pytest tests -q -m gpu 2>&1 | tail -8 > $O/pytest_gpu.log
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 > $O/smoke.log
-tail -c 400 $O/bench_default.log; tail -3 $O/pytest_gpu.log; cat $O/smoke.log
+tail -c 400 $O/bench_default.log; tail -3 $O/pytest_gpu.log; cat $O/smoke.log; tail -4 $O/power_clock_during_bench.log | cut -c1-150
+timeout 200 tools/sample_power.sh > $O/power_clock_during_bench.log 2>&1
+timeout 200 python tools/patch_phase_timers.py > $O/patch_phase_timers.log 2>&1
