@@ -136,6 +136,7 @@ int mmmot_conv1_fused_hq8(const float* crops, const void* w1, const float* bias1
 int mmmot_hq8_pack(const float* x, void* y, long n, void* stream);
 int mmmot_hq8_unpack(const void* x, float* y, long n, void* stream);
 int mmmot_debug_read_patch_timers(unsigned long long* out8, int reset); /* phase cycle sums of patch variant 9 */
+int mmmot_set_patch_grid_limit(int n); /* tests: cap the persistent grid of the patch kernels (multiple of 8, 0 = one workgroup per CU) */
 int mmmot_set_patch_variant(int v); /* timing experiments of the patch kernel (0 = product; 1..4 give WRONG results) */
 int mmmot_set_dma_variant(int v); /* tuning / experiment knob of the LDS-DMA kernel (0 = default) */
 int mmmot_conv3x3_first_hl16(const float* in, const float* wp, const float* bias, void* out,

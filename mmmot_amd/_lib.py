@@ -84,6 +84,7 @@ SIGNATURES = {
     'mmmot_set_conv_variant': [c_i],
     'mmmot_set_dma_variant': [c_i],
     'mmmot_set_patch_variant': [c_i],
+    'mmmot_set_patch_grid_limit': [c_i],
     'mmmot_debug_read_phase_timers': [ctypes.POINTER(ctypes.c_ulonglong), c_i],
     'mmmot_debug_read_patch_timers': [ctypes.POINTER(ctypes.c_ulonglong), c_i],
     'mmmot_hl16_pack': [c_f, c_f, ctypes.c_long, c_f],

@@ -1003,6 +1003,14 @@ extern "C" int mmmot_debug_read_patch_timers(unsigned long long* out8, int reset
 }
 
 static int g_patch_exp = 0;
+static int g_patch_grid_limit = 0;
+// Test knob: cap the persistent grid (a multiple of 8; 0 = one workgroup per CU) so that small problems exercise
+// the tile chaining (several tiles per workgroup) that production sizes run with.
+extern "C" int mmmot_set_patch_grid_limit(int n) {
+  if (n < 0 || n % 8 != 0) return MMMOT_EINVAL;
+  g_patch_grid_limit = n;
+  return MMMOT_OK;
+}
 extern "C" int mmmot_set_patch_variant(int v) {
   if (v < 0 || v > 10) return MMMOT_EINVAL;
   g_patch_exp = v;
@@ -1026,6 +1034,7 @@ static int launch_patch_e(const void* in, const void* wp, const float* bias, voi
   }
   const int nitems = ntm * ntn;
   int grid = (n_cu / 8) * 8;                       // one persistent workgroup per CU, whole XCDs
+  if (g_patch_grid_limit > 0 && grid > g_patch_grid_limit) grid = g_patch_grid_limit;
   if (grid > ((nitems + 7) / 8) * 8) grid = ((nitems + 7) / 8) * 8;
   hipLaunchKernelGGL((conv3x3_hl16_patch_kernel<BN, BS, POOL, EXP, FUSE1, Q8>), dim3(grid), dim3(512), 0, s,
                      (const u32x4*)in, (const u32x4*)wp, bias, (u32x4*)out, L, H, W, Cin, Cout, nby, nbx, nblk, ntm, ntn,

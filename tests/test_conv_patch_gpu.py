@@ -51,6 +51,40 @@ def test_conv3x3_hl16_patch(hip, pool, L, H, W, Cin, Cout):
     close(out, ref, 2e-6, 'conv3x3 hl16 patch kernel vs fp64')
 
 
+# more tiles than workgroups: the tiles of a workgroup are chained (the successor's first patch slab and weight
+# stages are streamed in during the last slab) - forced here by capping the persistent grid
+CHAIN_CASES = CASES + [
+    (0, 7, 16, 16, 32, 128),     # single-slab tiles: every slab is a transition slab
+    (1, 12, 32, 32, 96, 64),     # odd slab count (the two patch buffers swap roles from tile to tile), 64-channel tiles
+    (0, 40, 16, 16, 128, 256),   # 80 items on 8 workgroups: 10-tile chains, channel tile changes inside a chain
+    (1, 33, 24, 40, 64, 128),    # partial blocks + ragged last tile inside chains
+]
+
+
+@pytest.fixture
+def small_grid(hip):
+    from mmmot_amd import _lib
+    lib = _lib.load()
+    assert lib.mmmot_set_patch_grid_limit(8) == 0
+    yield 8
+    assert lib.mmmot_set_patch_grid_limit(0) == 0
+
+
+@pytest.mark.parametrize('pool,L,H,W,Cin,Cout', CHAIN_CASES)
+def test_conv3x3_hl16_patch_chained_tiles(hip, small_grid, pool, L, H, W, Cin, Cout):
+    out, ref, (x16, w16, bias, shift) = run_case(hip, pool, L, H, W, Cin, Cout, seed=470)
+    close(out, ref, 2e-6, 'chained tiles (grid capped at 8 workgroups) vs fp64')
+    # and bitwise the same as the unchained launch (one workgroup per tile where the grid allows)
+    from mmmot_amd import _lib
+    _lib.load().mmmot_set_patch_grid_limit(0)
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    o2 = torch.full((L * Ho * Wo, Cout), float('nan')).cuda()
+    hip.conv3x3_hl16_patch(x16.cuda(), w16.cuda(), bias.cuda(), o2, L, H, W, Cin, Cout, bool(pool), 2.0 ** -shift)
+    u2 = torch.zeros_like(o2)
+    hip.hl16_unpack(o2, u2)
+    assert torch.equal(out.cpu(), u2.cpu()), 'chained and unchained launches differ'
+
+
 def test_patch_matches_tile_kernel_and_is_deterministic(hip):
     """Same inputs through the register-staged tile kernel: fp32 accumulation order differs (32- vs 64-channel
     slabs), values must agree to fp32 rounding; repeated launches of the patch kernel are bitwise identical
@@ -98,3 +132,9 @@ def test_conv1_fused_matches_two_layer_reference(hip, L, H, W):
     out = torch.zeros_like(out16)
     hip.hl16_unpack(out16, out)
     close(out, ref, 3e-6, 'fused conv1_1 + conv1_2 + pool vs float64')
+
+
+def test_conv1_fused_many_tiles_per_workgroup(hip, small_grid):
+    """persistent grid capped at 8 workgroups: every workgroup walks 10+ tiles (raw-window prefetch of the next tile)"""
+    test_conv1_fused_matches_two_layer_reference(hip, 5, 64, 64)
+    test_conv1_fused_matches_two_layer_reference(hip, 3, 32, 48)

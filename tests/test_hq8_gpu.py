@@ -75,6 +75,35 @@ def test_conv3x3_hq8_geometry(hip, pool, L, H, W, Cin, Cout):
     close(dec, full, 2.5e-4, 'hq8 conv vs exact convolution')
 
 
+@pytest.mark.parametrize('pool,L,H,W,Cin,Cout', [(0, 7, 16, 16, 32, 128), (1, 12, 32, 32, 96, 64),
+                                                 (0, 40, 16, 16, 128, 256), (1, 33, 24, 40, 64, 128), (1, 9, 4, 4, 512, 512)])
+def test_conv3x3_hq8_chained_tiles(hip, pool, L, H, W, Cin, Cout):
+    """several tiles per workgroup (persistent grid capped at 8): chained tiles give the bytes of the unchained launch"""
+    from mmmot_amd import _lib
+    lib = _lib.load()
+    x = torch.relu(rnd(L * H * W, Cin, seed=680)) * 3.0
+    w = rnd(9, Cout, Cin, seed=681, scale=(2.0 / (9 * Cin)) ** 0.5)
+    bias = rnd(Cout, seed=682, scale=0.1).cuda()
+    shift = hl16_weight_shift(w)
+    xs, ws = to_hq8_act(x).cuda(), to_hq8_w(w.double() * 2.0 ** shift).cuda()
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    outs = []
+    try:
+        for limit in (0, 8):
+            assert lib.mmmot_set_patch_grid_limit(limit) == 0
+            o = torch.full((L * Ho * Wo, Cout), float('nan')).cuda()
+            hip.conv3x3_hq8(xs, ws, bias, o, L, H, W, Cin, Cout, bool(pool), 2.0 ** -shift)
+            outs.append(bytes_of(o))
+    finally:
+        lib.mmmot_set_patch_grid_limit(0)
+    assert torch.equal(outs[0], outs[1]), 'chained and unchained hq8 launches differ'
+    dec = torch.zeros(L * Ho * Wo, Cout).cuda()
+    hip.hq8_unpack(outs[1].cuda().view(torch.float32).view(L * Ho * Wo, Cout), dec)
+    emu = TorchOps(torch.float64)
+    ref = emu._conv_hq8(hq8_parts(to_hq8_act(x)), ws.cpu(), bias.cpu(), L, H, W, Cin, Cout, bool(pool), 2.0 ** -shift).float()
+    close(dec, ref, ENC_TOL, 'chained hq8 tiles vs fp64 statement')
+
+
 @pytest.mark.parametrize('which', ['fp8_only', 'fp16_only', 'a8_only', 'al8_only'])
 @pytest.mark.parametrize('pool,L,H,W,Cin,Cout', [(0, 2, 16, 16, 64, 128), (1, 3, 8, 8, 96, 64)])
 def test_conv3x3_hq8_operand_placement(hip, which, pool, L, H, W, Cin, Cout):
@@ -174,3 +203,14 @@ def test_f16q8_unfused_first_layer_matches_golden(monkeypatch):
     with torch.no_grad():
         out = m(*to_dev(case_inputs(c)))
     compare_outputs(out, golden(name), tol=TOL)
+
+
+def test_conv1_fused_hq8_many_tiles_per_workgroup(hip):
+    from mmmot_amd import _lib
+    lib = _lib.load()
+    assert lib.mmmot_set_patch_grid_limit(8) == 0
+    try:
+        test_conv1_fused_hq8(hip, 5, 64, 64)
+        test_conv1_fused_hq8(hip, 3, 32, 48)
+    finally:
+        lib.mmmot_set_patch_grid_limit(0)
