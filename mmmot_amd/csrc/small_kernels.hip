@@ -62,12 +62,14 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(
 // in parallel, ONE pass: S = sum S_t, Q = sum (M2_t + S_t^2 / n_t) in fp64, var = (Q - S^2/n) / n.
 // (The generic kernel walks the tiles once per channel with an 8 KB stride: 0.5 ms for the 16 384 half
 // tiles x 1024 channels of PointNet conv5 at 4 cfg3 pairs.)
-__global__ __launch_bounds__(256) void gn_finalize_perchannel_kernel(
+__global__ __launch_bounds__(1024) void gn_finalize_perchannel_kernel(
     const float* __restrict__ part, const int* __restrict__ grp_tile0, const int* __restrict__ grp_ntiles,
     const int* __restrict__ grp_count, const int* __restrict__ tile_nrows, int ldp, int C,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float* __restrict__ sc,
     float* __restrict__ sh) {
-  __shared__ double red[2][16][16];
+  // 1024 threads = 64 tile stripes x 16 channels: the loop is a chain of dependent-latency trips (2 048 tiles per
+  // group for a PointNet layer at cfg3), so the trip count is what matters, not the arithmetic
+  __shared__ double red[2][64][16];
   const int g = blockIdx.x, c = blockIdx.y * 16 + (threadIdx.x & 15);
   const int stripe = threadIdx.x >> 4;
   const int tile0 = grp_tile0[g], nt = grp_ntiles[g], rows = grp_count[g];
@@ -78,14 +80,14 @@ __global__ __launch_bounds__(256) void gn_finalize_perchannel_kernel(
     return tile_nrows ? tile_nrows[tile0 + ti] : (left < MM_BM ? left : MM_BM);
   };
   // 4 tiles per trip: 12 independent loads in flight per lane (the loop is latency-bound otherwise)
-  for (int ti = stripe; ti < nt; ti += 64) {
+  for (int ti = stripe; ti < nt; ti += 256) {
     int n_t[4];
     float s_t[4], m_t[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) n_t[u] = rows_of(ti + 16 * u);
+    for (int u = 0; u < 4; ++u) n_t[u] = rows_of(ti + 64 * u);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const long t = tile0 + min(ti + 16 * u, nt - 1);
+      const long t = tile0 + min(ti + 64 * u, nt - 1);
       s_t[u] = part[(t * 2 + 0) * ldp + c];
       m_t[u] = part[(t * 2 + 1) * ldp + c];
     }
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256) void gn_finalize_perchannel_kernel(
   if (threadIdx.x < 16) {
     double s = 0.0, q = 0.0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < 64; ++i) {
       s += red[0][i][threadIdx.x];
       q += red[1][i][threadIdx.x];
     }
@@ -123,7 +125,7 @@ extern "C" int mmmot_gn_finalize(const float* part, const int* grp_tile0, const 
   if (!part || !grp_tile0 || !grp_ntiles || !grp_count || !gamma || !beta || !sc || !sh) return MMMOT_EINVAL;
   if (G <= 0 || C <= 0 || NG <= 0 || C % NG != 0 || ldp < C) return MMMOT_EINVAL;
   if (NG == C && C % 16 == 0) {
-    hipLaunchKernelGGL(gn_finalize_perchannel_kernel, dim3(G, C / 16), dim3(256), 0, (hipStream_t)stream, part,
+    hipLaunchKernelGGL(gn_finalize_perchannel_kernel, dim3(G, C / 16), dim3(1024), 0, (hipStream_t)stream, part,
                        grp_tile0, grp_ntiles, grp_count, tile_nrows, ldp, C, gamma, beta, eps, sc, sh);
     return mm_check(hipGetLastError());
   }
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(
   const int row0 = tile_row0[t], nrows = tile_nrows[t];
   const int g = tile_group ? tile_group[t] : 0;
   const int C4 = C >> 2;
-  for (int idx = threadIdx.x; idx < nrows * C4; idx += 256) {
+  for (int idx = threadIdx.x + 256 * blockIdx.y; idx < nrows * C4; idx += 256 * gridDim.y) {
     const int r = idx / C4, c = (idx - r * C4) * 4;
     f32x4 v = *reinterpret_cast<const f32x4*>(&X[(long)(row0 + r) * ldx + c]);
     const f32x4 s4 = *reinterpret_cast<const f32x4*>(&sc[(long)g * ldsc + c]);
@@ -399,7 +401,7 @@ extern "C" int mmmot_affine_act(const float* X, int ldx, int C, const float* sc,
   if (!X || !sc || !sh || !tile_row0 || !tile_nrows || !Y || T <= 0) return MMMOT_EINVAL;
   if (C % 4 != 0 || ldx % 4 != 0 || ldy % 4 != 0 || ldsc % 4 != 0) return MMMOT_EINVAL;
   if (!mm_al16(X) || !mm_al16(Y) || !mm_al16(sc) || !mm_al16(sh)) return MMMOT_EINVAL;
-  hipLaunchKernelGGL(affine_act_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream, X, ldx, C, sc, sh, ldsc,
+  hipLaunchKernelGGL(affine_act_kernel, dim3(T, T < 256 ? 8 : 1), dim3(256), 0, (hipStream_t)stream, X, ldx, C, sc, sh, ldsc,
                      tile_row0, tile_nrows, tile_group, act, Y, ldy);
   return mm_check(hipGetLastError());
 }
@@ -416,7 +418,8 @@ __global__ __launch_bounds__(256) void fusion_combine_kernel(
   const int row0 = tile_row0[t], nrows = tile_nrows[t];
   const int g = tile_group ? tile_group[t] : 0;
   const int C4 = C >> 2;
-  for (int idx = threadIdx.x; idx < nrows * C4; idx += 256) {
+  // gridDim.y workgroups share a tile: one workgroup per 128-row tile is 64 dependent-latency trips on 8 CUs
+  for (int idx = threadIdx.x + 256 * blockIdx.y; idx < nrows * C4; idx += 256 * gridDim.y) {
     const int r = idx / C4, c = (idx - r * C4) * 4;
     const long d = row0 + r;
     const f32x4 fi = *reinterpret_cast<const f32x4*>(&cat[d * 2 * C + c]);
@@ -463,7 +466,7 @@ extern "C" int mmmot_fusion_combine(int mode, const float* cat, const float* Y0,
   if (mode < MMMOT_FUSION_A || mode > MMMOT_FUSION_C) return MMMOT_EINVAL;
   if (mode != MMMOT_FUSION_A && (!Y1 || !sc1 || !sh1)) return MMMOT_EINVAL;
   if (C % 4 != 0 || ld0 % 4 != 0 || ldsc % 4 != 0 || (Y1 && ld1 % 4 != 0)) return MMMOT_EINVAL;
-  hipLaunchKernelGGL(fusion_combine_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream, mode, cat, Y0, ld0, Y1,
+  hipLaunchKernelGGL(fusion_combine_kernel, dim3(T, 16), dim3(256), 0, (hipStream_t)stream, mode, cat, Y0, ld0, Y1,
                      ld1, sc0, sh0, sc1, sh1, ldsc, tile_row0, tile_nrows, tile_group, F, Lt, C);
   return mm_check(hipGetLastError());
 }
