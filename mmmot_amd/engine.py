@@ -41,6 +41,11 @@ class Engine:
         self.pn_gram = os.environ.get('MMMOT_PN_GRAM', '1') != '0'
         # conv1_1 evaluated inside conv1_2's patch prologue (MMMOT_FUSE_CONV1=0: two launches)
         self.fuse_conv1 = os.environ.get('MMMOT_FUSE_CONV1', '1') != '0'
+        # f16q8 applies to crops of at least this side; smaller crops run the f16x3 trunk.  The e4m3 correction
+        # terms cost ~3e-4 of score error at the 64..224-pixel crops of the reference's configurations and more
+        # where less spatial averaging follows the trunk (6e-4 measured at 32-pixel crops, tests/test_hq8_gpu.py),
+        # while the trunk is a negligible part of the step there.
+        self.q8_min_crop = int(os.environ.get('MMMOT_Q8_MIN_CROP', '64'))
         self.mlp = 'f32' if trunk == 'f32' else 'f16x3'  # the 1x1-conv / linear GEMMs: exact fp32 only with the f32 trunk
         if affinity_op not in PAIR_OPS:
             raise ValueError('unknown affinity_op %r' % (affinity_op,))
@@ -107,8 +112,9 @@ class Engine:
         """crops [Lt,3,S,S] NCHW (reference contract) -> cat[:, 0:512]."""
         ops, Lt, S = self.ops, plan.Lt, plan.S
         x, H, W = crops, S, S
-        q8 = (self.trunk == 'f16q8')   # activations travel as hq8 records (fp16 hi + two e4m3 copies, same bytes)
-        f16 = (self.trunk == 'f16x3') or q8  # activations travel in the hl16 split-half format (same bytes)
+        # q8: activations travel as hq8 records (fp16 hi + two e4m3 copies, same bytes)
+        q8 = (self.trunk == 'f16q8') and S >= self.q8_min_crop
+        f16 = self.trunk in ('f16x3', 'f16q8')  # activations travel in the hl16 split-half / hq8 format (same bytes)
         vgg = self.P['vgg']
         # conv1_1 + conv1_2 + pool as one launch when the trunk has the VGG16 head (3 -> 64 -> 64, pool)
         fuse1 = (f16 and (q8 or self.conv_impl == 'patch') and self.fuse_conv1 and len(vgg) > 1 and vgg[0]['cout'] == 64 and

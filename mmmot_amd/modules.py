@@ -328,7 +328,8 @@ class TrackingNet(nn.Module):
 
     def set_trunk(self, trunk):
         """'f16q8' (default): VGG trunk with the fp16 main term on the fp16 matrix cores and both hi/lo correction
-        terms in one block-scaled fp8 MFMA (score error <= 3e-4, budget 1e-3);
+        terms in one block-scaled fp8 MFMA (score error <= 3.3e-4 on the reference's configurations, budget 1e-3;
+        crops smaller than Engine.q8_min_crop = 64 pixels run the f16x3 trunk);
         'f16x3': all three terms on the fp16 matrix cores (fp32-class, score error ~3e-5);
         'f32': exact fp32 MFMA everywhere."""
         self.trunk = trunk

@@ -187,6 +187,7 @@ def test_f16q8_forward_matches_reference_golden(name):
     c, base = get_case(name)
     m = build_model(c, base, device='cuda')
     m.set_trunk('f16q8')
+    m.engine().q8_min_crop = 0  # the fixtures include 32-pixel crops: exercise the e4m3 arithmetic on them too
     assert m.engine().ops.name == 'hip' and m.engine().trunk == 'f16q8'
     with torch.no_grad():
         out = m(*to_dev(case_inputs(c)))
@@ -200,6 +201,7 @@ def test_f16q8_unfused_first_layer_matches_golden(monkeypatch):
     c, base = get_case(name)
     m = build_model(c, base, device='cuda')
     m.set_trunk('f16q8')
+    m.engine().q8_min_crop = 0
     with torch.no_grad():
         out = m(*to_dev(case_inputs(c)))
     compare_outputs(out, golden(name), tol=TOL)
@@ -214,3 +216,59 @@ def test_conv1_fused_hq8_many_tiles_per_workgroup(hip):
         test_conv1_fused_hq8(hip, 3, 32, 48)
     finally:
         lib.mmmot_set_patch_grid_limit(0)
+
+
+SURVEY = [  # (fusion, affinity, softmax, N, M, S, pts)
+    ('A', 'multiply', 'none', 4, 6, 224, 100), ('B', 'multiply', 'none', 10, 12, 128, 200),
+    ('C', 'multiply', 'none', 16, 16, 64, 128), ('C', 'minus_abs', 'dual_add', 2, 30, 96, 40),
+    ('C', 'minus_abs', 'dual_add', 25, 3, 160, 64), ('A', 'minus_abs', 'single', 7, 7, 32, 300),
+    ('B', 'multiply', 'dual', 12, 5, 192, 16), ('C', 'multiply', 'dual_max', 1, 1, 224, 2000),
+    ('C', 'multiply', 'none', 32, 32, 32, 64), ('A', 'multiply', 'none', 3, 3, 256, 500),
+]
+
+
+@pytest.mark.parametrize('fusion,aff,sm,N,M,S,pts', SURVEY)
+def test_f16q8_fresh_inputs_against_oracle(fusion, aff, sm, N, M, S, pts):
+    """the default trunk arithmetic carries e4m3 correction terms: beyond the golden fixtures, fresh seeds / crop
+    sizes / ragged point counts against the CPU oracle, every output within the 1e-3 budget (margins are printed)"""
+    from mmmot_amd.synth import make_pair
+    from oracle import restatement as R
+    c, base = get_case('s2_C_minus_abs_dual_add')
+    c = dict(c, fusion=fusion, aff=aff, sm=sm)
+    m = build_model(c, base)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.to('cuda')
+    assert m.trunk == 'f16q8'
+    m.engine().q8_min_crop = 0  # force the e4m3 arithmetic below the default minimum crop side as well
+    cfg = dict(fusion=fusion, affinity_op=aff, softmax_mode=sm, neg_threshold=base['neg_threshold'],
+               score_arch=base['score_arch'])
+    worst = {}
+    for seed in (0, 1):
+        dets, info, ds = make_pair(N, M, S, pts, seed=900 + 7 * seed + N + M, ragged=True)
+        with torch.no_grad():
+            ref = R.tracking_forward(sd, cfg, dets, info['points'], info['points_split'], [N, M])
+            out = m(*to_dev((dets, info, ds)))
+        for a, b, what in ((out[0], ref[0], 'det'), (out[1][0], ref[1][0], 'link'), (out[2], ref[2], 'new'),
+                           (out[3], ref[3], 'end')):
+            err = (a.cpu() - b).abs().max().item()
+            worst[what] = max(worst.get(what, 0.0), err)
+            assert err < TOL, (seed, what, err)
+    print('f16q8 %s/%s/%s N=%d M=%d S=%d pts=%d: %s' % (fusion, aff, sm, N, M, S, pts,
+                                                      {k: '%.1e' % v for k, v in worst.items()}))
+
+
+def test_f16q8_small_crops_use_the_f16x3_trunk():
+    """default policy: crops below 64 pixels run the fp32-class trunk (f16q8 would cost up to 6e-4 there)"""
+    name = 's1_C_multiply_none'
+    c, base = get_case(name)
+    assert c['S'] < 64
+    outs = []
+    for trunk in ('f16q8', 'f16x3'):
+        m = build_model(c, base, device='cuda')
+        m.set_trunk(trunk)
+        assert m.engine().q8_min_crop == 64
+        with torch.no_grad():
+            outs.append(m(*to_dev(case_inputs(c))))
+    for a, b in zip(outs[0][:1] + tuple(outs[0][1]) + outs[0][2:4], outs[1][:1] + tuple(outs[1][1]) + outs[1][2:4]):
+        assert torch.equal(a, b), 'f16q8 below the minimum crop side must be the f16x3 path'
+    compare_outputs(outs[0], golden(name), tol=TOL)
