@@ -12,7 +12,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
-LIB_PATH = os.path.join(_HERE, 'libmmmot_hip.so')
+LIB_PATH = os.environ.get('MMMOT_LIB_PATH', os.path.join(_HERE, 'libmmmot_hip.so'))  # override: tools' timing-experiment builds
 SOURCES = ['conv3x3.hip', 'conv3x3_hl16.hip', 'conv3x3_hl16_dma.hip', 'conv3x3_hl16_patch.hip', 'gemm_rows.hip',
            'gemm_ares.hip', 'gram.hip', 'points_gather.hip', 'crop_resize.hip', 'small_kernels.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
