@@ -66,6 +66,9 @@ extern "C" {
 #define MMMOT_FUSION_C 2
 
 /* library / device info -------------------------------------------------- */
+/* ABI history: 1 = first round-1 cut; 2 = gemm colsum / gemm_ares / gram / points / crops entry points,
+ * gn_finalize tile_nrows, segment_mean seg_div; 3 = hq8 arithmetic (mmmot_conv3x3_bn_relu_hq8, mmmot_conv1_fused_hq8,
+ * mmmot_hq8_pack/unpack, mmmot_segment_mean hl16 = 2), patch-kernel test / timing knobs. */
 int mmmot_abi_version(void);
 /* returns 0 and fills cu_count / gcn arch string (<=32 bytes) of device 0..; */
 int mmmot_device_info(int device, int* cu_count, char* arch, int arch_len);
