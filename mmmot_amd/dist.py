@@ -79,9 +79,9 @@ def gather_results(results, group=None, same_layout=False):
     """Per-rank list of per-sample results -> list over ALL samples in global (rank-major) order.
     ``same_layout=True`` (every rank holds identically shaped samples, e.g. the synthetic
     benchmark) skips the python-object exchange of shapes: one length + one data collective."""
-    flat, layout = flatten_results(results)
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return unflatten_results(flat, layout)
+        return list(results)  # single process: the results already are the global list (no packing, no copy)
+    flat, layout = flatten_results(results)
     world = dist.get_world_size(group)
     if same_layout:
         layouts = [layout] * world
