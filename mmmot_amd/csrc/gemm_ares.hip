@@ -68,79 +68,103 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
   if (t >= a.T) return;
   TileMeta cur = meta_of(t);
 
-  // ---- weight stage loader: thread -> (channel row = tid >> 2, units 2q, 2q+1 of the 8 in a 64-k stage) ----
-  const int wrow = tid >> 2, wq = tid & 3;
+  // ---- wave roles.  vmcnt retires in order PER WAVE: activation rows (HBM, a CU completes only ~30 line misses
+  // per microsecond) requested by a wave that also stages weights sit in front of every weight-stage wait, and
+  // requested late they arrive late (0.26 ms of 0.99 at N = 1024 was tile-switch time).  So waves 0-3 stream the
+  // weights (L2 hits) and waves 4-7 fetch the NEXT tile's activation rows a whole tile ahead, each group with its
+  // own queue.  Both views share one set of staging registers (a wave uses one of them).
+  const bool wspec = wave < 4;
+  u32x4 stg[16];
+  // weights: thread tw -> (channel rows tw >> 2 and (tw >> 2) + 64, units 2q, 2q+1 of the 8 in a 64-k stage)
+  const int wrow = (tid & 255) >> 2, wq = tid & 3;
   const u32x4* wp = reinterpret_cast<const u32x4*>(a.W);
   const long ku = (long)(a.K >> 3);  // hl16 units per weight row
-  u32x4 rw[2][4];                    // two stages in flight; hi, lo of two units each
-  auto load_w = [&](int s, auto SLOT) {
+  auto load_w = [&](int s, auto SLOT) {  // two stages in flight: slot = stage & 1
     constexpr int sl = decltype(SLOT)::value;
     const int nt = s / KS, ks = s - nt * KS;
-    const u32x4* p = wp + ((long)(nt * AR_BN + wrow) * ku + ks * 8 + wq * 2) * 2;
-    rw[sl][0] = p[0];
-    rw[sl][1] = p[1];
-    rw[sl][2] = p[2];
-    rw[sl][3] = p[3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const u32x4* p = wp + ((long)(nt * AR_BN + wrow + 64 * r) * ku + ks * 8 + wq * 2) * 2;
+      stg[sl * 8 + 4 * r + 0] = p[0];
+      stg[sl * 8 + 4 * r + 1] = p[1];
+      stg[sl * 8 + 4 * r + 2] = p[2];
+      stg[sl * 8 + 4 * r + 3] = p[3];
+    }
   };
   auto store_w = [&](int buf, auto SLOT) {
     constexpr int sl = decltype(SLOT)::value;
-    _Float16* bh = &Bs[buf][0][wrow * AR_LDT + wq * 16];
-    _Float16* bl = &Bs[buf][1][wrow * AR_LDT + wq * 16];
-    *reinterpret_cast<u32x4*>(bh) = rw[sl][0];
-    *reinterpret_cast<u32x4*>(bl) = rw[sl][1];
-    *reinterpret_cast<u32x4*>(bh + 8) = rw[sl][2];
-    *reinterpret_cast<u32x4*>(bl + 8) = rw[sl][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      _Float16* bh = &Bs[buf][0][(wrow + 64 * r) * AR_LDT + wq * 16];
+      _Float16* bl = &Bs[buf][1][(wrow + 64 * r) * AR_LDT + wq * 16];
+      *reinterpret_cast<u32x4*>(bh) = stg[sl * 8 + 4 * r + 0];
+      *reinterpret_cast<u32x4*>(bl) = stg[sl * 8 + 4 * r + 1];
+      *reinterpret_cast<u32x4*>(bh + 8) = stg[sl * 8 + 4 * r + 2];
+      *reinterpret_cast<u32x4*>(bl + 8) = stg[sl * 8 + 4 * r + 3];
+    }
   };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
 
-  // ---- activation rows: raw rows -> registers (load_x), normalise + ReLU + hi/lo split -> LDS (stage_a) ------
-  // thread -> (row = tid >> 2, quarter q of the K axis: 16 * KS consecutive channels)
-  const int ar = tid >> 2, aq = tid & 3;
-  f32x4 xr[2 * KS][2];
+  // ---- activation rows (waves 4-7): raw rows -> registers (load_x), normalise + ReLU + hi/lo split -> LDS (stage_a)
+  // thread tx -> (rows tx >> 2 and (tx >> 2) + 64, quarter q of the K axis: 16 * KS consecutive channels)
+  const int ar = (tid & 255) >> 2, aq = tid & 3;
   auto load_x = [&](const TileMeta& m) {
-    const float* px = a.X + (long)(m.row0 + (ar < m.nrows ? ar : 0)) * a.ldx + aq * (16 * KS);
 #pragma unroll
-    for (int u = 0; u < 2 * KS; ++u) {
-      xr[u][0] = *reinterpret_cast<const f32x4*>(px + 8 * u);
-      xr[u][1] = *reinterpret_cast<const f32x4*>(px + 8 * u + 4);
+    for (int r = 0; r < 2; ++r) {
+      const int row = ar + 64 * r;
+      const float* px = a.X + (long)(m.row0 + (row < m.nrows ? row : 0)) * a.ldx + aq * (16 * KS);
+#pragma unroll
+      for (int u = 0; u < 2 * KS; ++u) {
+        stg[r * 4 * KS + 2 * u] = *reinterpret_cast<const u32x4*>(px + 8 * u);
+        stg[r * 4 * KS + 2 * u + 1] = *reinterpret_cast<const u32x4*>(px + 8 * u + 4);
+      }
     }
   };
   auto stage_a = [&](const TileMeta& m) {
-    const bool rv = ar < m.nrows;
     const float* psc = a.sc + (long)m.grp * a.ldsc + aq * (16 * KS);
     const float* psh = a.sh + (long)m.grp * a.ldsc + aq * (16 * KS);
 #pragma unroll
-    for (int u = 0; u < 2 * KS; ++u) {  // 8-channel units of this thread
-      const f32x4 x0 = xr[u][0], x1 = xr[u][1];
-      const f32x4 s0 = *reinterpret_cast<const f32x4*>(psc + 8 * u), s1 = *reinterpret_cast<const f32x4*>(psc + 8 * u + 4);
-      const f32x4 h0 = *reinterpret_cast<const f32x4*>(psh + 8 * u), h1 = *reinterpret_cast<const f32x4*>(psh + 8 * u + 4);
-      f16x8 hi, lo;
+    for (int r = 0; r < 2; ++r) {
+      const int row = ar + 64 * r;
+      const bool rv = row < m.nrows;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float y0 = fminf(fmaxf(fmaf(x0[e], s0[e], h0[e]), 0.f), 65000.f);
-        float y1 = fminf(fmaxf(fmaf(x1[e], s1[e], h1[e]), 0.f), 65000.f);
-        if (!rv) y0 = y1 = 0.f;
-        hi[e] = (_Float16)y0;
-        lo[e] = (_Float16)(y0 - (float)hi[e]);
-        hi[4 + e] = (_Float16)y1;
-        lo[4 + e] = (_Float16)(y1 - (float)hi[4 + e]);
+      for (int u = 0; u < 2 * KS; ++u) {  // 8-channel units of this thread
+        const f32x4 x0 = __builtin_bit_cast(f32x4, stg[r * 4 * KS + 2 * u]);
+        const f32x4 x1 = __builtin_bit_cast(f32x4, stg[r * 4 * KS + 2 * u + 1]);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(psc + 8 * u), s1 = *reinterpret_cast<const f32x4*>(psc + 8 * u + 4);
+        const f32x4 h0 = *reinterpret_cast<const f32x4*>(psh + 8 * u), h1 = *reinterpret_cast<const f32x4*>(psh + 8 * u + 4);
+        f16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float y0 = fminf(fmaxf(fmaf(x0[e], s0[e], h0[e]), 0.f), 65000.f);
+          float y1 = fminf(fmaxf(fmaf(x1[e], s1[e], h1[e]), 0.f), 65000.f);
+          if (!rv) y0 = y1 = 0.f;
+          hi[e] = (_Float16)y0;
+          lo[e] = (_Float16)(y0 - (float)hi[e]);
+          hi[4 + e] = (_Float16)y1;
+          lo[4 + e] = (_Float16)(y1 - (float)hi[4 + e]);
+        }
+        const int k = aq * (16 * KS) + 8 * u;  // channel of the unit
+        const int ks = k / AR_BK, kk = k - ks * AR_BK;
+        *reinterpret_cast<f16x8*>(&As[ks][0][row * AR_LDT + kk]) = hi;
+        *reinterpret_cast<f16x8*>(&As[ks][1][row * AR_LDT + kk]) = lo;
       }
-      const int k = aq * (16 * KS) + 8 * u;  // channel of the unit
-      const int ks = k / AR_BK, kk = k - ks * AR_BK;
-      *reinterpret_cast<f16x8*>(&As[ks][0][ar * AR_LDT + kk]) = hi;
-      *reinterpret_cast<f16x8*>(&As[ks][1][ar * AR_LDT + kk]) = lo;
     }
   };
-  load_x(cur);
-  stage_a(cur);
+  if (!wspec) {
+    load_x(cur);
+    stage_a(cur);
+  }
   // weight stages: s -> register slot s & 1; two stages of global loads are always in flight (one LDS
   // stage of latency is not enough: the L2 round trip under load is longer than a 24-MFMA stage)
   auto prime_w = [&]() {
-    load_w(0, S0{});
-    load_w(1 % NS, S1{});
-    store_w(0, S0{});
-    load_w(2 % NS, S0{});
+    if (wspec) {
+      load_w(0, S0{});
+      load_w(1 % NS, S1{});
+      store_w(0, S0{});
+      load_w(2 % NS, S0{});
+    }
     __syncthreads();
   };
   prime_w();
@@ -192,12 +216,16 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
       const bool last_nt = nt + 1 >= ntn;  // then: first channel tile of the next row tile (same loads, other rows)
       TileMeta m = cur;
       if (last_nt) m = nxt;
+      // (handing these constants from waves 0-3 to waves 4-7 through LDS, so that they do not queue behind the
+      // activation rows, measured slower than loading them in every wave)
       epi_consts(m, last_nt ? 0 : nt + 1, cbn, osc_n, osh_n);
     }
     // stage s+1 (register slot !odd) -> the other LDS buffer (last read in stage s-1, every wave is past
     // that barrier); then its slot takes the loads of stage s+3
-    store_w(1 - odd, std::integral_constant<int, 1 - odd>{});
-    load_w((s + 3) % NS, std::integral_constant<int, 1 - odd>{});  // wraps into the next row tile
+    if (wspec) {
+      store_w(1 - odd, std::integral_constant<int, 1 - odd>{});
+      load_w((s + 3) % NS, std::integral_constant<int, 1 - odd>{});  // wraps into the next row tile
+    }
     // Four 16-channel steps; the fragments of step j+1 are read while the six MFMAs of step j issue, one
     // read per MFMA (sched_barrier pins the order): the two waves of a SIMD run in lockstep after every
     // barrier, so an LDS round trip that is not covered by this wave's own MFMAs is idle matrix-pipe time.
@@ -329,16 +357,16 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
     const int tn = t + gridDim.x;
     const bool more = tn < a.T;
     if (more) nxt = meta_of(tn);
-    // the next tile's rows are requested two stages before the end of this tile
-    const int s_fetch = NS >= 3 ? NS - 3 : 0;
+    // the next tile's rows are requested at the first stage of this tile (waves 4-7: nothing else in their queue
+    // but the small per-channel constants)
     for (int s = 0; s < NS; s += 2) {
-      if (more && (s == (s_fetch & ~1))) load_x(nxt);
+      if (more && !wspec && s == 0) load_x(nxt);
       stage(s, S0{});
       if (s + 1 < NS) stage(s + 1, S1{});
     }
     if (!more) break;
     // tile switch: every wave is past the barrier that ended the last stage, As is free
-    stage_a(nxt);
+    if (!wspec) stage_a(nxt);
     if (wrap_ok) __syncthreads();
     else prime_w();  // odd stage count: the buffer parity restarts, re-prime the weight pipeline
     cur = nxt;
