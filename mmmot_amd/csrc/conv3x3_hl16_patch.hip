@@ -991,8 +991,9 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
       compute_poff(mt_next);
     }
   }
-  if constexpr (FUSE1) __syncthreads();  // the staging area is overwritten by the next tile's prologue (raw window: vmcnt)
-  else pt_lds_barrier();                 // the staging area is the successor's next patch buffer
+  // LDS-only: the staging area is the successor's next patch buffer (FUSE1: the next tile's raw window / patches);
+  // the tile's own stores drain under the next tile, the raw-window registers are waited for where they are used
+  pt_lds_barrier();
   PT_STAMP(5)
   if constexpr (EXP == 9 || EXP == 10) {
     if (threadIdx.x == 0) atomicAdd(&pt_dbg[7], 1ull);
