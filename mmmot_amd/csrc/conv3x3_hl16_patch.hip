@@ -192,7 +192,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   static_assert(FUSE1 ? (SROWS * CLD * 4 <= LOOP_BYTES) : (RCH * CLD * 4 <= G::BYTES), "epilogue staging does not fit");
   // STREAM: tiles are chained through transition slabs.  The successor's patch source table is made during the
   // tile's own prologue (low register pressure) and parked in LDS: [PA][512] words behind the ring.  The 8x8-block
-  // variants have no room for it (and run 1-2 tiles per workgroup): they keep a load prologue per tile.
+  // variants have no room for it: they chain only onto a successor with the same pixel tile (same table).
   constexpr bool STREAM = !FUSE1 && G::NB == 1;
   constexpr int POFF_OFF = LOOP_BYTES + RAW_BYTES;
   constexpr int SMEM = POFF_OFF + (STREAM ? G::PA * 512 * 4 : 0);
@@ -550,11 +550,10 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
       pk[5 * 512] = poff_round(std::integral_constant<int, 5>{}, tb);
       if constexpr (G::PA > 6) pk[6 * 512] = poff_round(std::integral_constant<int, 6>{}, tb);
     }
-  } else {
-    pcur = P0_OFF;
-    pnext = P1_OFF;
   }
   if constexpr (FUSE1) {
+    pcur = P0_OFF;
+    pnext = P1_OFF;
     issue_b(0, 0, 0);  // conv1_2's weight ring flies while the patch is computed
     issue_b(1, 0, 1);
     issue_b(2, 0, 2);
@@ -762,7 +761,9 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     stage(std::integral_constant<int, 8>{}, LASTC, slab, pslab, wb2, ws2);
   };
   // slabs 0 .. nslab-2 are interior; the last one is a transition slab when the tile has a successor
-  const bool chain = STREAM && has_next;
+  // 8x8-block variants (no LDS room to park a table): chained when the successor works on the same pixel tile
+  // (another channel tile of it - the usual order inside an XCD's chunk), whose table is the one in registers
+  const bool chain = !FUSE1 && has_next && (G::NB == 1 || mt_next == mt);
   if (chain) wbase_next = wp + (long)(nt_next * BN) * (cin8 * 2);
   const int nloop = chain ? nslab : nslab - 1;
   for (int slab = 0; slab < nloop; ++slab) {
@@ -981,12 +982,12 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   mt = mt_next;
   nt = nt_next;
   wbase = wbase_next;
-  if constexpr (STREAM) {  // the successor's slab 0 sits in pnext
-    const int t = pcur;
-    pcur = pnext;
-    pnext = t;
-  } else if constexpr (!FUSE1) {
-    if (has_next) {
+  if constexpr (!FUSE1) {
+    if (chain) {  // the successor's slab 0 sits in pnext
+      const int t = pcur;
+      pcur = pnext;
+      pnext = t;
+    } else if (has_next) {  // (8x8-block variants only) another pixel tile: it starts with a load prologue
       wbase = wp + (long)(nt_next * BN) * (cin8 * 2);
       compute_poff(mt_next);
     }
