@@ -8,42 +8,59 @@ Metric (BASELINE.json): frame-pairs/sec of the full eval-mode
 N_det=64 configuration the metric is quoted on, ``configs[2]`` (= SURVEY cfg3):
 Fusion C, N=M=64 (128 crops of 128x128), 2048 LiDAR points per detection.
 One step = one pass of the hot path over one batch of ``--pairs`` synthetic
-frame pairs per GPU.  Multi-GPU: one process per GPU (torch.distributed, RCCL),
-samples sharded, no data-path collective, one flat result gather per step
-(weak scaling: per-GPU work is fixed).
+frame pairs per GPU.
+
+Multi-GPU: one process per GPU (torch.distributed, RCCL), samples sharded, no
+data-path collective, one flat result gather per step (weak scaling: per-GPU
+work is fixed).  ``python bench.py --gpus N`` launched WITHOUT a distributed
+environment re-executes itself under ``torch.distributed.run --nproc-per-node N``
+(127.0.0.1 rendezvous, a free port); launched by torchrun it reads
+RANK / LOCAL_RANK / WORLD_SIZE from the environment.  ``--dry`` runs the same
+launcher / shard / gather / timing / JSON code on CPU tensors over gloo with a
+stub step (no kernel runs; covered by tests/test_dist_cpu.py).
+
+Arithmetic legs.  The headline (``value``, ``dtype``, ``roofline``) is the
+``--trunk`` mode, by default ``f16x3`` - the fp32-class arithmetic (3-term fp16
+hi/lo split, 22 significand bits, score error ~3e-5 against the fp32 reference).
+The same run then times the other trunk mode(s) of ``--extra-trunks`` with the
+same warm-up / step counts and reports them under ``extra`` (``f16q8``: both
+correction terms on the fp8 matrix cores, score error ~3e-4 of the 1e-3 budget).
 
 Prints ONE JSON line on rank 0 with the contract fields plus
-  roofline     - the dominant kernel (conv3x3 implicit GEMM; f16 MFMA with the 3-term hi/lo split by
-                 default, fp32 MFMA with --trunk f32), measured with HIP events around every trunk
-                 launch inside the timed region; traffic from the committed PMC passes
+  roofline     - the dominant kernel (VGG trunk implicit GEMM), measured with HIP events around every
+                 trunk launch inside the timed region; traffic from the committed PMC passes
   cpu_baseline - the oracle (CPU restatement of the reference) on the host cores
+  parity       - L-inf of pair 0 against the committed output of the IMPORTED reference (tests/golden/f_*.npz,
+                 same seed) and of the CPU-baseline pairs against the oracle
+  extra        - the other arithmetic legs; latency of one reference-shaped call (B=1, cfg1 shape)
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
+import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from mmmot_amd import TrackingNet  # noqa: E402
-from mmmot_amd.dist import gather_results  # noqa: E402
+from mmmot_amd.dist import gather_results, shard_range  # noqa: E402
 from mmmot_amd.synth import make_pair  # noqa: E402
-from mmmot_amd.weights import init_module  # noqa: E402
 
 METRIC = 'frame-pairs/sec (fusion+affinity fwd) at N_det=64; affinity L∞ vs CPU ref'
 WORKLOADS = {
-    # name: (fusion, affinity_op, softmax_mode, N, M, S, pts/det)
-    'cfg3': ('C', 'multiply', 'none', 64, 64, 128, 2048),
-    'cfg2': ('A', 'multiply', 'none', 32, 32, 64, 512),
-    'cfg4': ('C', 'minus_abs', 'dual_add', 128, 128, 64, 512),
-    'tiny': ('C', 'multiply', 'none', 6, 5, 32, 40),
+    # name: (fusion, affinity_op, softmax_mode, N, M, S, pts/det, reference golden of the pair with seed 1000)
+    'cfg3': ('C', 'multiply', 'none', 64, 64, 128, 2048, 'f_cfg3_C'),
+    'cfg2': ('A', 'multiply', 'none', 32, 32, 64, 512, None),
+    'cfg4': ('C', 'minus_abs', 'dual_add', 128, 128, 64, 512, 'f_cfg4_C'),
+    'tiny': ('C', 'multiply', 'none', 6, 5, 32, 40, None),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide: BF16/F16 MFMA dense peak (AMD's 5 PF figure is 2:1 sparse)
+HEADLINE_TRUNK = 'f16x3'       # fp32-class arithmetic: what `value` is measured in unless --trunk says otherwise
 BASE_KW = dict(seq_len=2, score_arch='branch_cls', appear_arch='vgg', appear_len=512, appear_skippool=True,
                appear_fpn=False, point_arch='v1', point_len=512, without_reflectivity=True, end_arch='v2',
                end_mode='avg', test_mode=2, neg_threshold=0.2, dropblock=0, use_dropout=False)
@@ -57,109 +74,91 @@ def reference_flops_per_pair(N, M, S, P, fusion):
                 3 * N * M * 852096 + 3 * L * 327808)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=6)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='cfg3', choices=sorted(WORKLOADS))
     ap.add_argument('--pairs', type=int, default=8, help='frame pairs per step per GPU')
-    ap.add_argument('--cpu-pairs', type=int, default=2, help='timed pairs of the CPU baseline (0 disables)')
+    ap.add_argument('--cpu-pairs', type=int, default=3, help='timed pairs of the CPU baseline (0 disables)')
     ap.add_argument('--no-gather', action='store_true')
     ap.add_argument('--graph', action='store_true', help='capture the launch sequence of one step in a hipGraph and replay it')
-    ap.add_argument('--trunk', default='f16q8', choices=['f16q8', 'f16x3', 'f32'],
-                    help="VGG trunk arithmetic: fp16 matrix cores with 3-term hi/lo split (fp32-class), or exact fp32 MFMA")
-    args = ap.parse_args()
+    ap.add_argument('--trunk', default=HEADLINE_TRUNK, choices=['f16q8', 'f16x3', 'f32'],
+                    help="headline VGG trunk arithmetic: f16x3 = fp16 matrix cores, 3-term hi/lo split (fp32-class); "
+                         "f16q8 = fp16 main term + fp8 correction terms; f32 = exact fp32 MFMA")
+    ap.add_argument('--extra-trunks', default=None,
+                    help="comma list of further trunk modes timed in the same run and reported under 'extra' "
+                         "(default: the other one of f16x3 / f16q8; 'none' disables)")
+    ap.add_argument('--no-latency', action='store_true', help='skip the B=1 reference-call latency extra')
+    ap.add_argument('--dry', action='store_true',
+                    help='CPU / gloo dry run of the launcher, sharding, gather, timing and JSON with a stub step')
+    return ap.parse_args(argv)
 
-    rank = int(os.environ.get('RANK', 0))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
 
-    fusion, aff, sm, N, M, S, pts = WORKLOADS[args.workload]
-    model = TrackingNet(**dict(BASE_KW, score_fusion_arch=fusion, affinity_op=aff, softmax_mode=sm))
-    init_module(model, seed=0)
-    model.eval().to(dev)
-    model.set_trunk(args.trunk)
-    eng = model.engine()
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` without a distributed environment: become N ranks on this node."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault('OMP_NUM_THREADS', '8')
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, env)
 
-    # synthetic batch: distinct seeds per (rank, pair); inputs resident in HBM before timing
-    B = args.pairs
-    ins = [make_pair(N, M, S, pts, seed=1000 + rank * B + i) for i in range(B)]
-    samples = [([N, M], x[1]['points_split'].reshape(-1).long().numpy()) for x in ins]
-    plan = model.make_plan(samples, S)
-    crops = torch.cat([x[0] for x in ins]).to(dev)
-    points = torch.cat([x[1]['points'].reshape(-1, 3) for x in ins]).to(dev)
-    torch.cuda.synchronize()
 
-    def step():
-        res = model.forward_batch(plan, crops, points)
-        if not args.no_gather:
-            res = gather_results(res, same_layout=True)  # trivial for world == 1
-        return res
+def stub_results(pairs, N, M, seed0):
+    """--dry: reference-shaped per-sample results from a seed (no kernel, no oracle)."""
+    out = []
+    for i in range(pairs):
+        g = torch.Generator().manual_seed(seed0 + i)
+        L = N + M
+        out.append((torch.rand(3, L, generator=g), [torch.rand(3, N, M, generator=g)], torch.rand(3, L, generator=g),
+                    torch.rand(3, L, generator=g)))
+    return out
 
-    for _ in range(args.warmup):
-        step()
-    if args.graph:
-        # the C-ABI entry points only launch (no allocation, no synchronisation): the whole step is capturable
-        eager_step = step
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            graph_res = eager_step()
 
-        def step():  # noqa: F811
-            graph.replay()
-            return graph_res
-        step()
-
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    eng.conv_events = []
+def time_steps(step, steps, barrier):
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    res = None
+    for _ in range(steps):
         res = step()
     barrier()
-    dt = time.perf_counter() - t0
-    events, eng.conv_events = eng.conv_events, None
+    return time.perf_counter() - t0, res
 
+
+def max_over_ranks(dt, world, dev):
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+    return dt
 
-    # ---- roofline of the dominant kernel (rank-local; HIP events on the launch stream) ----
+
+def roofline_of(trunk, events, eng, B, workload, dt):
+    """Roofline entry of the dominant kernel from the HIP events recorded around every trunk launch."""
     per_layer = {}
     for li, rows, cin, cout, e0, e1 in events:
         ms = e0.elapsed_time(e1)
-        fl = 2.0 * rows * 9 * cin * cout
         a = per_layer.setdefault(li, [0.0, 0.0, 0, rows, cin, cout])
         a[0] += ms
-        a[1] += fl
+        a[1] += 2.0 * rows * 9 * cin * cout
         a[2] += 1
     trunk_ms = sum(a[0] for a in per_layer.values())
-    if args.trunk == 'f16x3':
-        # dominant kernel = the hl16 trunk kernel (layers 1..12); layer 0 (Cin=3) runs the fp32-MFMA kernel
+    if trunk == 'f16x3':
+        # dominant kernel = the hl16 trunk kernel (layers 1..12); conv1_1 (Cin=3) is computed in the first launch's prologue
         dom = {li: a for li, a in per_layer.items() if li != 0}
-        kname = '%s (VGG16-BN trunk layers 2-13, 12 launches/step)' % {
-            'patch': 'conv3x3_hl16_patch_kernel', 'tile': 'conv3x3_hl16_kernel', 'dma': 'conv3x3_hl16_dma_kernel'}[eng.conv_impl]
+        kname = 'conv3x3_hl16_patch_kernel (VGG16-BN trunk layers 2-13, 12 launches/step)'
         peak = PEAK_F16_MFMA_TFLOPS / 3.0
         peak_basis = ('%.0f TFLOP/s dense f16 MFMA / 3 MFMAs per algorithmic product (a_hi*w_hi + a_hi*w_lo + '
                       'a_lo*w_hi, fp32 accumulate)' % PEAK_F16_MFMA_TFLOPS)
-    elif args.trunk == 'f16q8':
+    elif trunk == 'f16q8':
         dom = {li: a for li, a in per_layer.items() if li != 0}
         kname = 'conv3x3_hl16_patch_kernel<Q8> (VGG16-BN trunk layers 2-13, 12 launches/step)'
         peak = PEAK_F16_MFMA_TFLOPS / 2.0
@@ -175,13 +174,12 @@ def main():
     conv_fl = sum(a[1] for a in dom.values())
     n_launch = sum(a[2] for a in dom.values())
     achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0  # 0 with --graph: replays record no events
-
     # HBM/fabric bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process,
     # so the figure comes from the committed rocprofv3 --pmc passes of this same command (profiles/traffic.json).
     traffic, traffic_src = None, None
     try:
         with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
-            tr = json.load(f).get('%s/%s' % (args.workload, args.trunk))
+            tr = json.load(f).get('%s/%s' % (workload, trunk))
         if tr:
             traffic = round((tr['fetch_bytes_per_pair'] + tr['write_bytes_per_pair']) * B / tr['launches_per_step'])
             traffic_src = tr['source']
@@ -190,79 +188,267 @@ def main():
     # algorithmic bytes per launch: every layer reads its input and weights once and writes its output once (4 B/value)
     alg_bytes = sum((a[3] * a[4] + (a[3] // (4 if li in (1, 3, 6, 9, 12) else 1)) * a[5] + 9 * a[4] * a[5]) * 4.0
                     for li, a in dom.items()) / max(len(dom), 1)
+    roof = {'bound': 'mfma', 'kernel': kname, 'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+            'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_unit': 'bytes/launch (mean)',
+            'traffic_source': traffic_src, 'algorithmic_bytes_per_launch': round(alg_bytes), 'peak_basis': peak_basis,
+            'avg_launch_ms': round(conv_ms / max(n_launch, 1), 4), 'trunk_share_of_step': round(trunk_ms / (dt * 1e3), 4),
+            'flops_basis': 'algorithmic 2*9*Cin*Cout per output pixel (conv1_1 counted at Cin=3)'}
+    layers = {str(li): dict(ms_per_launch=a[0] / a[2], tflops=a[1] / (a[0] * 1e-3) / 1e12 if a[0] else 0, rows=a[3],
+                            cin=a[4], cout=a[5]) for li, a in sorted(per_layer.items())}
+    return roof, layers
 
-    pairs_total = args.steps * B * world
-    value = pairs_total / dt
+
+def golden_linf(res0, name):
+    """L-inf of one sample's (det, links, new, end) against the committed output of the imported reference."""
+    path = os.path.join(ROOT, 'tests', 'golden', name + '.npz')
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    det, links, new, end = res0
+    return float(max(np.abs(det.cpu().numpy() - g['det']).max(), np.abs(links[0].cpu().numpy() - g['link0']).max(),
+                     np.abs(new.cpu().numpy() - g['new']).max(), np.abs(end.cpu().numpy() - g['end']).max()))
+
+
+def cpu_baseline(model, ins, res, fusion, aff, sm, N, M, n_timed):
+    """The oracle (CPU restatement of the reference) on the host cores: >= 3 timed pairs after one warm-up pair,
+    batch-1 loop like the reference (eval_seq.py:153), median s/pair.  Thread count: all cores is NOT the fastest
+    on a many-core host (256 threads: 71 s/pair on the GPU box vs ~5 s at 32-64), so the count is calibrated on a
+    proxy with the workload's two heavy parts (VGG trunk on 8 crops + PointNet feature MLP on 32 768 points)."""
+    from oracle import restatement as R  # checker / baseline only - never on the product path
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    cfg = dict(fusion=fusion, affinity_op=aff, softmax_mode=sm, neg_threshold=BASE_KW['neg_threshold'],
+               score_arch=BASE_KW['score_arch'])
+    host = os.cpu_count()
+    proxy_c = ins[0][0][:8]
+    pp = ins[0][1]['points'][:, :32768].transpose(-1, -2)
+    ps = torch.arange(0, pp.shape[-1] + 1, 2048)
+
+    def proxy():
+        x = proxy_c
+        for s in range(4):
+            x = R.vgg_stage(x, sd, s)
+        R.pointnet(pp, ps, sd)
+
+    best_thr, best_t, sweep = 1, float('inf'), {}
+    for thr in sorted({min(host, c) for c in (8, 16, 32, 64, 128)}):
+        torch.set_num_threads(thr)
+        with torch.no_grad():
+            proxy()
+            t1 = time.perf_counter()
+            proxy()
+            t = time.perf_counter() - t1
+        sweep[thr] = round(t, 3)
+        if t < best_t:
+            best_thr, best_t = thr, t
+    torch.set_num_threads(best_thr)
+    times, linf = [], 0.0
+    B = len(ins)
+    with torch.no_grad():
+        for i in range(n_timed + 1):
+            dets, info, _ = ins[i % B]
+            t1 = time.perf_counter()
+            o = R.tracking_forward(sd, cfg, dets, info['points'], info['points_split'], [N, M])
+            if i > 0:
+                times.append(time.perf_counter() - t1)
+            if res is not None:
+                det, links, new, end = res[i % B]
+                linf = max(linf, (links[0].cpu() - o[1][0]).abs().max().item(), (det.cpu() - o[0]).abs().max().item(),
+                           (new.cpu() - o[2]).abs().max().item(), (end.cpu() - o[3]).abs().max().item())
+    times.sort()
+    med = times[len(times) // 2]
+    base = {'value': round(1.0 / med, 4), 'unit': 'frame-pairs/s', 'cores': best_thr, 'threads': best_thr,
+            'host_cores': host, 'kind': 'port',
+            'sample': '%d timed pairs of the same workload after 1 warm-up pair, median s/pair %.3f (all: %s), torch %s '
+                      'CPU fp32, batch-1 loop like the reference; %d threads = fastest of the calibration sweep %s '
+                      '(s per proxy: VGG trunk on 8 crops + PointNet on 32768 points) on a %d-core host' % (
+                          len(times), med, ' '.join('%.2f' % t for t in times), torch.__version__, best_thr, sweep, host)}
+    return base, linf
+
+
+def latency_b1(dev, trunk):
+    """What eval_seq.py:143-153 actually calls: ONE frame pair per call through ``model(dets, det_info, dets_split)``
+    at the shape of BASELINE.json configs[0] (Fusion A, N=10, M=12, 224x224 crops, ragged ~300 pts/det), inputs on the
+    device, INCLUDING the per-call host work (points_split D2H, BatchPlan build + table uploads, launches) and a
+    final synchronize.  Every call sees a different points_split (plan-cache miss), like consecutive frames."""
+    from mmmot_amd import TrackingNet
+    from mmmot_amd.weights import init_module
+    model = TrackingNet(**dict(BASE_KW, score_fusion_arch='A', affinity_op='multiply', softmax_mode='none'))
+    init_module(model, seed=0)
+    model.eval().to(dev)
+    model.set_trunk(trunk)
+    ins = []
+    for i in range(12):
+        dets, info, ds = make_pair(10, 12, 224, 300, seed=3000 + i, ragged=True)
+        ins.append((dets.to(dev), {k: v.to(dev) for k, v in info.items()}, ds))
+    ts, ts_cached = [], []
+    with torch.no_grad():
+        for rep in range(2):
+            for i, (dets, info, ds) in enumerate(ins):
+                if rep == 0:
+                    model._plans.clear()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                out = model(dets, info, ds)
+                out[1][0].sum().item()  # the consumer reads the scores on the host
+                (ts if rep == 0 else ts_cached).append(time.perf_counter() - t0)
+    ts, ts_cached = sorted(ts[2:]), sorted(ts_cached)
+    return {'shape': 'cfg1: Fusion A, N=10, M=12, 224x224 crops, ragged ~300 pts/det, B=1, trunk %s' % trunk,
+            'latency_ms_b1': round(ts[len(ts) // 2] * 1e3, 3), 'latency_ms_b1_plan_cached': round(ts_cached[len(ts_cached) // 2] * 1e3, 3),
+            'includes': 'points_split D2H + BatchPlan build/upload (plan-cache miss) + launches + D2H of the scores'}
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        relaunch_under_torchrun(args)  # does not return
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        raise SystemExit('WORLD_SIZE=%d but --gpus %d' % (world, args.gpus))
+    fusion, aff, sm, N, M, S, pts, gold_name = WORKLOADS[args.workload]
+    B = args.pairs
+    # the global batch is world * B pairs; rank r owns the contiguous shard [lo, hi)
+    lo, hi = shard_range(world * B, rank, world)
+
+    if args.dry:
+        import torch.distributed as dist
+        dev = torch.device('cpu')
+        if world > 1:
+            dist.init_process_group('gloo')
+
+        def barrier():
+            if world > 1:
+                dist.barrier()
+
+        def step():
+            res = stub_results(hi - lo, N, M, 1000 + lo)
+            return res if args.no_gather else gather_results(res, same_layout=True)
+
+        for _ in range(args.warmup):
+            step()
+        dt, res = time_steps(step, args.steps, barrier)
+        dt = max_over_ranks(dt, world, dev)
+        ok = args.no_gather or (len(res) == world * B and all(
+            torch.equal(res[i][1][0], stub_results(1, N, M, 1000 + i)[0][1][0]) for i in range(0, world * B, max(B // 2, 1))))
+        if rank == 0:
+            print(json.dumps({'metric': METRIC, 'value': None, 'unit': 'frame-pairs/s', 'n_gpus': world, 'steps': args.steps,
+                              'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+                              'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': None,
+                              'data': 'dry-run stub (no kernel executed)', 'gather_ok': bool(ok),
+                              'config': {'workload': args.workload, 'pairs_per_step_per_gpu': B,
+                                         'parallelism': 'sample-sharded x%d, flat all_gather of scores (gloo, CPU)' % world}}),
+                  flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        if not ok:
+            raise SystemExit('dry run: gathered results are wrong')
+        return
+
+    from mmmot_amd import TrackingNet
+    from mmmot_amd.weights import init_module
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    model = TrackingNet(**dict(BASE_KW, score_fusion_arch=fusion, affinity_op=aff, softmax_mode=sm))
+    init_module(model, seed=0)
+    model.eval().to(dev)
+
+    # synthetic batch: distinct seeds per global pair index; inputs resident in HBM before timing
+    ins = [make_pair(N, M, S, pts, seed=1000 + i) for i in range(lo, hi)]
+    samples = [([N, M], x[1]['points_split'].reshape(-1).long().numpy()) for x in ins]
+    plan = model.make_plan(samples, S)
+    crops = torch.cat([x[0] for x in ins]).to(dev)
+    points = torch.cat([x[1]['points'].reshape(-1, 3) for x in ins]).to(dev)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run_leg(trunk):
+        """W warm-up steps, then exactly K timed steps between barrier + synchronize brackets, max over ranks."""
+        model.set_trunk(trunk)
+        eng = model.engine()
+
+        def step():
+            res = model.forward_batch(plan, crops, points)
+            if not args.no_gather:
+                res = gather_results(res, same_layout=True)  # trivial for world == 1
+            return res
+
+        for _ in range(args.warmup):
+            step()
+        if args.graph:
+            # the C-ABI entry points only launch (no allocation, no synchronisation): the whole step is capturable
+            eager_step = step
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                graph_res = eager_step()
+
+            def step():  # noqa: F811
+                graph.replay()
+                return graph_res
+            step()
+        eng.conv_events = []
+        dt, res = time_steps(step, args.steps, barrier)
+        events, eng.conv_events = eng.conv_events, None
+        dt = max_over_ranks(dt, world, dev)
+        roof, layers = roofline_of(trunk, events, eng, B, args.workload, dt)
+        leg = {'value': round(args.steps * B * world / dt, 4), 'ms_per_step': round(dt / args.steps * 1e3, 3),
+               'dtype': trunk, 'roofline': roof}
+        if rank == 0 and gold_name is not None:
+            leg['linf_vs_reference_golden'] = golden_linf(res[0], gold_name)
+        return leg, res, layers
+
+    head, res, layers = run_leg(args.trunk)
+    value = head['value']
+    fref = reference_flops_per_pair(N, M, S, (N + M) * pts, fusion)
     out = {
-        'metric': METRIC, 'value': round(value, 4), 'unit': 'frame-pairs/s', 'n_gpus': world, 'steps': args.steps,
-        'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+        'metric': METRIC, 'value': value, 'unit': 'frame-pairs/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': head['ms_per_step'], 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': args.trunk, 'data': 'synthetic',
         'config': {'workload': '%s: Fusion %s, %s/%s, N=M=%d (%d crops of %dx%d), %d pts/det; %d pairs/step/GPU' % (
             args.workload, fusion, aff, sm, N, N + M, S, S, pts, B), 'pairs_per_step_per_gpu': B, 'trunk': args.trunk,
             'parallelism': 'sample-sharded x%d, flat all_gather of scores' % world, 'hipgraph': bool(args.graph)},
-        'roofline': {'bound': 'mfma', 'kernel': kname,
-                     'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
-                     'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_unit': 'bytes/launch (mean)',
-                     'traffic_source': traffic_src, 'algorithmic_bytes_per_launch': round(alg_bytes),
-                     'peak_basis': peak_basis,
-                     'avg_launch_ms': round(conv_ms / max(n_launch, 1), 4),
-                     'trunk_share_of_step': round(trunk_ms / (dt * 1e3), 4),
-                     'flops_basis': 'algorithmic 2*9*Cin*Cout per output pixel (conv1_1 counted at Cin=3)'},
-        'end_to_end': {'ref_gflop_per_pair': round(reference_flops_per_pair(N, M, S, (N + M) * pts, fusion) / 1e9, 1),
-                       'ref_tflops_equiv': round(reference_flops_per_pair(N, M, S, (N + M) * pts, fusion) * value / 1e12 / world, 2)},
+        'roofline': head['roofline'],
+        'end_to_end': {'ref_gflop_per_pair': round(fref / 1e9, 1), 'ref_tflops_equiv': round(fref * value / 1e12 / world, 2)},
+        'parity': {'tolerance': 1e-3},
     }
-
+    if head.get('linf_vs_reference_golden') is not None:
+        out['parity']['linf_vs_reference_golden'] = head['linf_vs_reference_golden']
+        out['parity']['golden'] = 'tests/golden/%s.npz (output of the imported reference on the pair with seed 1000)' % gold_name
     if rank == 0:
-        prof_dir = os.path.join(ROOT, 'gpurun_out')
         try:
-            os.makedirs(prof_dir, exist_ok=True)
-            with open(os.path.join(prof_dir, 'bench_conv_layers_n%d.json' % world), 'w') as f:
-                json.dump({str(li): dict(ms_per_launch=a[0] / a[2], tflops=a[1] / (a[0] * 1e-3) / 1e12 if a[0] else 0,
-                                         rows=a[3], cin=a[4], cout=a[5]) for li, a in sorted(per_layer.items())}, f, indent=1)
+            os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+            with open(os.path.join(ROOT, 'gpurun_out', 'bench_conv_layers_n%d.json' % world), 'w') as f:
+                json.dump(layers, f, indent=1)
         except OSError:
             pass
 
     # ---- CPU baseline + parity on the same inputs (rank 0, single-GPU runs only) ----
     if rank == 0 and world == 1 and args.cpu_pairs > 0:
-        from oracle import restatement as R  # checker / baseline only - never on the product path
-        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-        cfg = dict(fusion=fusion, affinity_op=aff, softmax_mode=sm, neg_threshold=BASE_KW['neg_threshold'],
-                   score_arch=BASE_KW['score_arch'])
-        # Thread count: all cores is NOT the fastest on a many-core host (first run on the 256-core GPU
-        # box: 71 s/pair at 256 threads vs ~3 s at 8 threads in the build container).  Calibrate on a
-        # proxy (VGG stage 0 on 4 crops) and give the baseline its best setting.
-        best_thr, best_t = 1, float('inf')
-        proxy = ins[0][0][:4]
-        for thr in sorted({min(os.cpu_count(), c) for c in (8, 16, 32, 64, 128, 256)}):
-            torch.set_num_threads(thr)
-            with torch.no_grad():
-                R.vgg_stage(proxy, sd, 0)
-                t1 = time.perf_counter()
-                R.vgg_stage(proxy, sd, 0)
-                t = time.perf_counter() - t1
-            if t < best_t:
-                best_thr, best_t = thr, t
-        torch.set_num_threads(best_thr)
-        times, linf = [], 0.0
-        with torch.no_grad():
-            for i in range(min(args.cpu_pairs + 1, B + 1)):
-                dets, info, _ = ins[i % B]
-                t1 = time.perf_counter()
-                o = R.tracking_forward(sd, cfg, dets, info['points'], info['points_split'], [N, M])
-                if i > 0:
-                    times.append(time.perf_counter() - t1)
-                det, links, new, end = res[i % B]
-                linf = max(linf, (links[0].cpu() - o[1][0]).abs().max().item(), (det.cpu() - o[0]).abs().max().item(),
-                           (new.cpu() - o[2]).abs().max().item(), (end.cpu() - o[3]).abs().max().item())
-        times.sort()
-        med = times[len(times) // 2]
-        out['cpu_baseline'] = {'value': round(1.0 / med, 4), 'unit': 'frame-pairs/s', 'cores': torch.get_num_threads(),
-                               'kind': 'port',
-                               'sample': '%d pairs of the same workload after 1 warm-up pair, median s/pair %.3f, '
-                                         'torch %s CPU fp32, batch-1 loop like the reference; %d threads = fastest of a '
-                                         'calibration sweep on a %d-core host' % (len(times), med, torch.__version__,
-                                                                                torch.get_num_threads(), os.cpu_count())}
-        out['parity'] = {'linf_vs_cpu_oracle': linf, 'tolerance': 1e-3}
+        base, linf = cpu_baseline(model, ins, res, fusion, aff, sm, N, M, max(args.cpu_pairs, 1))
+        out['cpu_baseline'] = base
+        out['parity']['linf_vs_cpu_oracle'] = linf
+
+    # ---- the other arithmetic legs, same run, same step counts ----
+    extra = args.extra_trunks
+    if extra is None:
+        extra = {'f16x3': 'f16q8', 'f16q8': 'f16x3'}.get(args.trunk, 'none')
+    out['extra'] = {}
+    for t in [t for t in extra.split(',') if t and t != 'none' and t != args.trunk]:
+        leg, _, _ = run_leg(t)
+        out['extra'][t] = leg
+    if rank == 0 and world == 1 and not args.no_latency:
+        del crops, points
+        out['extra']['latency'] = latency_b1(dev, args.trunk)
 
     if rank == 0:
         print(json.dumps(out), flush=True)

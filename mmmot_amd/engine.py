@@ -111,6 +111,12 @@ class Engine:
     def appearance(self, plan, crops, cat):
         """crops [Lt,3,S,S] NCHW (reference contract) -> cat[:, 0:512]."""
         ops, Lt, S = self.ops, plan.Lt, plan.S
+        if S <= 0 or S % 32 != 0:
+            # every trunk kernel works on 2x2-aligned maps (pooling fused into the conv epilogue), and conv5 runs on
+            # the S/16 map: S must be a multiple of 32.  The reference's dataset resizes every crop to 224
+            # (dataset/test_seq_dataset.py:218); its MaxPool2d floors odd maps, which is not built here.
+            raise ValueError('crop side %d is not supported: the HIP VGG trunk needs a multiple of 32 '
+                             '(32, 64, ..., 224, 256); resize the crops (mmmot_amd.crops.crop_resize_normalize)' % S)
         x, H, W = crops, S, S
         # q8: activations travel as hq8 records (fp16 hi + two e4m3 copies, same bytes)
         q8 = (self.trunk == 'f16q8') and S >= self.q8_min_crop

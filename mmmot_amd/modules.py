@@ -9,8 +9,11 @@ the reference key names and ``load_state_dict`` semantics); none of their
 ``forward`` methods is ever called.  All arithmetic happens in
 libmmmot_hip.so through ``Engine``; CPU tensors are rejected (no fallback).
 
-Inference (eval mode) only: the north-star path is the forward; ``train()``
-mode raises.
+Inference (eval mode) only: the north-star path is the forward.  ``train()`` /
+``eval()`` only record the flag like any ``nn.Module`` (the reference's
+``TrackingModule`` toggles them around validation, tracking_model.py:32-48,
+eval_seq.py:127); a forward in training mode raises - batch-statistics
+BatchNorm, dropout and the backward are not built.
 """
 import os
 
@@ -333,23 +336,19 @@ class TrackingNet(nn.Module):
         'f16x3': all three terms on the fp16 matrix cores (fp32-class, score error ~3e-5);
         'f32': exact fp32 MFMA everywhere."""
         self.trunk = trunk
-        self._engine = None
+        self.invalidate()
 
     def invalidate(self):
         self._engine = None
+        self._plans = {}
 
     def _apply(self, fn, *a, **k):
-        self._engine = None
+        self.invalidate()  # .to() / .cuda(): packed weights and the cached plans' tables live on the old device
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, state_dict, strict=True, **k):
         self._engine = None
         return super().load_state_dict(state_dict, strict=strict, **k)
-
-    def train(self, mode=True):
-        if mode:
-            raise NotImplementedError('mmmot_amd.TrackingNet is inference-only (the HIP path is the forward)')
-        return super().train(False)
 
     def make_plan(self, samples, crop_hw, rows=(0, 1, 2)):
         """samples: list of (frame_counts, points_split) - see BatchPlan."""
@@ -361,7 +360,8 @@ class TrackingNet(nn.Module):
         """crops [Lt,3,S,S], points [P,3] (device, concatenated over the plan's samples).
         Returns per-sample reference-shaped tuples."""
         if self.training:
-            raise NotImplementedError('inference only')
+            raise NotImplementedError('mmmot_amd.TrackingNet computes the eval-mode forward only (call .eval(); the '
+                                      'training-mode forward / backward of tracking_model.py:50-66 is not built)')
         out = self.engine().forward(plan, crops, points)
         res = []
         pi = 0
@@ -401,12 +401,12 @@ class TrackingNet(nn.Module):
             ps = ps_t.detach().to('cpu').numpy().astype(np.int64)  # one D2H copy (reference: 2 .item() per detection)
             points = det_info['points'].reshape(-1, 3).contiguous()
         S = int(dets.shape[-1]) if dets is not None else 0
-        key = (tuple(fc), None if ps is None else ps.tobytes(), S, rows)
+        dev = points.device if points is not None else dets.device
+        key = (tuple(fc), None if ps is None else ps.tobytes(), S, rows, str(dev))
         plan = self._plans.get(key)
         if plan is None:
             if len(self._plans) > 64:
                 self._plans.clear()
-            dev = points.device if points is not None else dets.device
             plan = BatchPlan([(fc, ps)], S, dev, rows=rows, use_points=need_pts)
             self._plans[key] = plan
         crops = dets.contiguous() if need_img else None

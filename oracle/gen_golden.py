@@ -14,7 +14,15 @@ runs the case matrix, checks oracle/restatement.py against the reference
 (pinning the oracle) and stores the reference's outputs as fixtures.
 
     python oracle/gen_golden.py            # regenerate every fixture
+    python oracle/gen_golden.py --only f_   # only the cases whose name starts with f_ (manifest entries merged)
+
+Full-size cases (names ``f_*``, BASELINE.json's cfg3 / cfg4 sizes; cfg5 = modality rows 0 / 1 of the cfg3
+case) store the reference's OUTPUTS only (inputs regenerate from the seed; the cfg3 seed is the
+seed of bench.py's first pair, so the benchmark checks itself against the reference too).  The script also
+dumps ``tests/golden/state_dict_manifest.json``: key -> shape of the imported reference's ``state_dict()`` for
+fusion A / B / C, which tests/test_host_logic.py compares exactly with the mirror modules'.
 """
+import argparse
 import contextlib
 import io
 import json
@@ -88,17 +96,53 @@ CASES.append(dict(name='s4_cfg4like_C', fusion='C', aff='minus_abs', sm='dual_ad
                   ragged=False, seed=1004))
 CASES.append(dict(name='s5_3frames_B', fusion='B', aff='multiply', sm='dual_add', counts=[3, 4, 2], S=32, pts=20,
                   ragged=True, seed=1005))
+# full-size cases: outputs only ('full': True)
+CASES.append(dict(name='f_cfg3_C', fusion='C', aff='multiply', sm='none', N=64, M=64, S=128, pts=2048,
+                  ragged=False, seed=1000, full=True))
+CASES.append(dict(name='f_cfg4_C', fusion='C', aff='minus_abs', sm='dual_add', N=128, M=128, S=64, pts=512,
+                  ragged=False, seed=1000, full=True))
+CASES.append(dict(name='f_cfg3_ragged_C', fusion='C', aff='multiply', sm='none', N=64, M=50, S=128, pts=1024,
+                  ragged=True, seed=1006, full=True))
+CASES.append(dict(name='f_cfg4_ragged_B', fusion='B', aff='minus_abs', sm='dual_add', N=128, M=97, S=64, pts=256,
+                  ragged=True, seed=1007, full=True))
+
+
+def dump_state_dict_manifest(ref_modules):
+    """key -> shape of the imported reference's state_dict for every fusion module (boundary check)."""
+    out = {}
+    for fusion in 'ABC':
+        kw = dict(BASE, score_fusion_arch=fusion, affinity_op='multiply', softmax_mode='none')
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = ref_modules.TrackingNet(**kw)
+        out[fusion] = {k: list(v.shape) for k, v in m.state_dict().items()}
+    with open(os.path.join(GOLD, 'state_dict_manifest.json'), 'w') as f:
+        json.dump(dict(generator='oracle/gen_golden.py (imported reference modules.TrackingNet)', base_kwargs=BASE,
+                       keys=out), f, separators=(',', ':'))
+    return out
 
 
 def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', default=None, help='regenerate only the cases whose name starts with this prefix')
+    args = ap.parse_args()
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count())
     ref_modules = import_reference()
     os.makedirs(GOLD, exist_ok=True)
+    dump_state_dict_manifest(ref_modules)
     manifest = []
+    old = {}
+    if args.only is not None:
+        with open(os.path.join(GOLD, 'manifest.json')) as f:
+            old = {c['name']: c for c in json.load(f)['cases']}
     models = {}
     worst = 0.0
+    n_run = 0
     for c in CASES:
+        if args.only is not None and not c['name'].startswith(args.only):
+            if c['name'] in old:
+                manifest.append(old[c['name']])
+            continue
         key = (c['fusion'], c['aff'], c['sm'], len(c.get('counts', [0, 0])))
         if key not in models:
             models[key] = build_reference(ref_modules, c['fusion'], c['aff'], c['sm'], seq_len=key[3])
@@ -110,9 +154,10 @@ def main():
         t0 = time.time()
         with torch.no_grad():
             det, links, new, end, trans = model(dets, info, dsplit)
-            app = model.appearance(dets)
-            pnt, _ = model.point_net(info['points'].transpose(-1, -2), info['points_split'].long().squeeze(0))
             feats, _ = model.feature(dets, info)
+            if not c.get('full'):
+                app = model.appearance(dets)
+                pnt, _ = model.point_net(info['points'].transpose(-1, -2), info['points_split'].long().squeeze(0))
         t_ref = time.time() - t0
         cfg = dict(fusion=c['fusion'], affinity_op=c['aff'], softmax_mode=c['sm'], neg_threshold=BASE['neg_threshold'],
                    score_arch=BASE['score_arch'])
@@ -133,11 +178,15 @@ def main():
             assert errs['F'] < 1e-3, errs
         e = max(v for k, v in errs.items() if k != 'F')
         worst = max(worst, e)
+        n_run += 1
         print('%-28s ref %.2fs oracle %.2fs  max|ref-oracle| %.2e  %s' % (c['name'], t_ref, t_orc, e,
               ' '.join('%s=%.1e' % kv for kv in errs.items())), flush=True)
         assert e < 5e-5, 'oracle restatement disagrees with the reference: %r' % (errs,)
-        arrays = dict(det=det.numpy(), new=new.numpy(), end=end.numpy(), appearance=app.numpy(), point=pnt.numpy(),
-                      feats=feats.numpy(), trans1=trans[0].numpy(), trans2=trans[1].numpy())
+        if c.get('full'):
+            arrays = dict(det=det.numpy(), new=new.numpy(), end=end.numpy(), trans1=trans[0].numpy(), trans2=trans[1].numpy())
+        else:
+            arrays = dict(det=det.numpy(), new=new.numpy(), end=end.numpy(), appearance=app.numpy(), point=pnt.numpy(),
+                          feats=feats.numpy(), trans1=trans[0].numpy(), trans2=trans[1].numpy())
         for i, l in enumerate(links):
             arrays['link%d' % i] = l.numpy()
         np.savez_compressed(os.path.join(GOLD, c['name'] + '.npz'), **arrays)
@@ -145,7 +194,7 @@ def main():
     with open(os.path.join(GOLD, 'manifest.json'), 'w') as f:
         json.dump(dict(generator='oracle/gen_golden.py', torch=torch.__version__, weights_seed=0,
                        base_kwargs=BASE, cases=manifest), f, indent=1)
-    print('worst oracle-vs-reference error %.2e over %d cases' % (worst, len(CASES)))
+    print('worst oracle-vs-reference error %.2e over %d cases' % (worst, len(models) and n_run))
 
 
 if __name__ == '__main__':

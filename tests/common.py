@@ -19,10 +19,16 @@ def manifest():
 
 
 def case_names(light_only=False):
-    names = [c['name'] for c in manifest()['cases']]
+    """Small fixtures (outputs + stage checkpoints).  The full-size ones are in full_case_names()."""
+    names = [c['name'] for c in manifest()['cases'] if not c.get('full')]
     if light_only:
         names = [n for n in names if not n.startswith('s3_')]
     return names
+
+
+def full_case_names():
+    """BASELINE.json-size fixtures (cfg3 / cfg4 shapes, outputs of the imported reference only)."""
+    return [c['name'] for c in manifest()['cases'] if c.get('full')]
 
 
 def get_case(name):

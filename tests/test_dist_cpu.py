@@ -61,3 +61,23 @@ def test_two_rank_gather_gloo():
     port = 29500 + os.getpid() % 2000
     mp.spawn(_worker, args=(world, port, B, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+def test_bench_single_command_launcher_dry_run():
+    """`python bench.py --gpus 2` must become two ranks by itself (the driver launches it exactly so): the --dry
+    mode runs bench.py's own launcher, shard_range split, gather_results(same_layout=True) loop, barrier /
+    max-over-ranks timing and rank-0-only JSON on CPU tensors over gloo with a stub step."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--dry', '--gpus', '2', '--workload', 'tiny',
+                        '--steps', '3', '--warmup', '1', '--pairs', '3'], capture_output=True, text=True, timeout=300,
+                       env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout  # rank 0 only
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 3 and out['warmup'] == 1 and out['gather_ok'] is True
+    assert out['scaling'] == 'weak' and out['config']['pairs_per_step_per_gpu'] == 3

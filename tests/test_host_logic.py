@@ -55,14 +55,21 @@ def test_single_modality_rows():
     compare_outputs(out1, g, tol=2e-4, rows=(1,))
 
 
-def test_state_dict_keys_match_reference_golden_manifest():
-    """The reference state_dict (fusion C) has 21 218 212 elements (probe of the imported reference)."""
-    c, base = get_case('s2_C_multiply_none')
-    m = build_model(c, base)
-    assert sum(v.numel() for v in m.state_dict().values()) == 21218212
-    ka = build_model(get_case('s2_A_multiply_none')[0], base).state_dict().keys()
-    assert 'fusion_module.input_w.0.weight' in ka and 'w_link.w_new_end.conv1.6.bias' in ka
-    assert 'appearance.layers.0.10.weight' in ka and 'point_net.feat.stn2.output.weight' in ka
+@pytest.mark.parametrize('fusion', ['A', 'B', 'C'])
+def test_state_dict_keys_and_shapes_equal_the_reference(fusion):
+    """Exact key -> shape equality with the IMPORTED reference's ``TrackingNet.state_dict()`` (manifest written by
+    oracle/gen_golden.py from /root/reference): same keys, same order, same shapes."""
+    import json
+    import os
+    from common import GOLD
+    with open(os.path.join(GOLD, 'state_dict_manifest.json')) as f:
+        man = json.load(f)
+    ref = man['keys'][fusion]
+    m = TrackingNet(**dict(man['base_kwargs'], score_fusion_arch=fusion, affinity_op='multiply', softmax_mode='none'))
+    ours = {k: list(v.shape) for k, v in m.state_dict().items()}
+    assert list(ours) == list(ref), (sorted(set(ours) ^ set(ref))[:8])
+    assert ours == ref
+    assert sum(int(np.prod(v)) for v in ref.values()) == {'A': 20691364, 'B': 20692900, 'C': 21218212}[fusion]
 
 
 def test_build_model_from_reference_yaml_dict():
@@ -79,8 +86,12 @@ def test_build_model_from_reference_yaml_dict():
 def test_inference_only_and_no_cpu_fallback():
     c, base = get_case('s1_A_multiply_none')
     m = build_model(c, base)
+    # train() / eval() only record the flag (the reference toggles them around validation, tracking_model.py:32-48);
+    # a forward in training mode is refused
+    assert m.train() is m and m.training
     with pytest.raises(NotImplementedError):
-        m.train()
+        m(*case_inputs(c))
+    assert m.eval() is m and not m.training
     # default backend = HipOps: CPU tensors must be refused, never computed on the host
     with pytest.raises(RuntimeError):
         m(*case_inputs(c))

@@ -4,7 +4,7 @@ oracle/gen_golden.py recorded from the REAL reference (imported from
 import pytest
 import torch
 
-from common import case_inputs, case_names, compare_outputs, get_case, golden
+from common import case_inputs, case_names, compare_outputs, full_case_names, get_case, golden
 from mmmot_amd.weights import generate_state_dict
 from mmmot_amd import TrackingNet
 from common import case_kwargs
@@ -21,7 +21,7 @@ def state_dict_for(c, base):
     return _SD[key]
 
 
-@pytest.mark.parametrize('name', case_names())
+@pytest.mark.parametrize('name', case_names() + full_case_names())
 def test_oracle_matches_reference_golden(name):
     c, base = get_case(name)
     sd = state_dict_for(c, base)
