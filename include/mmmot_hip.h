@@ -68,7 +68,10 @@ extern "C" {
 /* library / device info -------------------------------------------------- */
 /* ABI history: 1 = first round-1 cut; 2 = gemm colsum / gemm_ares / gram / points / crops entry points,
  * gn_finalize tile_nrows, segment_mean seg_div; 3 = hq8 arithmetic (mmmot_conv3x3_bn_relu_hq8, mmmot_conv1_fused_hq8,
- * mmmot_hq8_pack/unpack, mmmot_segment_mean hl16 = 2), patch-kernel test / timing knobs. */
+ * mmmot_hq8_pack/unpack, mmmot_segment_mean hl16 = 2), patch-kernel test / timing knobs;
+ * 4 = per-output-channel weight scales (oscale is a [Cout] vector in the hl16 / hq8 trunk entry points),
+ * mmmot_trunk_range_read, the tile / LDS-DMA trunk kernels and their knobs removed, timing experiments only in
+ * -DMMMOT_DEBUG builds. */
 int mmmot_abi_version(void);
 /* returns 0 and fills cu_count / gcn arch string (<=32 bytes) of device 0..; */
 int mmmot_device_info(int device, int* cu_count, char* arch, int arch_len);
@@ -92,63 +95,68 @@ int mmmot_conv3x3_bn_relu(const float* in, const float* wp, const float* bias,
                           int first, int pool, void* stream);
 
 /* ---------------------------------------------------------------------------
- * fp16-matrix-core variant of the trunk layer with fp32-class accuracy.
+ * fp16-matrix-core variant of the trunk layer with fp32-class accuracy ("f16x3").
  * "hl16" split-half format (same bytes as fp32): a row of C channels is C/8
  * units of 32 bytes, unit u = [fp16 hi of channels 8u..8u+7 | fp16 lo of the
  * same channels], hi = fp16(x), lo = fp16(x - hi).  Every product is evaluated
  * as a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on v_mfma_f32_32x32x16_f16 with fp32
  * accumulation (3 MFMAs per algorithmic product: ceiling 2.5 PF / 3).
- *   in  : hl16 NHWC [L][H][W][Cin]       wp: hl16 [9][Cout][Cin] (host-scaled by 2^wshift)
- *   out : hl16 NHWC (pooled when pool=1)  oscale = 2^-wshift, applied before bias
- * Cin % 64 == 0, Cout % 64 == 0, H and W even.  Same reference lines as above.
+ *   in  : hl16 NHWC [L][H][W][Cin]       wp: hl16 [9][Cout][Cin], output channel n host-scaled by 2^wshift[n]
+ *   out : hl16 NHWC (pooled when pool=1)  oscale[Cout] = 2^-wshift[n], applied before the bias
+ * Cin % 32 == 0, Cout % 64 == 0, H and W even.  Same reference lines as above
+ * (conv2d + batch_norm + relu_ (+ max_pool2d), modules/vgg.py:67-80).
+ * Kernel: LDS-resident haloed activation patch + streamed weight ring, persistent workgroups of 256 pixels
+ * (16x16 or 4 x 8x8 blocks) x 64/128 channels (conv3x3_hl16_patch.hip).
  * mmmot_conv3x3_first_hl16 is the Cin=3 layer (fp32 MFMA on the NCHW crops) that
  * emits hl16; mmmot_hl16_pack/unpack convert n fp32 values (n % 8 == 0). */
-int mmmot_conv3x3_bn_relu_hl16(const void* in, const void* wp, const float* bias, void* out,
-                               int L, int H, int W, int Cin, int Cout, int pool, float oscale,
-                               void* stream);
-/* same contract, LDS-DMA + producer/consumer-wave kernel on 256-row tiles (conv3x3_hl16_dma.hip) */
-int mmmot_conv3x3_bn_relu_hl16_dma(const void* in, const void* wp, const float* bias, void* out,
-                                   int L, int H, int W, int Cin, int Cout, int pool, float oscale,
-                                   void* stream);
-/* same contract (Cin % 32 == 0 suffices), LDS-resident haloed activation patch + streamed weight ring,
- * 256 pixels (16x16 or 4 x 8x8 blocks) x 64/128 channels per workgroup (conv3x3_hl16_patch.hip) */
 int mmmot_conv3x3_bn_relu_hl16_patch(const void* in, const void* wp, const float* bias, void* out,
-                                     int L, int H, int W, int Cin, int Cout, int pool, float oscale,
+                                     int L, int H, int W, int Cin, int Cout, int pool, const float* oscale,
                                      void* stream);
 /* conv1_1 (3->64) + conv1_2 (64->64) + 2x2 max-pool of the VGG trunk in ONE kernel (reference modules/vgg.py:67-80,
  * layers 0-6 of vgg16_bn.features): the patch kernel computes conv1_1 for the haloed 18x18 patch of every tile in
  * its prologue instead of reading it, so the [L][H][W][64] tensor (537 MB per cfg3 pair) is never written.
- *   crops NCHW fp32 [L][3][H][W];  w1 hl16 [64][32] (k = (ky*3+kx)*3 + colour, zero-padded), bias1 [64], oscale1;
- *   w2 hl16 [9][64][64], bias2 [64], oscale2;  out hl16 NHWC [L][H/2][W/2][64].  H, W even. */
+ *   crops NCHW fp32 [L][3][H][W];  w1 hl16 [64][32] (k = (ky*3+kx)*3 + colour, zero-padded), bias1 [64], oscale1 (scalar);
+ *   w2 hl16 [9][64][64], bias2 [64], oscale2 [64];  out hl16 NHWC [L][H/2][W/2][64].  H, W even. */
 int mmmot_conv1_fused_hl16(const float* crops, const void* w1, const float* bias1, float oscale1,
-                           const void* w2, const float* bias2, float oscale2, void* out, int L, int H, int W,
+                           const void* w2, const float* bias2, const float* oscale2, void* out, int L, int H, int W,
                            void* stream);
-/* "hq8" arithmetic (opt-in trunk mode, same reference lines): the two correction terms of the hi/lo split run on
+/* "hq8" arithmetic (trunk mode 'f16q8', same reference lines): the two correction terms of the hi/lo split run on
  * the fp8 matrix cores (one block-scaled K=64 MFMA), 2 instead of 3 fp16-MFMA equivalents per product.
  *   activation record per 32 channels (128 bytes, like hl16): [32 x fp16 hi | 32 x e4m3(a / 4) | 32 x e4m3((a - hi) * 512)]
- *   weight record per 32 input channels: [32 x fp16 hi(w') | 32 x e4m3((w' - hi) * 32) | 32 x e4m3(hi / 64)], w' = w * 2^wshift
+ *   weight record per 32 input channels: [32 x fp16 hi(w') | 32 x e4m3((w' - hi) * 32) | 32 x e4m3(hi / 64)],
+ *   w' = w * 2^wshift[n] with a shift PER OUTPUT CHANNEL n (max|w'| of every channel in (2^13, 2^14]: the e4m3 copies
+ *   of a low-gain channel of a trained, BatchNorm-folded layer keep their precision).
  * e4m3 = OCP FP8 E4M3 (max 448).  Relative error of a product ~2^-15 instead of 2^-21 (hl16); end-to-end score
- * error stays below the 1e-3 budget (tools/study_fp8_correction.py, tests/test_hq8_gpu.py).
+ * error stays below the 1e-3 budget (tools/study_fp8_correction.py, tests/test_hq8_gpu.py, tests/test_robust_gpu.py).
  * Cin % 32 == 0, Cout % 64 == 0, H and W even.  mmmot_hq8_pack/unpack convert n fp32 values (n % 32 == 0). */
 int mmmot_conv3x3_bn_relu_hq8(const void* in, const void* wp, const float* bias, void* out,
-                              int L, int H, int W, int Cin, int Cout, int pool, float oscale, void* stream);
+                              int L, int H, int W, int Cin, int Cout, int pool, const float* oscale, void* stream);
 /* mmmot_conv1_fused_hl16 with conv1_2 in hq8 arithmetic: w1 stays hl16, w2 is hq8 [9][64][64], out is hq8 */
 int mmmot_conv1_fused_hq8(const float* crops, const void* w1, const float* bias1, float oscale1,
-                          const void* w2, const float* bias2, float oscale2, void* out, int L, int H, int W,
+                          const void* w2, const float* bias2, const float* oscale2, void* out, int L, int H, int W,
                           void* stream);
 int mmmot_hq8_pack(const float* x, void* y, long n, void* stream);
 int mmmot_hq8_unpack(const void* x, float* y, long n, void* stream);
-int mmmot_debug_read_patch_timers(unsigned long long* out8, int reset); /* phase cycle sums of patch variant 9 */
-int mmmot_set_patch_grid_limit(int n); /* tests: cap the persistent grid of the patch kernels (multiple of 8, 0 = one workgroup per CU) */
-int mmmot_set_patch_variant(int v); /* timing experiments of the patch kernel (0 = product; 1..4 give WRONG results) */
-int mmmot_set_dma_variant(int v); /* tuning / experiment knob of the LDS-DMA kernel (0 = default) */
+/* Range guard of the reduced-range activation formats.  The trunk epilogues count, on the device,
+ *   out4[0]: activation elements written with |a| > 1792 in hq8 mode (their e4m3 copies saturate: the products of
+ *            that element fall back to fp16-class accuracy);
+ *   out4[1]: elements clamped at +-65000 by the fp16 `hi` half (hl16 and hq8: the value itself is wrong);
+ *   out4[2]: workgroup-lanes of the fused first launch whose conv1_1 outputs crossed the mode's limit;  out4[3]: 0.
+ * Synchronous read of the current device's counters into a HOST array (the caller synchronises the launch stream
+ * first); reset != 0 clears them.  mmmot_amd.Engine reads them on the first forward and periodically, and moves the
+ * trunk to f16x3 / f32 when they are hit. */
+int mmmot_trunk_range_read(unsigned int* out4, int reset);
+/* tests: cap the persistent grid of the patch kernels (multiple of 8, 0 = one workgroup per CU) so that small
+ * problems run several chained tiles per workgroup like production sizes do.  Results do not depend on it. */
+int mmmot_set_patch_grid_limit(int n);
+#ifdef MMMOT_DEBUG
+/* -DMMMOT_DEBUG builds only (tools/, never the product library): timing experiments of the patch kernel
+ * (0 = product; 1..8 remove loads / barriers / MFMAs / stores and give WRONG results) and their phase timers. */
+int mmmot_set_patch_variant(int v);
+int mmmot_debug_read_patch_timers(unsigned long long* out8, int reset);
+#endif
 int mmmot_conv3x3_first_hl16(const float* in, const float* wp, const float* bias, void* out,
                              int L, int H, int W, int Cout, void* stream);
-/* tuning knob: inner-loop schedule of the hl16 trunk kernel (0..3; results are identical) */
-int mmmot_set_conv_variant(int v);
-/* variant 3 is instrumented: accumulated shader-clock cycles per phase of the K loop (see
- * conv3x3_hl16.hip); out8 is a HOST array of 8 counters, reset != 0 clears them. Synchronous. */
-int mmmot_debug_read_phase_timers(unsigned long long* out8, int reset);
 int mmmot_hl16_pack(const float* x, void* y, long n, void* stream);
 int mmmot_hl16_unpack(const void* x, float* y, long n, void* stream);
 

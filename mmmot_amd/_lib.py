@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.environ.get('MMMOT_LIB_PATH', os.path.join(_HERE, 'libmmmot_hip.so'))  # override: tools' timing-experiment builds
-SOURCES = ['conv3x3.hip', 'conv3x3_hl16.hip', 'conv3x3_hl16_dma.hip', 'conv3x3_hl16_patch.hip', 'gemm_rows.hip',
+SOURCES = ['conv3x3.hip', 'hl16_format.hip', 'conv3x3_hl16_patch.hip', 'gemm_rows.hip',
            'gemm_ares.hip', 'gram.hip', 'points_gather.hip', 'crop_resize.hip', 'small_kernels.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 HIPFLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
@@ -74,19 +74,13 @@ SIGNATURES = {
     'mmmot_gn_finalize_gram': [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_i, c_f, c_f, ctypes.c_float, c_f, c_f, c_f, c_f],
     'mmmot_gn_finalize': [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, ctypes.c_float, c_f, c_f, c_f],
     'mmmot_segment_mean': [c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_f, c_i, c_i, c_f, c_i, c_i, c_f],
-    'mmmot_conv3x3_bn_relu_hl16': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, c_f],
-    'mmmot_conv3x3_bn_relu_hl16_dma': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, c_f],
-    'mmmot_conv3x3_bn_relu_hl16_patch': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, c_f],
-    'mmmot_conv1_fused_hl16': [c_f, c_f, c_f, ctypes.c_float, c_f, c_f, ctypes.c_float, c_f, c_i, c_i, c_i, c_f],
-    'mmmot_conv3x3_bn_relu_hq8': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, c_f],
-    'mmmot_conv1_fused_hq8': [c_f, c_f, c_f, ctypes.c_float, c_f, c_f, ctypes.c_float, c_f, c_i, c_i, c_i, c_f],
+    'mmmot_conv3x3_bn_relu_hl16_patch': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f],
+    'mmmot_conv1_fused_hl16': [c_f, c_f, c_f, ctypes.c_float, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f],
+    'mmmot_conv3x3_bn_relu_hq8': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f],
+    'mmmot_conv1_fused_hq8': [c_f, c_f, c_f, ctypes.c_float, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f],
     'mmmot_conv3x3_first_hl16': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
-    'mmmot_set_conv_variant': [c_i],
-    'mmmot_set_dma_variant': [c_i],
-    'mmmot_set_patch_variant': [c_i],
     'mmmot_set_patch_grid_limit': [c_i],
-    'mmmot_debug_read_phase_timers': [ctypes.POINTER(ctypes.c_ulonglong), c_i],
-    'mmmot_debug_read_patch_timers': [ctypes.POINTER(ctypes.c_ulonglong), c_i],
+    'mmmot_trunk_range_read': [ctypes.POINTER(ctypes.c_uint), c_i],
     'mmmot_hl16_pack': [c_f, c_f, ctypes.c_long, c_f],
     'mmmot_hl16_unpack': [c_f, c_f, ctypes.c_long, c_f],
     'mmmot_hq8_pack': [c_f, c_f, ctypes.c_long, c_f],
@@ -108,19 +102,30 @@ SIGNATURES = {
 }
 
 
-def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 and link libmmmot_hip.so in-tree."""
+# entry points that exist only in -DMMMOT_DEBUG builds (timing experiments of tools/; never the product library)
+DEBUG_SIGNATURES = {
+    'mmmot_set_patch_variant': [c_i],
+    'mmmot_debug_read_patch_timers': [ctypes.POINTER(ctypes.c_ulonglong), c_i],
+}
+DEBUG_LIB_PATH = os.path.join(_HERE, 'libmmmot_hip_debug.so')
+
+
+def build(force=False, verbose=False, debug=False):
+    """Compile every HIP source for gfx950 and link libmmmot_hip.so in-tree.  ``debug=True`` builds the
+    -DMMMOT_DEBUG variant (timing experiments of the patch kernel) as libmmmot_hip_debug.so; load it by setting
+    MMMOT_LIB_PATH before importing mmmot_amd (tools/ do)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(CSRC, 'common.h'), os.path.join(_HERE, '..', 'include', 'mmmot_hip.h')]
-    if not force and os.path.exists(LIB_PATH):
-        if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-            return LIB_PATH
+    lib_path = DEBUG_LIB_PATH if debug else LIB_PATH
+    if not force and os.path.exists(lib_path):
+        if all(os.path.getmtime(lib_path) >= os.path.getmtime(d) for d in deps):
+            return lib_path
     objs = []
     procs = []
     for s in srcs:
-        o = s[:-4] + '.o'
+        o = s[:-4] + ('.dbg.o' if debug else '.o')
         objs.append(o)
-        cmd = [HIPCC] + HIPFLAGS + ['-c', s, '-o', o]
+        cmd = [HIPCC] + HIPFLAGS + (['-DMMMOT_DEBUG'] if debug else []) + ['-c', s, '-o', o]
         if verbose:
             print(' '.join(cmd))
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -128,11 +133,11 @@ def build(force=False, verbose=False):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError('hipcc failed: %s\n%s' % (' '.join(cmd), out.decode()))
-    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
+    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib_path] + objs
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)
-    return LIB_PATH
+    return lib_path
 
 
 def load():
@@ -149,6 +154,11 @@ def load():
                 fn = getattr(lib, name)  # AttributeError if the symbol is missing
                 fn.argtypes = argtypes
                 fn.restype = c_i
+            for name, argtypes in DEBUG_SIGNATURES.items():  # present in -DMMMOT_DEBUG builds only
+                fn = getattr(lib, name, None)
+                if fn is not None:
+                    fn.argtypes = argtypes
+                    fn.restype = c_i
             _lib = lib
     return _lib
 

@@ -19,6 +19,7 @@
 //     under the MFMAs of the second), ONE s_barrier per stage with counted vmcnt.
 // Rows of the implicit GEMM are in quad order (4 consecutive rows = one 2x2 pooling window), so max-pool
 // stays an in-register/LDS-local max in the epilogue.
+#include <atomic>
 #include <type_traits>
 
 #include "common.h"
@@ -70,6 +71,32 @@ __device__ __forceinline__ void pt_encode_q8(const float (&v)[16], u32x4& hi0, u
     pl = __builtin_amdgcn_cvt_pk_fp8_f32(lo[4 * w + 2], lo[4 * w + 3], pl, true);
     a8[w] = (unsigned)pa;
     l8[w] = (unsigned)pl;
+  }
+}
+
+// Range guard of the reduced-range activation formats (read by mmmot_trunk_range_read): [0] activation elements
+// written with |a| > 1792 in hq8 mode (the e4m3(a/4) and e4m3(512 a_lo) copies saturate: fp16-class products for that
+// element), [1] elements clamped at the fp16 range limit 65000 (either mode: wrong value), [2] the same two events for
+// conv1_1 outputs inside the fused first launch (counted once per patch pixel, halo pixels included).
+// The common path costs a running maximum (v_max3) and one compare per 16 values; the atomics run only on a hit.
+__device__ unsigned int pt_range[4];
+#define PT_SAT_E4M3 1792.f
+#define PT_SAT_FP16 65000.f
+
+template <int N>
+__device__ __forceinline__ void pt_range_guard(const float* v, bool q8) {
+  float mx = v[0];
+#pragma unroll
+  for (int e = 1; e < N; ++e) mx = fmaxf(mx, v[e]);  // post-ReLU values: >= 0
+  if (mx > (q8 ? PT_SAT_E4M3 : PT_SAT_FP16)) {
+    unsigned c = 0, d = 0;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      c += v[e] > PT_SAT_E4M3;
+      d += v[e] > PT_SAT_FP16;
+    }
+    if (q8) atomicAdd(&pt_range[0], c);
+    if (d) atomicAdd(&pt_range[1], d);
   }
 }
 
@@ -160,7 +187,7 @@ template <int BN, int BS, bool POOL, int EXP, bool FUSE1 = false, bool Q8 = fals
 __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     const u32x4* __restrict__ in, const u32x4* __restrict__ wp, const float* __restrict__ bias,
     u32x4* __restrict__ out, int L, int H, int W, int Cin, int Cout, int nby, int nbx, int nblk, int ntm, int ntn,
-    float oscale, Fuse1Args fz) {
+    const float* __restrict__ oscv, Fuse1Args fz) {
   static_assert(!FUSE1 || (BN == 64 && BS == 16), "the fused first layer exists for 64-channel 16x16 tiles");
   using G = PatchGeom<BS>;
   constexpr int WN = (BN == 128) ? 2 : 1;  // waves along channels
@@ -573,6 +600,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     // hi and lo halves leave as two 8-byte LDS stores and all per-pixel work (coordinates, swizzle, image
     // mask) is done once per lane.  11 pixel tiles of 32: waves take g = wave, wave + 8. ----
     const float* B1 = reinterpret_cast<const float*>(smem + RAW_OFF + 4800);  // conv1_1 bias [64] (staged above)
+    float c11max = 0.f;  // range guard of the conv1_1 outputs (pt_range[2])
 #pragma nounroll
     for (int g = wave; g < (EXP == 8 ? 0 : 11); g += 8) {  // EXP 8: timing experiment without the conv1_1 prologue
       const int n = g * 32 + lr;  // this lane's patch pixel
@@ -616,8 +644,10 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
             float vv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              float v = fminf(fmaxf(fmaf(c1[nt1][4 * q + r], fz.oscale1, bq[r]), 0.f), 65000.f);
+              float v = fmaxf(fmaf(c1[nt1][4 * q + r], fz.oscale1, bq[r]), 0.f);
               if (!inimg) v = 0.f;
+              c11max = fmaxf(c11max, v);
+              v = fminf(v, 65000.f);
               vv[r] = v;
               hi[r] = (_Float16)v;
               lo[r] = (_Float16)(v - (float)hi[r]);
@@ -645,6 +675,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
         }
       }
     }
+    if (c11max > (Q8 ? PT_SAT_E4M3 : PT_SAT_FP16)) atomicAdd(&pt_range[2], 1u);
     pt_wait_vm<2 * NBL>();  // weight stage 0 landed (this wave's part)
     __syncthreads();        // both patch slabs are complete
   } else {
@@ -797,14 +828,18 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   constexpr int RSTEP = 512 / UN;  // 32 / 64
   const int eu = tid % UN, er0 = tid / UN;
   const f32x8 bv = *reinterpret_cast<const f32x8*>(&bias[n0 + eu * 8]);
+  const f32x8 sv = *reinterpret_cast<const f32x8*>(&oscv[n0 + eu * 8]);  // per-output-channel 2^-shift
   // Q8: thread -> 16 channels (hi = two pieces, fp8 copies = one piece each: 4 stores of 16 bytes per 16 channels)
   constexpr int UN16 = BN / 16;
   constexpr int RSTEP16 = 512 / UN16;  // 64 / 128
   const int eu16 = tid % UN16, er16 = tid / UN16;
-  float bq[16];
+  float bq[16], sq[16];
   if constexpr (Q8) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) bq[e] = bias[n0 + eu16 * 16 + e];
+    for (int e = 0; e < 16; ++e) {
+      bq[e] = bias[n0 + eu16 * 16 + e];
+      sq[e] = oscv[n0 + eu16 * 16 + e];
+    }
   }
   // blocks of this tile: validity and first pixel (block-local (0,0)) of each
   int bcrop[G::NB], bgy0[G::NB], bgx0[G::NB];
@@ -877,8 +912,9 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
           for (int e = 0; e < 16; e += 4) {
             const f32x4 w4 = *reinterpret_cast<const f32x4*>(c + e);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[e + k] = fmaxf(fmaf(w4[k], oscale, bq[e + k]), 0.f);
+            for (int k = 0; k < 4; ++k) v[e + k] = fmaxf(fmaf(w4[k], sq[e + k], bq[e + k]), 0.f);
           }
+          pt_range_guard<16>(v, true);
           u32x4 hi0, hi1, a8, l8;
           pt_encode_q8(v, hi0, hi1, a8, l8);
           const long pix = POOL ? ((long)crop * Hq + (gy >> 1)) * Wq + (gx >> 1) : ((long)crop * H + gy) * W + gx;
@@ -931,7 +967,13 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
       if (crop >= 0 && gy < H && gx < W) {
         f32x8 v = *reinterpret_cast<const f32x8*>(&Cs[qdl * CLD + eu * 8]);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], oscale, bv[e]), 0.f);
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], sv[e], bv[e]), 0.f);
+        {
+          float vg[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) vg[e] = v[e];
+          pt_range_guard<8>(vg, false);
+        }
         u32x4 hi, lo;
         pt_split8(v, hi, lo);
         const long pix = ((long)crop * Hq + (gy >> 1)) * Wq + (gx >> 1);
@@ -962,7 +1004,13 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
       if (crop >= 0 && gy < H && gx < W) {
         f32x8 v = *reinterpret_cast<const f32x8*>(&Cs[rl * CLD + eu * 8]);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], oscale, bv[e]), 0.f);
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], sv[e], bv[e]), 0.f);
+        {
+          float vg[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) vg[e] = v[e];
+          pt_range_guard<8>(vg, false);
+        }
         u32x4 hi, lo;
         pt_split8(v, hi, lo);
         const long pix = ((long)crop * H + gy) * W + gx;
@@ -1002,6 +1050,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   }  // persistent tile loop
 }
 
+#ifdef MMMOT_DEBUG
 extern "C" int mmmot_debug_read_patch_timers(unsigned long long* out8, int reset) {
   hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(pt_dbg), 8 * sizeof(unsigned long long));
   if (e != hipSuccess) return (int)e;
@@ -1011,25 +1060,43 @@ extern "C" int mmmot_debug_read_patch_timers(unsigned long long* out8, int reset
   }
   return mm_check(e);
 }
+#endif
 
-static int g_patch_exp = 0;
-static int g_patch_grid_limit = 0;
+// Range-guard counters (see pt_range): synchronous read of the CURRENT device's counters into a HOST array of 4;
+// the caller synchronises the launch stream first.  reset != 0 clears them.
+extern "C" int mmmot_trunk_range_read(unsigned int* out4, int reset) {
+  if (!out4) return MMMOT_EINVAL;
+  hipError_t e = hipMemcpyFromSymbol(out4, HIP_SYMBOL(pt_range), 4 * sizeof(unsigned int));
+  if (e != hipSuccess) return (int)e;
+  if (reset) {
+    unsigned int z[4] = {0, 0, 0, 0};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(pt_range), z, sizeof(z));
+  }
+  return mm_check(e);
+}
+
+static std::atomic<int> g_patch_grid_limit{0};
 // Test knob: cap the persistent grid (a multiple of 8; 0 = one workgroup per CU) so that small problems exercise
-// the tile chaining (several tiles per workgroup) that production sizes run with.
+// the tile chaining (several tiles per workgroup) that production sizes run with.  Results do not depend on it.
 extern "C" int mmmot_set_patch_grid_limit(int n) {
   if (n < 0 || n % 8 != 0) return MMMOT_EINVAL;
-  g_patch_grid_limit = n;
+  g_patch_grid_limit.store(n);
   return MMMOT_OK;
 }
+#ifdef MMMOT_DEBUG
+// Timing experiments (tools/ only; -DMMMOT_DEBUG builds of the library, never the product build): variants 1..8 give
+// WRONG results by construction (they remove loads / barriers / MFMAs / stores to time what is left).
+static int g_patch_exp = 0;
 extern "C" int mmmot_set_patch_variant(int v) {
   if (v < 0 || v > 11) return MMMOT_EINVAL;
   g_patch_exp = v;
   return MMMOT_OK;
 }
+#endif
 
 template <int BN, int BS, bool POOL, int EXP, bool FUSE1 = false, bool Q8 = false>
 static int launch_patch_e(const void* in, const void* wp, const float* bias, void* out, int L, int H, int W, int Cin,
-                        int Cout, float oscale, hipStream_t s, Fuse1Args fz = Fuse1Args{nullptr, nullptr, nullptr, 1.f}) {
+                        int Cout, const float* oscale, hipStream_t s, Fuse1Args fz = Fuse1Args{nullptr, nullptr, nullptr, 1.f}) {
   const int nby = (H + BS - 1) / BS, nbx = (W + BS - 1) / BS;
   const int nblk = L * nby * nbx;
   constexpr int NB = PatchGeom<BS>::NB;
@@ -1044,7 +1111,8 @@ static int launch_patch_e(const void* in, const void* wp, const float* bias, voi
   }
   const int nitems = ntm * ntn;
   int grid = (n_cu / 8) * 8;                       // one persistent workgroup per CU, whole XCDs
-  if (g_patch_grid_limit > 0 && grid > g_patch_grid_limit) grid = g_patch_grid_limit;
+  const int glimit = g_patch_grid_limit.load();
+  if (glimit > 0 && grid > glimit) grid = glimit;
   if (grid > ((nitems + 7) / 8) * 8) grid = ((nitems + 7) / 8) * 8;
   hipLaunchKernelGGL((conv3x3_hl16_patch_kernel<BN, BS, POOL, EXP, FUSE1, Q8>), dim3(grid), dim3(512), 0, s,
                      (const u32x4*)in, (const u32x4*)wp, bias, (u32x4*)out, L, H, W, Cin, Cout, nby, nbx, nblk, ntm, ntn,
@@ -1054,7 +1122,8 @@ static int launch_patch_e(const void* in, const void* wp, const float* bias, voi
 
 template <int BN, int BS, bool POOL>
 static int launch_patch(const void* in, const void* wp, const float* bias, void* out, int L, int H, int W, int Cin,
-                        int Cout, float oscale, hipStream_t s) {
+                        int Cout, const float* oscale, hipStream_t s) {
+#ifdef MMMOT_DEBUG
   if constexpr (BN == 128 && BS == 16 && !POOL) {  // the experiments exist for one instantiation only
     switch (g_patch_exp) {
       case 1: return launch_patch_e<BN, BS, POOL, 1>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
@@ -1066,22 +1135,23 @@ static int launch_patch(const void* in, const void* wp, const float* bias, void*
       default: break;
     }
   }
+#endif
   return launch_patch_e<BN, BS, POOL, 0>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
 }
 
 template <int BN, int BS>
 static int launch_patch_p(int pool, const void* in, const void* wp, const float* bias, void* out, int L, int H, int W,
-                          int Cin, int Cout, float oscale, hipStream_t s) {
+                          int Cin, int Cout, const float* oscale, hipStream_t s) {
   return pool ? launch_patch<BN, BS, true>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s)
               : launch_patch<BN, BS, false>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
 }
 
 // Same contract as mmmot_conv3x3_bn_relu_hl16 (Cin % 32 == 0, Cout % 64 == 0, H and W even).
 extern "C" int mmmot_conv3x3_bn_relu_hl16_patch(const void* in, const void* wp, const float* bias, void* out, int L,
-                                                int H, int W, int Cin, int Cout, int pool, float oscale,
+                                                int H, int W, int Cin, int Cout, int pool, const float* oscale,
                                                 void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (!in || !wp || !bias || !out || L <= 0 || H <= 0 || W <= 0) return MMMOT_EINVAL;
+  if (!in || !wp || !bias || !out || !oscale || L <= 0 || H <= 0 || W <= 0) return MMMOT_EINVAL;
   if ((H & 1) || (W & 1) || Cin % 32 != 0 || Cout % 64 != 0) return MMMOT_EINVAL;
   if (!mm_al16(in) || !mm_al16(wp) || !mm_al16(out)) return MMMOT_EINVAL;
   if ((long)L * H * W * (Cin / 4) >= (1L << 31) - 64) return MMMOT_EINVAL;  // 32-bit piece offsets
@@ -1095,10 +1165,10 @@ extern "C" int mmmot_conv3x3_bn_relu_hl16_patch(const void* in, const void* wp, 
 
 // conv1_1 (3 -> 64) + conv1_2 (64 -> 64) + 2x2 max-pool in one kernel: see FUSE1 above.
 extern "C" int mmmot_conv1_fused_hl16(const float* crops, const void* w1, const float* bias1, float oscale1,
-                                      const void* w2, const float* bias2, float oscale2, void* out, int L, int H,
+                                      const void* w2, const float* bias2, const float* oscale2, void* out, int L, int H,
                                       int W, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (!crops || !w1 || !bias1 || !w2 || !bias2 || !out || L <= 0 || H <= 0 || W <= 0) return MMMOT_EINVAL;
+  if (!crops || !w1 || !bias1 || !w2 || !bias2 || !oscale2 || !out || L <= 0 || H <= 0 || W <= 0) return MMMOT_EINVAL;
   if ((H & 1) || (W & 1) || !mm_al16(w1) || !mm_al16(w2) || !mm_al16(out)) return MMMOT_EINVAL;
   Fuse1Args fz{crops, (const u32x4*)w1, bias1, oscale1};
   return launch_patch_e<64, 16, true, 0, true>(nullptr, w2, bias2, out, L, H, W, 64, 64, oscale2, s, fz);
@@ -1107,7 +1177,8 @@ extern "C" int mmmot_conv1_fused_hl16(const float* crops, const void* w1, const 
 // ---- hq8 arithmetic: same contracts, activations / weights in the hq8 record format (see Q8 above) ----
 template <int BN, int BS>
 static int launch_q8_p(int pool, const void* in, const void* wp, const float* bias, void* out, int L, int H, int W,
-                       int Cin, int Cout, float oscale, hipStream_t s) {
+                       int Cin, int Cout, const float* oscale, hipStream_t s) {
+#ifdef MMMOT_DEBUG
   if constexpr (BN == 128 && BS == 16) {  // timing experiments (wrong results), unpooled 128-channel tiles only
     if (!pool && g_patch_exp == 3) return launch_patch_e<BN, BS, false, 3, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
     if (!pool && g_patch_exp == 4) return launch_patch_e<BN, BS, false, 4, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
@@ -1117,14 +1188,15 @@ static int launch_q8_p(int pool, const void* in, const void* wp, const float* bi
     if (!pool && g_patch_exp == 10) return launch_patch_e<BN, BS, false, 10, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
     if (!pool && g_patch_exp == 11) return launch_patch_e<BN, BS, false, 11, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
   }
+#endif
   return pool ? launch_patch_e<BN, BS, true, 0, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s)
               : launch_patch_e<BN, BS, false, 0, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
 }
 
 extern "C" int mmmot_conv3x3_bn_relu_hq8(const void* in, const void* wp, const float* bias, void* out, int L, int H,
-                                         int W, int Cin, int Cout, int pool, float oscale, void* stream) {
+                                         int W, int Cin, int Cout, int pool, const float* oscale, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (!in || !wp || !bias || !out || L <= 0 || H <= 0 || W <= 0) return MMMOT_EINVAL;
+  if (!in || !wp || !bias || !out || !oscale || L <= 0 || H <= 0 || W <= 0) return MMMOT_EINVAL;
   if ((H & 1) || (W & 1) || Cin % 32 != 0 || Cout % 64 != 0) return MMMOT_EINVAL;
   if (!mm_al16(in) || !mm_al16(wp) || !mm_al16(out)) return MMMOT_EINVAL;
   if ((long)L * H * W * (Cin / 4) >= (1L << 31) - 64) return MMMOT_EINVAL;
@@ -1137,15 +1209,17 @@ extern "C" int mmmot_conv3x3_bn_relu_hq8(const void* in, const void* wp, const f
 }
 
 extern "C" int mmmot_conv1_fused_hq8(const float* crops, const void* w1, const float* bias1, float oscale1,
-                                     const void* w2, const float* bias2, float oscale2, void* out, int L, int H,
+                                     const void* w2, const float* bias2, const float* oscale2, void* out, int L, int H,
                                      int W, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (!crops || !w1 || !bias1 || !w2 || !bias2 || !out || L <= 0 || H <= 0 || W <= 0) return MMMOT_EINVAL;
+  if (!crops || !w1 || !bias1 || !w2 || !bias2 || !oscale2 || !out || L <= 0 || H <= 0 || W <= 0) return MMMOT_EINVAL;
   if ((H & 1) || (W & 1) || !mm_al16(w1) || !mm_al16(w2) || !mm_al16(out)) return MMMOT_EINVAL;
   Fuse1Args fz{crops, (const u32x4*)w1, bias1, oscale1};
+#ifdef MMMOT_DEBUG
   if (g_patch_exp == 4) return launch_patch_e<64, 16, true, 4, true, true>(nullptr, w2, bias2, out, L, H, W, 64, 64, oscale2, s, fz);
   if (g_patch_exp == 6) return launch_patch_e<64, 16, true, 6, true, true>(nullptr, w2, bias2, out, L, H, W, 64, 64, oscale2, s, fz);
   if (g_patch_exp == 8) return launch_patch_e<64, 16, true, 8, true, true>(nullptr, w2, bias2, out, L, H, W, 64, 64, oscale2, s, fz);
+#endif
   return launch_patch_e<64, 16, true, 0, true, true>(nullptr, w2, bias2, out, L, H, W, 64, 64, oscale2, s, fz);
 }
 

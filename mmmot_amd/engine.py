@@ -12,6 +12,7 @@ chain of  GEMM(+stats epilogue) -> finalize -> next GEMM(normalise prologue).
 engine itself only allocates memory and orders launches.
 """
 import os
+import warnings
 
 import torch
 
@@ -24,16 +25,31 @@ EPS = 1e-5  # nn.GroupNorm / nn.BatchNorm default used everywhere in the referen
 class Engine:
     def __init__(self, packed, ops, fusion='A', affinity_op='multiply', softmax_mode='none',
                  neg_threshold=0.0, score_arch='branch_cls', end_mode='avg', trunk=None):
-        trunk = trunk or os.environ.get('MMMOT_TRUNK', 'f16q8')
+        trunk = trunk or os.environ.get('MMMOT_TRUNK', 'f16x3')
         if trunk not in ('f16x3', 'f16q8', 'f32'):
             raise ValueError("trunk must be 'f16x3' (fp16 matrix cores, 3-term split), 'f16q8' (fp16 main term + "
                              "fp8 correction terms, include/mmmot_hip.h hq8) or 'f32' (exact fp32 MFMA)")
-        self.trunk = trunk
-        # machine mapping of the hl16 trunk layers (same arithmetic): 'patch' = LDS-resident haloed patch
-        # (conv3x3_hl16_patch.hip, fastest), 'tile' = register-staged 128-row tiles, 'dma' = LDS-DMA ring
-        self.conv_impl = os.environ.get('MMMOT_CONV', 'patch')
-        if self.conv_impl not in ('patch', 'tile', 'dma'):
-            raise ValueError("MMMOT_CONV must be 'patch', 'tile' or 'dma'")
+        self.trunk = trunk            # arithmetic the trunk currently runs in (the range guard may lower it)
+        self.trunk_requested = trunk
+        # Range guard (include/mmmot_hip.h: mmmot_trunk_range_read).  The hq8 / hl16 activation formats have a finite
+        # range: e4m3 copies saturate above 1792 (products of that element become fp16-class), the fp16 `hi` half
+        # clamps at 65000 (wrong value).  The trunk epilogues count both on the device; the engine reads the counters
+        # on its first forward and then every `range_check_every` forwards (one stream synchronisation each; never
+        # during hipGraph capture) and, when they are hit, moves the trunk f16q8 -> f16x3 -> f32 for good, repeats the
+        # trunk of that forward and records the event.  MMMOT_RANGE_GUARD=0 disables it.
+        self.range_guard = os.environ.get('MMMOT_RANGE_GUARD', '1') != '0'
+        self.range_check_every = int(os.environ.get('MMMOT_RANGE_CHECK_EVERY', '64'))
+        self.q8_sat_limit = float(os.environ.get('MMMOT_Q8_SAT_LIMIT', '1e-4'))  # tolerated fraction of saturated elements
+        self.range_events = []
+        self._n_forward = 0
+        # f16q8 only: trunk layers (indices into P['vgg'], 1..12) that run the hq8 arithmetic; None = all of them
+        # (MMMOT_Q8_LAYERS=all).  The others run f16x3; at a boundary the activation tensor is re-encoded (hq8 <-> hl16,
+        # two small kernels).  Default: conv3_1 .. conv5_3 (layers 4..12).  Measured on trained-like statistics
+        # (tools/study_robustness.py, calibrated BatchNorm, per-channel gains over 1e4, heavy-tailed weights): the
+        # full-resolution layers 1..3 carry two thirds of the e4m3 error (all layers 5.8e-4 .. 9.5e-4 of the 1e-3
+        # budget; layers 4..12 3.8e-4 .. 4.0e-4) for a fifth of the trunk's time.
+        ql = os.environ.get('MMMOT_Q8_LAYERS', '4,5,6,7,8,9,10,11,12')
+        self.q8_layers = None if ql == 'all' else set(int(v) for v in ql.split(',') if v)
         # PointNet conv5 / conv1: statistics pass + fused normalise-ReLU-segment-sum pass instead of
         # materialising the [P][1024] / [P][512] tensors (MMMOT_PN_FUSED=0 keeps the materialising path)
         self.pn_fused = os.environ.get('MMMOT_PN_FUSED', '1') != '0'
@@ -123,12 +139,24 @@ class Engine:
         f16 = self.trunk in ('f16x3', 'f16q8')  # activations travel in the hl16 split-half / hq8 format (same bytes)
         vgg = self.P['vgg']
         # conv1_1 + conv1_2 + pool as one launch when the trunk has the VGG16 head (3 -> 64 -> 64, pool)
-        fuse1 = (f16 and (q8 or self.conv_impl == 'patch') and self.fuse_conv1 and len(vgg) > 1 and vgg[0]['cout'] == 64 and
+        fuse1 = (f16 and self.fuse_conv1 and len(vgg) > 1 and vgg[0]['cout'] == 64 and
                  vgg[1]['cin'] == 64 and vgg[1]['cout'] == 64 and vgg[1]['pool'] and not vgg[0]['last'] and
                  not vgg[0]['pool'] and H % 2 == 0 and W % 2 == 0)
+        fmt = 'raw'  # format of x: 'raw' NCHW crops, 'f32' NHWC fp32, 'hl16', 'hq8' (same bytes per value)
         for li, cv in enumerate(vgg):
             if fuse1 and li == 0:
                 continue
+            lq8 = q8 and (self.q8_layers is None or li in self.q8_layers)  # this layer's arithmetic
+            want = 'hq8' if lq8 else 'hl16'
+            if f16 and fmt in ('hl16', 'hq8') and fmt != want:
+                # arithmetic boundary inside an f16q8 trunk: re-encode the activation tensor (exact up to the target
+                # format's own rounding)
+                n = Lt * H * W * cv['cin']
+                tmp = self.buf('vgg_recode32', n)
+                (ops.hq8_unpack if fmt == 'hq8' else ops.hl16_unpack)(x, tmp)
+                x = self.buf('vgg_recode', n)
+                (ops.hq8_pack if want == 'hq8' else ops.hl16_pack)(tmp, x)
+                fmt = want
             Ho, Wo = (H // 2, W // 2) if cv['pool'] else (H, W)
             out = self.buf('vgg%d' % (li & 1), Lt * Ho * Wo, cv['cout'])
             if self.conv_events is not None:  # bench.py: HIP events around every trunk launch
@@ -136,33 +164,79 @@ class Engine:
                 e0.record()
             if fuse1 and li == 1:
                 c0 = vgg[0]
-                if q8:
+                if lq8:
                     ops.conv1_fused_hq8(x, c0['wp16'], c0['bias'], c0['oscale'], cv['wpq8'], cv['bias'], cv['oscale'],
                                         out, Lt, H, W)
                 else:
                     ops.conv1_fused_hl16(x, c0['wp16'], c0['bias'], c0['oscale'], cv['wp16'], cv['bias'],
                                          cv['oscale'], out, Lt, H, W)
-            elif q8 and li == 0:  # unfused first layer: exact fp32 MFMA, then re-encoded
-                tmp = self.buf('vgg_first32', Lt * H * W, cv['cout'])
-                ops.conv3x3(x, cv['wp'], cv['bias'], tmp, Lt, H, W, cv['cin'], cv['cout'], True, cv['pool'])
-                ops.hq8_pack(tmp, out)
-            elif q8:
+                fmt = want
+            elif f16 and li == 0:  # unfused first layer: exact fp32 MFMA on the crops, output encoded for layer 1
+                nq8 = q8 and (self.q8_layers is None or 1 in self.q8_layers)
+                if nq8:
+                    tmp = self.buf('vgg_first32', Lt * H * W, cv['cout'])
+                    ops.conv3x3(x, cv['wp'], cv['bias'], tmp, Lt, H, W, cv['cin'], cv['cout'], True, cv['pool'])
+                    ops.hq8_pack(tmp, out)
+                else:
+                    ops.conv3x3_first_hl16(x, cv['wp'], cv['bias'], out, Lt, H, W, cv['cout'])
+                fmt = 'hq8' if nq8 else 'hl16'
+            elif lq8:
                 ops.conv3x3_hq8(x, cv['wpq8'], cv['bias'], out, Lt, H, W, cv['cin'], cv['cout'], cv['pool'], cv['oscale'])
+                fmt = 'hq8'
             elif not f16:
                 ops.conv3x3(x, cv['wp'], cv['bias'], out, Lt, H, W, cv['cin'], cv['cout'], li == 0, cv['pool'])
-            elif li == 0:
-                ops.conv3x3_first_hl16(x, cv['wp'], cv['bias'], out, Lt, H, W, cv['cout'])
+                fmt = 'f32'
             else:
-                conv = {'patch': ops.conv3x3_hl16_patch, 'tile': ops.conv3x3_hl16,
-                        'dma': ops.conv3x3_hl16_dma}[self.conv_impl]
-                conv(x, cv['wp16'], cv['bias'], out, Lt, H, W, cv['cin'], cv['cout'], cv['pool'], cv['oscale'])
+                ops.conv3x3_hl16_patch(x, cv['wp16'], cv['bias'], out, Lt, H, W, cv['cin'], cv['cout'], cv['pool'],
+                                       cv['oscale'])
+                fmt = 'hl16'
             if self.conv_events is not None:
                 e1.record()
                 self.conv_events.append((li, Lt * H * W, cv['cin'], cv['cout'], e0, e1))
             x, H, W = out, Ho, Wo
             if cv['last']:
                 self._stash('vgg_stage%d' % cv['stage'], x)
-                self._skippool(plan, cv['stage'], x, H * W, cv['cout'], cat, hl16=2 if q8 else f16)
+                self._skippool(plan, cv['stage'], x, H * W, cv['cout'], cat, hl16={'hq8': 2, 'hl16': 1, 'f32': 0}[fmt])
+
+    def trunk_elements(self, plan):
+        """activation elements the trunk writes per forward (the denominator of the range guard's fractions)"""
+        n, H = 0, plan.S
+        for cv in self.P['vgg']:
+            if cv['pool']:
+                H //= 2
+            n += plan.Lt * H * H * cv['cout']
+        return n
+
+    def _guarded_appearance(self, plan, crops, cat):
+        """appearance() under the range guard: see __init__."""
+        capturing = torch.cuda.is_current_stream_capturing() if crops.is_cuda else False
+        first = self._n_forward == 0
+        due = first or (self.range_check_every > 0 and self._n_forward % self.range_check_every == 0)
+        check = (self.range_guard and self.trunk != 'f32' and due and not capturing and
+                 hasattr(self.ops, 'trunk_range_read'))
+        if check and first:
+            self.ops.trunk_range_read(crops.device, reset=True)  # counters are per device: start from zero
+        self.appearance(plan, crops, cat)
+        while check and self.trunk != 'f32':
+            sat, clamp, c11, _ = self.ops.trunk_range_read(crops.device, reset=True)
+            q8 = self.trunk == 'f16q8' and plan.S >= self.q8_min_crop
+            window = 1 if first else self.range_check_every
+            lower = None
+            if clamp > 0 or (c11 > 0 and not q8):
+                lower = 'f32'
+            elif q8 and (sat > self.q8_sat_limit * self.trunk_elements(plan) * window or c11 > 0):
+                lower = 'f16x3'
+            if lower is None:
+                break
+            ev = dict(forward=self._n_forward, was=self.trunk, now=lower, e4m3_saturated=sat, fp16_clamped=clamp,
+                      conv1_1_hits=c11, trunk_elements=self.trunk_elements(plan))
+            self.range_events.append(ev)
+            warnings.warn('mmmot_amd range guard: trunk arithmetic %(was)s -> %(now)s (%(e4m3_saturated)d activation '
+                          'elements beyond the e4m3 range, %(fp16_clamped)d beyond the fp16 range, of %(trunk_elements)d '
+                          'per forward); the trunk of this forward is recomputed' % ev, RuntimeWarning, stacklevel=3)
+            self.trunk = lower
+            self.appearance(plan, crops, cat)
+        self._n_forward += 1
 
     def _skippool(self, plan, s, x, hw, C, cat, hl16=False):
         """reference modules/appear_net.py:9-32 for stage s -> cat[:, 128 s : 128 (s+1)]."""
@@ -375,7 +449,7 @@ class Engine:
         if need_img:
             if crops is None or tuple(crops.shape) != (Lt, 3, plan.S, plan.S) or not crops.is_contiguous():
                 raise ValueError('crops must be a contiguous [%d,3,%d,%d] tensor' % (Lt, plan.S, plan.S))
-            self.appearance(plan, crops, cat)
+            self._guarded_appearance(plan, crops, cat)
         if need_pts:
             if points is None or tuple(points.shape) != (plan.P, 3) or not points.is_contiguous():
                 raise ValueError('points must be a contiguous [%d,3] tensor' % plan.P)

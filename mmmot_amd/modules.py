@@ -301,7 +301,7 @@ class TrackingNet(nn.Module):
         self.w_det = nn.Sequential(nn.Conv1d(c, c, 1, 1), nn.BatchNorm1d(c), nn.ReLU(inplace=True),
                                    nn.Conv1d(c, c // 2, 1, 1), nn.BatchNorm1d(c // 2), nn.ReLU(inplace=True),
                                    nn.Conv1d(c // 2, 1, 1, 1))
-        self.trunk = os.environ.get('MMMOT_TRUNK', 'f16q8')
+        self.trunk = os.environ.get('MMMOT_TRUNK', 'f16x3')
         self._ops = None       # operator backend (HipOps unless a test injects another)
         self._engine = None
         self._engine_key = None
@@ -330,11 +330,15 @@ class TrackingNet(nn.Module):
         return self._engine
 
     def set_trunk(self, trunk):
-        """'f16q8' (default): VGG trunk with the fp16 main term on the fp16 matrix cores and both hi/lo correction
-        terms in one block-scaled fp8 MFMA (score error <= 3.3e-4 on the reference's configurations, budget 1e-3;
-        crops smaller than Engine.q8_min_crop = 64 pixels run the f16x3 trunk);
-        'f16x3': all three terms on the fp16 matrix cores (fp32-class, score error ~3e-5);
-        'f32': exact fp32 MFMA everywhere."""
+        """Arithmetic of the VGG trunk (the other GEMMs follow: f16x3, or exact fp32 with 'f32'):
+        'f16x3' (default): fp16 matrix cores, 3-term hi/lo split - fp32-class, score error ~3e-5 against the fp32
+                 reference (indistinguishable from fp32 summation-order noise);
+        'f16q8': opt-in: fp16 main term + both correction terms in one block-scaled fp8 MFMA on the trunk layers
+                 ``Engine.q8_layers`` (+20 % throughput; score error 3e-4 on He-normal weights, up to 9e-4 on
+                 trained-like statistics with every layer in fp8, DESIGN.md 4b; crops under 64 pixels run f16x3);
+        'f32':   exact fp32 MFMA everywhere.
+        The engine's range guard lowers f16q8 -> f16x3 -> f32 by itself when activations leave the e4m3 / fp16 range
+        (``engine().range_events``)."""
         self.trunk = trunk
         self.invalidate()
 

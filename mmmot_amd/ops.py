@@ -51,6 +51,20 @@ class HipOps:
 
     def __init__(self):
         self.lib = _lib.load()
+        self._osvecs = {}
+
+    def _osv(self, oscale, Cout, like):
+        """The [Cout] per-output-channel scale vector of the trunk entry points; a python float (the kernel tests'
+        one-scale-per-layer case) is expanded to a cached constant vector."""
+        if torch.is_tensor(oscale):
+            if oscale.numel() != Cout:
+                raise ValueError('oscale must hold one scale per output channel')
+            return oscale
+        key = (float(oscale), Cout, like.device)
+        v = self._osvecs.get(key)
+        if v is None:
+            v = self._osvecs[key] = torch.full((Cout,), float(oscale), dtype=torch.float32, device=like.device)
+        return v
 
     @staticmethod
     def _stream():
@@ -61,41 +75,41 @@ class HipOps:
                                             int(first), int(pool), self._stream())
         _lib.check(st, 'mmmot_conv3x3_bn_relu')
 
-    def conv3x3_hl16(self, inp, wp, bias, out, L, H, W, Cin, Cout, pool, oscale):
-        """fp16-split trunk layer: inp/out/wp are fp32-typed buffers holding hl16 data (same bytes)."""
-        st = self.lib.mmmot_conv3x3_bn_relu_hl16(_ptr(inp), _ptr(wp), _ptr(bias), _ptr(out), L, H, W, Cin, Cout,
-                                                 int(pool), float(oscale), self._stream())
-        _lib.check(st, 'mmmot_conv3x3_bn_relu_hl16')
-
-    def conv3x3_hl16_dma(self, inp, wp, bias, out, L, H, W, Cin, Cout, pool, oscale):
-        """Same contract as conv3x3_hl16; LDS-DMA / producer-consumer kernel (256-row tiles)."""
-        st = self.lib.mmmot_conv3x3_bn_relu_hl16_dma(_ptr(inp), _ptr(wp), _ptr(bias), _ptr(out), L, H, W, Cin,
-                                                     Cout, int(pool), float(oscale), self._stream())
-        _lib.check(st, 'mmmot_conv3x3_bn_relu_hl16_dma')
-
     def conv3x3_hl16_patch(self, inp, wp, bias, out, L, H, W, Cin, Cout, pool, oscale):
-        """Same contract as conv3x3_hl16; LDS-resident haloed patch kernel (256 pixels per workgroup)."""
+        """fp16-split trunk layer (LDS-resident haloed patch kernel): inp/out/wp are fp32-typed buffers holding hl16
+        data (same bytes), oscale the [Cout] vector of per-output-channel 2^-shift."""
         st = self.lib.mmmot_conv3x3_bn_relu_hl16_patch(_ptr(inp), _ptr(wp), _ptr(bias), _ptr(out), L, H, W, Cin,
-                                                       Cout, int(pool), float(oscale), self._stream())
+                                                       Cout, int(pool), _ptr(self._osv(oscale, Cout, out)), self._stream())
         _lib.check(st, 'mmmot_conv3x3_bn_relu_hl16_patch')
 
     def conv1_fused_hl16(self, crops, w1, bias1, oscale1, w2, bias2, oscale2, out, L, H, W):
         """conv1_1 + conv1_2 + max-pool in one launch (the conv1_1 tensor never reaches HBM)."""
         st = self.lib.mmmot_conv1_fused_hl16(_ptr(crops), _ptr(w1), _ptr(bias1), float(oscale1), _ptr(w2),
-                                             _ptr(bias2), float(oscale2), _ptr(out), L, H, W, self._stream())
+                                             _ptr(bias2), _ptr(self._osv(oscale2, 64, out)), _ptr(out), L, H, W, self._stream())
         _lib.check(st, 'mmmot_conv1_fused_hl16')
 
     def conv3x3_hq8(self, inp, wp, bias, out, L, H, W, Cin, Cout, pool, oscale):
         """conv3x3_hl16_patch in hq8 arithmetic: activations / weights are hq8 records (pack.to_hq8_act / to_hq8_w)."""
         st = self.lib.mmmot_conv3x3_bn_relu_hq8(_ptr(inp), _ptr(wp), _ptr(bias), _ptr(out), L, H, W, Cin, Cout,
-                                                int(pool), float(oscale), self._stream())
+                                                int(pool), _ptr(self._osv(oscale, Cout, out)), self._stream())
         _lib.check(st, 'mmmot_conv3x3_bn_relu_hq8')
 
     def conv1_fused_hq8(self, crops, w1, bias1, oscale1, w2, bias2, oscale2, out, L, H, W):
         """conv1_fused_hl16 with conv1_2 in hq8 arithmetic (w1 hl16, w2 hq8, out hq8)."""
         st = self.lib.mmmot_conv1_fused_hq8(_ptr(crops), _ptr(w1), _ptr(bias1), float(oscale1), _ptr(w2),
-                                            _ptr(bias2), float(oscale2), _ptr(out), L, H, W, self._stream())
+                                            _ptr(bias2), _ptr(self._osv(oscale2, 64, out)), _ptr(out), L, H, W, self._stream())
         _lib.check(st, 'mmmot_conv1_fused_hq8')
+
+    def trunk_range_read(self, device, reset=True):
+        """(e4m3-saturated, fp16-clamped, conv1_1 hits, 0) activation-element counters of the trunk epilogues on
+        ``device`` since the last reset; synchronises the current stream (see mmmot_trunk_range_read)."""
+        if torch.device(device).type != 'cuda':
+            raise RuntimeError('mmmot_amd HIP ops need device tensors (got %s); there is no CPU fallback' % device)
+        buf = (ctypes.c_uint * 4)()
+        with torch.cuda.device(device):
+            torch.cuda.current_stream().synchronize()
+            _lib.check(self.lib.mmmot_trunk_range_read(buf, int(reset)), 'mmmot_trunk_range_read')
+        return tuple(int(v) for v in buf)
 
     def hq8_pack(self, x, y):
         _lib.check(self.lib.mmmot_hq8_pack(_ptr(x), _ptr(y), x.numel(), self._stream()), 'mmmot_hq8_pack')

@@ -106,6 +106,18 @@ def hl16_weight_shift(w):
     return 0 if m == 0.0 else max(-14, min(24, int(math.floor(math.log2(16384.0 / m)))))
 
 
+def hl16_channel_shifts(wp):
+    """Per-OUTPUT-channel power-of-two pre-scales of a trunk weight [9][Cout][Cin] (fp64): channel n is scaled so that
+    max|w[:, n, :]| lands in (2^13, 2^14].  A trained, BatchNorm-folded VGG layer has per-channel gains
+    gamma / sqrt(var + eps) spread over orders of magnitude; with ONE scale per layer the e4m3 copies of a low-gain
+    channel (hq8: e4m3(32 w_lo) underflows below 2^-9, e4m3(w_hi / 64) loses its 3 mantissa bits below 2^-6) would
+    silently drop that channel's correction terms.  Returns an int64 tensor [Cout]."""
+    import math
+    m = wp.abs().amax(dim=(0, 2))
+    return torch.tensor([0 if float(v) == 0.0 else max(-14, min(40, int(math.floor(math.log2(16384.0 / float(v))))))
+                         for v in m], dtype=torch.int64)
+
+
 def _add_hl16_copies(P, device):
     """For every row-GEMM weight ([N][K] fp32, K % 64 == 0) add ``<name>_h16`` (hl16 split-half copy
     scaled by 2^shift) and ``<name>_os`` (= 2^-shift) so the engine can run the GEMM on the fp16
@@ -167,14 +179,21 @@ def pack_weights(sd, fusion, device, eps=1e-5):
                     wp = w.permute(2, 3, 0, 1).reshape(9, cout, cin)
                 cv = dict(wp=f32(wp), bias=f32(b), cin=cin, cout=cout, pool=pool, stage=s,
                           last=(idx == stage[-1][0]))
-                if True:
-                    # fp16-split (hl16) copy for the f16 matrix-core trunk: weights scaled by 2^shift (the first
-                    # layer's [Cout][32] copy feeds the fused conv1_1+conv1_2 kernel)
+                if cin == 3:
+                    # fp16-split (hl16) copy of the first layer's [Cout][32] weights for the fused conv1_1+conv1_2
+                    # kernel: one power-of-two scale for the layer (hl16 keeps 22 bits down to 2^-17 of the maximum)
                     shift = hl16_weight_shift(wp)
                     cv['wp16'] = to_hl16(wp * (2.0 ** shift)).contiguous().to(device)
                     cv['oscale'] = 2.0 ** (-shift)
-                    if cin != 3:  # hq8 copy (opt-in trunk mode 'f16q8'), same 2^shift scaling
-                        cv['wpq8'] = to_hq8_w(wp * (2.0 ** shift)).contiguous().to(device)
+                else:
+                    # hl16 ('f16x3') and hq8 ('f16q8') copies for the matrix-core trunk: every OUTPUT channel scaled
+                    # by its own power of two (exact), undone by the [Cout] vector `oscale` in the epilogue
+                    shifts = hl16_channel_shifts(wp)
+                    ws = wp * torch.pow(2.0, shifts.to(torch.float64)).reshape(1, -1, 1)
+                    cv['wp16'] = to_hl16(ws).contiguous().to(device)
+                    cv['wpq8'] = to_hq8_w(ws).contiguous().to(device)
+                    cv['oscale'] = f32(torch.pow(2.0, -shifts.to(torch.float64)))
+                    cv['wshift'] = shifts
                 convs.append(cv)
         P['vgg'] = convs
         heads = []

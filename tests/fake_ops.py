@@ -37,6 +37,26 @@ class TorchOps:
 
     def __init__(self, dtype=torch.float32):
         self.dtype = dtype
+        self.range = [0, 0, 0, 0]  # emulation of the trunk range-guard counters (mmmot_trunk_range_read)
+
+    @staticmethod
+    def _osv(oscale, Cout):
+        """per-output-channel scale [Cout] (a python float = the same scale for every channel) -> [1, Cout, 1, 1]"""
+        if torch.is_tensor(oscale):
+            return oscale.reshape(1, Cout, 1, 1).double()
+        return torch.full((1, Cout, 1, 1), float(oscale), dtype=torch.float64)
+
+    def _guard(self, rows, q8):
+        """rows: post-ReLU activations about to be stored; counts what the epilogue's range guard counts"""
+        if q8:
+            self.range[0] += int((rows > 1792.0).sum())
+        self.range[1] += int((rows > 65000.0).sum())
+
+    def trunk_range_read(self, device=None, reset=True):
+        r = tuple(self.range)
+        if reset:
+            self.range = [0, 0, 0, 0]
+        return r
 
     def conv3x3(self, inp, wp, bias, out, L, H, W, Cin, Cout, first, pool):
         if first:
@@ -51,28 +71,25 @@ class TorchOps:
         out.view(L, y.shape[2], y.shape[3], Cout).copy_(y.permute(0, 2, 3, 1).to(out.dtype))
 
     # ---- hl16 (fp16 hi/lo split) trunk: same conv, operands/outputs stored split-half ----------
-    def conv3x3_hl16_patch(self, *a):
-        return self.conv3x3_hl16(*a)
-
-    def conv3x3_hl16_dma(self, *a):
-        return self.conv3x3_hl16(*a)
-
-    def conv3x3_hl16(self, inp, wp, bias, out, L, H, W, Cin, Cout, pool, oscale):
+    def conv3x3_hl16_patch(self, inp, wp, bias, out, L, H, W, Cin, Cout, pool, oscale):
         from mmmot_amd.pack import from_hl16, to_hl16
         x = from_hl16(inp.reshape(-1)[:L * H * W * Cin].view(L * H * W, Cin)).view(L, H, W, Cin).permute(0, 3, 1, 2)
-        w = from_hl16(wp.reshape(9 * Cout, Cin)).view(3, 3, Cout, Cin).permute(2, 3, 0, 1) * oscale
+        w = from_hl16(wp.reshape(9 * Cout, Cin)).view(3, 3, Cout, Cin).permute(2, 3, 0, 1)
+        w = (w.double() * self._osv(oscale, Cout).reshape(Cout, 1, 1, 1))  # exact: powers of two
         y = torch.relu(torch.nn.functional.conv2d(x.to(self.dtype), w.to(self.dtype), bias.to(self.dtype), padding=1))
         if pool:
             y = torch.nn.functional.max_pool2d(y, 2, 2)
         rows = y.permute(0, 2, 3, 1).reshape(-1, Cout)
-        out.reshape(-1)[:rows.numel()].view(-1, Cout).copy_(to_hl16(rows))
+        self._guard(rows, False)
+        out.reshape(-1)[:rows.numel()].view(-1, Cout).copy_(to_hl16(rows.clamp(max=65000.0)))
 
     def conv1_fused_hl16(self, crops, w1, bias1, oscale1, w2, bias2, oscale2, out, L, H, W):
         from mmmot_amd.pack import from_hl16, to_hl16
         w1f = from_hl16(w1.reshape(64, 32)) * oscale1
         tmp = torch.zeros(L * H * W, 64)
         self.conv3x3(crops, w1f, bias1, tmp, L, H, W, 3, 64, True, False)
-        self.conv3x3_hl16(to_hl16(tmp), w2, bias2, out, L, H, W, 64, 64, True, oscale2)
+        self.range[2] += int((tmp > 65000.0).any())
+        self.conv3x3_hl16_patch(to_hl16(tmp.clamp(max=65000.0)), w2, bias2, out, L, H, W, 64, 64, True, oscale2)
 
     def _conv_hq8(self, x, wp, bias, L, H, W, Cin, Cout, pool, oscale):
         """the hq8 arithmetic: hi*hi + 2^-3 (a8 * w_lo8 + a_lo8 * w8), x = decoded parts (hi, a8, al8) NHWC"""
@@ -81,7 +98,7 @@ class TorchOps:
         ah, a8, al8 = [t.reshape(L, H, W, Cin).permute(0, 3, 1, 2).to(self.dtype) for t in x]
         cv = torch.nn.functional.conv2d
         y = cv(ah, wh, None, padding=1) + 0.125 * (cv(a8, wl8, None, padding=1) + cv(al8, w8, None, padding=1))
-        y = torch.relu(y * oscale + bias.to(self.dtype).view(1, -1, 1, 1))
+        y = torch.relu(y * self._osv(oscale, Cout).to(self.dtype) + bias.to(self.dtype).view(1, -1, 1, 1))
         if pool:
             y = torch.nn.functional.max_pool2d(y, 2, 2)
         return y.permute(0, 2, 3, 1).reshape(-1, Cout)
@@ -90,6 +107,7 @@ class TorchOps:
         from mmmot_amd.pack import hq8_parts, to_hq8_act
         x = hq8_parts(inp.reshape(-1)[:L * H * W * Cin].view(L * H * W, Cin))
         rows = self._conv_hq8(x, wp, bias, L, H, W, Cin, Cout, pool, oscale)
+        self._guard(rows, True)
         out.reshape(-1)[:rows.numel()].view(-1, Cout).copy_(to_hq8_act(rows))
 
     def conv1_fused_hq8(self, crops, w1, bias1, oscale1, w2, bias2, oscale2, out, L, H, W):
@@ -97,7 +115,9 @@ class TorchOps:
         w1f = from_hl16(w1.reshape(64, 32)) * oscale1
         tmp = torch.zeros(L * H * W, 64)
         self.conv3x3(crops, w1f, bias1, tmp, L, H, W, 3, 64, True, False)
+        self.range[2] += int((tmp > 1792.0).any())
         rows = self._conv_hq8(hq8_parts(to_hq8_act(tmp)), w2, bias2, L, H, W, 64, 64, True, oscale2)
+        self._guard(rows, True)
         out.reshape(-1)[:rows.numel()].view(-1, 64).copy_(to_hq8_act(rows))
 
     def hq8_pack(self, x, y):

@@ -9,9 +9,16 @@ from mmmot_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
+def declared_symbols(debug=False):
+    """entry points of include/mmmot_hip.h; the `#ifdef MMMOT_DEBUG` block (timing experiments of tools/, absent from
+    the product library) is returned separately with debug=True"""
     text = open(os.path.join(ROOT, 'include', 'mmmot_hip.h')).read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    dbg = ''.join(re.findall(r'#ifdef MMMOT_DEBUG(.*?)#endif', text, flags=re.S))
+    if not debug:
+        text = re.sub(r'#ifdef MMMOT_DEBUG.*?#endif', '', text, flags=re.S)
+    else:
+        text = dbg
     return sorted(set(re.findall(r'\bint\s+(mmmot_\w+)\s*\(', text)))
 
 
@@ -24,11 +31,16 @@ def test_library_builds_and_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), 'symbol %s declared in include/mmmot_hip.h but not exported' % s
     assert set(syms) == set(_lib.SIGNATURES), (set(syms) ^ set(_lib.SIGNATURES))
+    # experiment knobs live behind -DMMMOT_DEBUG: declared, bound by _lib when present, NOT in the product library
+    dbg = declared_symbols(debug=True)
+    assert set(dbg) == set(_lib.DEBUG_SIGNATURES) and dbg
+    for s in dbg:
+        assert not hasattr(lib, s), 'debug entry point %s leaked into the product library' % s
 
 
 def test_abi_version_and_argument_checks_without_gpu():
     lib = _lib.load()
-    assert lib.mmmot_abi_version() == 3
+    assert lib.mmmot_abi_version() == 4
     # contract violations are rejected before any launch (safe on a GPU-less host)
     assert lib.mmmot_gemm_rows(None, None) == -1
     assert lib.mmmot_conv3x3_bn_relu(None, None, None, None, 1, 8, 8, 64, 64, 0, 0, None) == -1

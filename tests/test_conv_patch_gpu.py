@@ -1,5 +1,4 @@
-"""The LDS-resident-patch trunk kernel (conv3x3_hl16_patch.hip) must agree with the fp64 convolution like the
-register-staged kernel does (same arithmetic, different machine mapping).  Geometry cases exercise both block
+"""The LDS-resident-patch trunk kernel (conv3x3_hl16_patch.hip) must agree with the fp64 convolution.  Geometry cases exercise both block
 shapes (16x16x1, 8x8x4), partial blocks (maps that are not multiples of the block), maps smaller than a block,
 tiles that straddle crops, partial last tiles and 2..16 channel slabs."""
 import pytest
@@ -85,17 +84,11 @@ def test_conv3x3_hl16_patch_chained_tiles(hip, small_grid, pool, L, H, W, Cin, C
     assert torch.equal(out.cpu(), u2.cpu()), 'chained and unchained launches differ'
 
 
-def test_patch_matches_tile_kernel_and_is_deterministic(hip):
-    """Same inputs through the register-staged tile kernel: fp32 accumulation order differs (32- vs 64-channel
-    slabs), values must agree to fp32 rounding; repeated launches of the patch kernel are bitwise identical
-    (no race in the DMA ring / counted-vmcnt pipeline)."""
+def test_patch_kernel_is_deterministic(hip):
+    """repeated launches of the patch kernel are bitwise identical (no race in the DMA ring / counted-vmcnt
+    pipeline)."""
     pool, L, H, W, Cin, Cout = 0, 6, 16, 16, 256, 256
     out, ref, (x16, w16, bias, shift) = run_case(hip, pool, L, H, W, Cin, Cout, seed=440)
-    o_tile = torch.zeros(L * H * W, Cout).cuda()
-    hip.conv3x3_hl16(x16.cuda(), w16.cuda(), bias.cuda(), o_tile, L, H, W, Cin, Cout, False, 2.0 ** -shift)
-    t = torch.zeros_like(o_tile)
-    hip.hl16_unpack(o_tile, t)
-    close(out, t, 2e-6, 'patch kernel vs tile kernel')
     xs, ws, bs = x16.cuda(), w16.cuda(), bias.cuda()
     first = None
     for _ in range(20):
@@ -105,6 +98,36 @@ def test_patch_matches_tile_kernel_and_is_deterministic(hip):
             first = o.clone()
         else:
             assert torch.equal(first, o), 'patch kernel is not deterministic across launches'
+
+
+@pytest.mark.parametrize('pool,L,H,W,Cin,Cout', [(0, 3, 16, 16, 64, 128), (1, 2, 8, 8, 128, 64), (1, 2, 32, 32, 64, 256)])
+def test_conv3x3_hl16_patch_per_channel_scales(hip, pool, L, H, W, Cin, Cout):
+    """Output channels with gains spread over 1e6 (a trained, BatchNorm-folded layer): every channel carries its own
+    power-of-two weight scale (pack.hl16_channel_shifts) and the [Cout] vector undoes it in the epilogue; each channel
+    must keep fp32-class RELATIVE accuracy."""
+    from mmmot_amd.pack import hl16_channel_shifts
+    g = torch.Generator().manual_seed(77)
+    gain = torch.pow(10.0, torch.rand(Cout, generator=g) * 6.0 - 4.0).double()     # 1e-4 .. 1e2
+    x = torch.relu(rnd(L * H * W, Cin, seed=480)) * 3.0
+    w = rnd(9, Cout, Cin, seed=481, scale=(2.0 / (9 * Cin)) ** 0.5).double() * gain.view(1, -1, 1)
+    bias = (rnd(Cout, seed=482, scale=0.1).double() * gain).float()
+    shifts = hl16_channel_shifts(w)
+    assert int(shifts.max() - shifts.min()) >= 15
+    w16 = to_hl16(w * torch.pow(2.0, shifts.double()).view(1, -1, 1))
+    osc = torch.pow(2.0, -shifts.double()).float()
+    x16 = to_hl16(x)
+    emu = TorchOps(torch.float64)
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    ref = torch.zeros(L * Ho * Wo, Cout, dtype=torch.float64)
+    wv = from_hl16(w16).double() * osc.double().view(1, -1, 1)
+    emu.conv3x3(from_hl16(x16).view(L, H, W, Cin), wv, bias, ref, L, H, W, Cin, Cout, False, bool(pool))
+    out16 = torch.full((L * Ho * Wo, Cout), float('nan')).cuda()
+    hip.conv3x3_hl16_patch(x16.cuda(), w16.cuda(), bias.cuda(), out16, L, H, W, Cin, Cout, bool(pool), osc.cuda())
+    out = torch.zeros_like(out16)
+    hip.hl16_unpack(out16, out)
+    rel = ((out.cpu().double() - ref).abs().amax(dim=0) / ref.abs().amax(dim=0).clamp_min(1e-30)).max().item()
+    print('per-channel-scale conv: worst per-channel relative error %.2e' % rel)
+    assert rel < 4e-6, rel
 
 
 @pytest.mark.parametrize('L,H,W', [(2, 16, 16), (3, 32, 48), (1, 14, 22), (5, 64, 64), (2, 8, 8)])

@@ -182,12 +182,33 @@ def test_segment_mean_reads_hq8(hip):
     close(out, want, 2e-6, 'segment mean over hq8 rows')
 
 
+@pytest.mark.parametrize('pool,L,H,W,Cin,Cout', [(0, 3, 16, 16, 64, 128), (1, 2, 8, 8, 128, 64), (1, 2, 32, 32, 64, 256)])
+def test_conv3x3_hq8_per_channel_scales(hip, pool, L, H, W, Cin, Cout):
+    """output channels with gains spread over 1e6, every channel with its own power-of-two weight scale and the
+    [Cout] vector undoing it in the epilogue: every channel matches the emulation of the hq8 arithmetic (what the
+    per-channel scales buy in accuracy is pinned on the host side, tests/test_hq8_pack_cpu.py)"""
+    from mmmot_amd.pack import hl16_channel_shifts
+    g = torch.Generator().manual_seed(78)
+    gain = torch.pow(10.0, torch.rand(Cout, generator=g) * 6.0 - 4.0).double()
+    x = torch.relu(rnd(L * H * W, Cin, seed=490)) * 3.0
+    w = rnd(9, Cout, Cin, seed=491, scale=(2.0 / (9 * Cin)) ** 0.5).double() * gain.view(1, -1, 1)
+    bias = (rnd(Cout, seed=492, scale=0.1).double() * gain).float()
+    shifts = hl16_channel_shifts(w)
+    osc = torch.pow(2.0, -shifts.double()).float()
+    xrec, wrec = to_hq8_act(x), to_hq8_w(w * torch.pow(2.0, shifts.double()).view(1, -1, 1))
+    dec, ref, _ = run_records(hip, xrec, wrec, bias, pool, L, H, W, Cin, Cout, osc)
+    per_ch = ((dec.cpu().double() - ref.double()).abs().amax(dim=0) / ref.double().abs().amax(dim=0).clamp_min(1e-30))
+    print('hq8 per-channel scales: worst per-channel relative deviation from the emulation %.2e' % per_ch.max().item())
+    assert per_ch.max().item() < ENC_TOL, 'kernel differs from the emulation of the hq8 arithmetic'
+
+
 @pytest.mark.parametrize('name', case_names())
 def test_f16q8_forward_matches_reference_golden(name):
     c, base = get_case(name)
     m = build_model(c, base, device='cuda')
     m.set_trunk('f16q8')
     m.engine().q8_min_crop = 0  # the fixtures include 32-pixel crops: exercise the e4m3 arithmetic on them too
+    m.engine().q8_layers = None  # ... on every trunk layer (the default keeps the first three in f16x3)
     assert m.engine().ops.name == 'hip' and m.engine().trunk == 'f16q8'
     with torch.no_grad():
         out = m(*to_dev(case_inputs(c)))
@@ -202,6 +223,7 @@ def test_f16q8_unfused_first_layer_matches_golden(monkeypatch):
     m = build_model(c, base, device='cuda')
     m.set_trunk('f16q8')
     m.engine().q8_min_crop = 0
+    m.engine().q8_layers = None
     with torch.no_grad():
         out = m(*to_dev(case_inputs(c)))
     compare_outputs(out, golden(name), tol=TOL)
@@ -229,7 +251,7 @@ SURVEY = [  # (fusion, affinity, softmax, N, M, S, pts)
 
 @pytest.mark.parametrize('fusion,aff,sm,N,M,S,pts', SURVEY)
 def test_f16q8_fresh_inputs_against_oracle(fusion, aff, sm, N, M, S, pts):
-    """the default trunk arithmetic carries e4m3 correction terms: beyond the golden fixtures, fresh seeds / crop
+    """the opt-in f16q8 trunk arithmetic carries e4m3 correction terms: beyond the golden fixtures, fresh seeds / crop
     sizes / ragged point counts against the CPU oracle, every output within the 1e-3 budget (margins are printed)"""
     from mmmot_amd.synth import make_pair
     from oracle import restatement as R
@@ -238,8 +260,9 @@ def test_f16q8_fresh_inputs_against_oracle(fusion, aff, sm, N, M, S, pts):
     m = build_model(c, base)
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     m = m.to('cuda')
-    assert m.trunk == 'f16q8'
+    m.set_trunk('f16q8')
     m.engine().q8_min_crop = 0  # force the e4m3 arithmetic below the default minimum crop side as well
+    m.engine().q8_layers = None  # and on every trunk layer
     cfg = dict(fusion=fusion, affinity_op=aff, softmax_mode=sm, neg_threshold=base['neg_threshold'],
                score_arch=base['score_arch'])
     worst = {}

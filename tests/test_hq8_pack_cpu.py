@@ -84,3 +84,33 @@ def test_hq8_product_identity():
     err_main = float((main_only - exact).abs().max()) / scale
     assert err_q8 < 3e-5, err_q8
     assert err_main > 4 * err_q8, (err_main, err_q8)   # the correction terms do their job
+
+
+def test_per_channel_weight_scales_keep_low_gain_channels_precise():
+    """Output channels with gains spread over 1e6 (a trained, BatchNorm-folded layer).  With ONE power-of-two scale
+    for the layer the e4m3 copies of the low-gain channels underflow (their correction terms vanish: the effective
+    weight hi + e4m3(32 w_lo) / 32 is fp16-class, 2^-12); with a scale per output channel (pack.hl16_channel_shifts)
+    every channel's effective weight is within 2^-15 of the true one, relative to that channel's largest weight."""
+    from mmmot_amd.pack import hl16_channel_shifts
+    Cout, Cin = 128, 64
+    g = torch.Generator().manual_seed(5)
+    gain = torch.pow(10.0, torch.rand(Cout, generator=g) * 6.0 - 4.0).double()
+    w = rnd(9, Cout, Cin, seed=6, scale=0.05).double() * gain.view(1, -1, 1)
+
+    def per_channel_error(scaled, unscale):
+        hi, wl8, _ = hq8_parts(to_hq8_w(scaled))
+        eff = (hi + wl8 / 32.0) * unscale
+        return ((eff - w).abs().amax(dim=(0, 2)) / w.abs().amax(dim=(0, 2))).max().item()
+
+    sh = hl16_channel_shifts(w)
+    assert int(sh.max() - sh.min()) >= 15
+    e_vec = per_channel_error(w * torch.pow(2.0, sh.double()).view(1, -1, 1), torch.pow(2.0, -sh.double()).view(1, -1, 1))
+    s1 = hl16_weight_shift(w)
+    e_one = per_channel_error(w * 2.0 ** s1, 2.0 ** -s1)
+    assert e_vec < 2.0 ** -15, e_vec
+    assert e_one > 2.0 ** -13, e_one
+    # the a_lo * w_hi operand: e4m3(w_hi / 64) keeps its 3 mantissa bits for every channel only with per-channel scales
+    _, _, w8 = hq8_parts(to_hq8_w(w * torch.pow(2.0, sh.double()).view(1, -1, 1)))
+    assert (w8.abs().amax(dim=(0, 2)) >= 128.0).all()   # every channel's largest weight sits in e4m3's top binades
+    _, _, w8 = hq8_parts(to_hq8_w(w * 2.0 ** s1))
+    assert (w8.abs().amax(dim=(0, 2)) < 2.0 ** -6).any()  # one scale: some channels are entirely subnormal / zero

@@ -351,7 +351,7 @@ def test_conv3x3_hl16(hip, pool, L, H, W, Cin, Cout):
     emu.conv3x3(from_hl16(x16).view(L, H, W, Cin), (from_hl16(w16) * 2.0 ** -shift), bias, ref, L, H, W, Cin, Cout,
                 False, bool(pool))
     out16 = torch.zeros(L * Ho * Wo, Cout).cuda()
-    hip.conv3x3_hl16(x16.cuda(), w16.cuda(), bias.cuda(), out16, L, H, W, Cin, Cout, bool(pool), 2.0 ** -shift)
+    hip.conv3x3_hl16_patch(x16.cuda(), w16.cuda(), bias.cuda(), out16, L, H, W, Cin, Cout, bool(pool), 2.0 ** -shift)
     out = torch.zeros_like(out16)
     hip.hl16_unpack(out16, out)
     close(out, ref, 2e-6, 'conv3x3 hl16 (3-term fp16 split) vs fp64')
@@ -387,7 +387,7 @@ def test_hl16_small_magnitudes_keep_absolute_accuracy(hip):
     ref = torch.zeros(L * H * W, Cout)
     emu.conv3x3(x.view(L, H, W, Cin), w, bias, ref, L, H, W, Cin, Cout, False, False)   # exact fp32 inputs
     out16 = torch.zeros(L * H * W, Cout).cuda()
-    hip.conv3x3_hl16(x16.cuda(), w16.cuda(), bias.cuda(), out16, L, H, W, Cin, Cout, False, 2.0 ** -shift)
+    hip.conv3x3_hl16_patch(x16.cuda(), w16.cuda(), bias.cuda(), out16, L, H, W, Cin, Cout, False, 2.0 ** -shift)
     out = torch.zeros_like(out16)
     hip.hl16_unpack(out16, out)
     err = (out.cpu().double() - ref.double()).abs().max().item()

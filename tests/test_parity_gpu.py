@@ -33,7 +33,7 @@ def test_hip_forward_matches_reference_golden(name, trunk):
     print(name, {k: '%.1e' % v for k, v in errs.items()})
 
 
-@pytest.mark.parametrize('trunk', ['f16q8', 'f16x3', 'f32'])
+@pytest.mark.parametrize('trunk', ['f16x3', 'f16q8', 'f16q8-all', 'f32'])
 @pytest.mark.parametrize('name', full_case_names())
 def test_full_size_forward_matches_reference_golden(name, trunk):
     """BASELINE.json sizes against outputs of the IMPORTED REFERENCE (oracle/gen_golden.py, cases f_*):
@@ -42,7 +42,9 @@ def test_full_size_forward_matches_reference_golden(name, trunk):
     512 pts/det; plus a ragged N != M variant of each.  All three trunk arithmetics."""
     c, base = get_case(name)
     m = build_model(c, base, device=DEV)
-    m.set_trunk(trunk)
+    m.set_trunk(trunk.split('-')[0])
+    if trunk == 'f16q8-all':
+        m.engine().q8_layers = None  # e4m3 correction terms on every trunk layer (default: layers 4..12)
     with torch.no_grad():
         out = m(*to_dev(case_inputs(c)))
     errs = compare_outputs(out, golden(name), tol=TOL)
@@ -189,12 +191,12 @@ def test_full_size_properties_cfg3_sizes_with_cfg4_modes():
 
 
 @pytest.mark.parametrize('knobs', [
-    dict(conv_impl='tile'), dict(conv_impl='dma'), dict(fuse_conv1=False), dict(pn_gram=False), dict(pn_fused=False),
-    dict(conv_impl='tile', pn_fused=False, pn_gram=False, fuse_conv1=False)], ids=lambda k: ','.join('%s=%s' % kv for kv in k.items()))
+    dict(fuse_conv1=False), dict(pn_gram=False), dict(pn_fused=False),
+    dict(pn_fused=False, pn_gram=False, fuse_conv1=False)], ids=lambda k: ','.join('%s=%s' % kv for kv in k.items()))
 @pytest.mark.parametrize('name', ['s4_cfg2_A', 's2_C_minus_abs_dual_add', 's3_kitti_A'])
 def test_alternative_engine_paths_match_golden(name, knobs):
-    """Every machine mapping the engine can be switched to (tile / LDS-DMA trunk kernels, unfused conv1,
-    statistics pass instead of the Gram route, materialising PointNet) stays inside the same tolerance."""
+    """Every machine mapping the engine can be switched to (unfused conv1, statistics pass instead of the Gram
+    route, materialising PointNet) stays inside the same tolerance."""
     if name not in case_names():
         pytest.skip('no such golden case')
     c, base = get_case(name)

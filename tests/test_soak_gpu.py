@@ -14,11 +14,13 @@ KW = dict(seq_len=2, score_arch='branch_cls', appear_arch='vgg', appear_len=512,
           softmax_mode='none')
 
 
+@pytest.mark.parametrize('trunk', ['f16x3', 'f16q8'])
 @pytest.mark.parametrize('N,M,S,pts,B,reps', [(64, 64, 128, 2048, 2, 12), (7, 9, 64, 300, 3, 40)])
-def test_repeated_forwards_are_bitwise_identical(N, M, S, pts, B, reps):
+def test_repeated_forwards_are_bitwise_identical(N, M, S, pts, B, reps, trunk):
     model = TrackingNet(**KW)
     init_module(model, seed=0)
     model.eval().cuda()
+    model.set_trunk(trunk)
     ins = [make_pair(N, M, S, pts, seed=700 + i, ragged=(pts < 1000)) for i in range(B)]
     samples = [([N, M], x[1]['points_split'].reshape(-1).long().numpy()) for x in ins]
     plan = model.make_plan(samples, S)

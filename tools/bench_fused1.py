@@ -9,6 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mmmot_amd import _lib  # noqa: E402
+_lib.LIB_PATH = _lib.build(debug=True)  # the -DMMMOT_DEBUG build carries the timing experiments (never the product library)
 from mmmot_amd.ops import HipOps  # noqa: E402
 from mmmot_amd.pack import hl16_weight_shift, to_hl16, to_hq8_w  # noqa: E402
 
