@@ -125,9 +125,14 @@ def test_conv3x3_hl16_patch_per_channel_scales(hip, pool, L, H, W, Cin, Cout):
     hip.conv3x3_hl16_patch(x16.cuda(), w16.cuda(), bias.cuda(), out16, L, H, W, Cin, Cout, bool(pool), osc.cuda())
     out = torch.zeros_like(out16)
     hip.hl16_unpack(out16, out)
-    rel = ((out.cpu().double() - ref).abs().amax(dim=0) / ref.abs().amax(dim=0).clamp_min(1e-30)).max().item()
-    print('per-channel-scale conv: worst per-channel relative error %.2e' % rel)
-    assert rel < 4e-6, rel
+    # per channel: fp32-class relative to the channel's largest output, plus the absolute quantum of the hl16 OUTPUT
+    # format (the lo half of a value below ~2.5e-4 is an fp16 subnormal: 2^-25 absolute, see
+    # test_hl16_small_magnitudes_keep_absolute_accuracy)
+    err, chmax = (out.cpu().double() - ref).abs().amax(dim=0), ref.abs().amax(dim=0)
+    rel = (err / chmax.clamp_min(1e-30)).max().item()
+    print('per-channel-scale conv: worst per-channel relative error %.2e (output maxima %.1e .. %.1e)' % (
+        rel, chmax.min().item(), chmax.max().item()))
+    assert (err <= 4e-6 * chmax + 2.0 ** -24).all(), rel
 
 
 @pytest.mark.parametrize('L,H,W', [(2, 16, 16), (3, 32, 48), (1, 14, 22), (5, 64, 64), (2, 8, 8)])

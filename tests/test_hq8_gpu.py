@@ -51,7 +51,8 @@ def run_records(hip, xrec, wrec, bias, pool, L, H, W, Cin, Cout, oscale):
     ref = emu._conv_hq8(hq8_parts(xrec), wrec, bias, L, H, W, Cin, Cout, bool(pool), oscale).float()
     Ho, Wo = (H // 2, W // 2) if pool else (H, W)
     out = torch.full((L * Ho * Wo, Cout), float('nan')).cuda()
-    hip.conv3x3_hq8(xrec.cuda(), wrec.cuda(), bias.cuda(), out, L, H, W, Cin, Cout, bool(pool), oscale)
+    hip.conv3x3_hq8(xrec.cuda(), wrec.cuda(), bias.cuda(), out, L, H, W, Cin, Cout, bool(pool),
+                    oscale.cuda() if torch.is_tensor(oscale) else oscale)
     dec = torch.zeros_like(out)
     hip.hq8_unpack(out, dec)
     return dec, ref, out
