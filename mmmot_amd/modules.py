@@ -21,6 +21,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import torch_ops
 from .engine import Engine
 from .pack import VGG_STAGES, pack_weights
 from .plan import BatchPlan
@@ -68,10 +69,7 @@ class AppearanceNet(nn.Module):
         eng = _standalone_engine(self, 'appearance.')
         L, S = x.shape[0], x.shape[-1]
         plan = BatchPlan(_dummy_samples(L), S, x.device, use_points=False)
-        eng.dev = x.device
-        cat = eng.buf('cat', L, 1024)
-        eng.appearance(plan, x.contiguous(), cat)
-        return cat[:, :512].clone()
+        return torch.ops.mmmot.appearance(x.contiguous(), torch_ops.engine_handle(eng), torch_ops.plan_handle(plan))
 
 
 class STN3d(nn.Module):
@@ -137,12 +135,9 @@ class PointNet_v1(nn.Module):
         ps = point_split.detach().cpu().numpy().astype(np.int64)
         L = ps.shape[0] - 1
         plan = BatchPlan([(_dummy_samples(L)[0][0], ps)], 32, x.device)
-        eng.dev = x.device
-        cat = eng.buf('cat', L, 1024)
-        pts = x[0].t().contiguous()
-        eng.pointnet(plan, pts, cat)
+        feat = torch.ops.mmmot.pointnet(x[0].t().contiguous(), torch_ops.engine_handle(eng), torch_ops.plan_handle(plan))
         pn = eng.P['pointnet']
-        return cat[:, 512:].clone(), [pn['trans1'].unsqueeze(0).clone(), pn['trans2'].unsqueeze(0).clone()]
+        return feat, [pn['trans1'].unsqueeze(0).clone(), pn['trans2'].unsqueeze(0).clone()]
 
 
 def _conv_gn(cin, cout, groups):
@@ -267,6 +262,34 @@ def _standalone_engine(module, prefix, **cfg):
     return cache[1]
 
 
+class GraphedForward:
+    """See ``TrackingNet.capture``."""
+
+    def __init__(self, model, plan, crops, points):
+        self.plan = plan
+        self.crops = None if crops is None else crops.clone()
+        self.points = None if points is None else points.clone()
+        eng = model.engine()
+        with torch.no_grad():
+            model.forward_batch(plan, self.crops, self.points)   # warm-up: workspace allocation, range-guard check
+            torch.cuda.synchronize()
+            eng.range_guard, guard = False, eng.range_guard      # the guard's counter read would synchronise
+            self.graph = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(self.graph):
+                    self.result = model.forward_batch(plan, self.crops, self.points)
+            finally:
+                eng.range_guard = guard
+
+    def __call__(self, crops=None, points=None):
+        if crops is not None and crops.data_ptr() != self.crops.data_ptr():
+            self.crops.copy_(crops, non_blocking=True)
+        if points is not None and points.data_ptr() != self.points.data_ptr():
+            self.points.copy_(points, non_blocking=True)
+        self.graph.replay()
+        return self.result
+
+
 class TrackingNet(nn.Module):
     """Reference-compatible tracking network (modules/tracking_net.py:15-193), HIP forward."""
 
@@ -366,7 +389,14 @@ class TrackingNet(nn.Module):
         if self.training:
             raise NotImplementedError('mmmot_amd.TrackingNet computes the eval-mode forward only (call .eval(); the '
                                       'training-mode forward / backward of tracking_model.py:50-66 is not built)')
-        out = self.engine().forward(plan, crops, points)
+        eng = self.engine()
+        if eng.ops.name == 'hip':
+            # the registered PyTorch-ROCm operator (mmmot_amd/torch_ops.py): CUDA dispatch key only, no CPU kernel
+            det_t, link_t, new_t, end_t = torch.ops.mmmot.forward_batch(
+                crops, points, torch_ops.engine_handle(eng), torch_ops.plan_handle(plan))
+            out = dict(det=det_t, link=link_t, new=new_t, end=end_t)
+        else:  # an injected backend (tests: the torch emulation of the C-ABI)
+            out = eng.forward(plan, crops, points)
         res = []
         pi = 0
         nR = plan.nR
@@ -380,6 +410,15 @@ class TrackingNet(nn.Module):
                 pi += 1
             res.append((out['det'][:, d0:d1], links, out['new'][:, d0:d1], out['end'][:, d0:d1]))
         return res
+
+    def capture(self, plan, crops, points):
+        """hipGraph of one ``forward_batch`` for a FIXED plan (the C-ABI entry points only launch: no allocation, no
+        synchronisation, so the whole step is capturable).  Returns a ``GraphedForward``; its ``__call__(crops,
+        points)`` copies the inputs into the captured buffers, replays the graph and returns the same per-sample
+        tuples as ``forward_batch`` (views of static output buffers, overwritten by the next replay).  Use it when
+        consecutive calls share the batch shape (throughput serving of fixed-size batches, the benchmark); a tracker
+        whose detections change every frame calls ``forward`` / ``forward_batch`` instead."""
+        return GraphedForward(self, plan, crops, points)
 
     def trans(self):
         pn = self.engine().P['pointnet']

@@ -120,3 +120,32 @@ def test_weight_generator_is_order_independent():
     b = gen_tensor('w_det.0.weight', (512, 512, 1), 0)
     assert np.array_equal(a, b) and not np.array_equal(a, gen_tensor('w_det.3.weight', (512, 512, 1), 0))
     assert np.array_equal(gen_tensor('x.idt', (3, 3)), np.eye(3, dtype=np.float32))
+
+
+def test_custom_operators_are_registered_for_the_device_only():
+    """mmmot_amd/torch_ops.py: the module API reaches the HIP library through torch.library operators with a CUDA
+    (= HIP) kernel and a Meta kernel - and no CPU kernel (no fallback)."""
+    import torch
+    from mmmot_amd import torch_ops
+    c, base = get_case('s2_C_multiply_none')
+    m = build_model(c, base)
+    eng = m.engine()
+    assert eng.ops.name == 'hip'
+    dets, info, ds = case_inputs(c)
+    L, P = dets.shape[0], info['points'].shape[1]
+    plan = m.make_plan([([c['N'], c['M']], info['points_split'].reshape(-1).long().numpy())], c['S'])
+    eh, ph = torch_ops.engine_handle(eng), torch_ops.plan_handle(plan)
+    for name in ('forward_batch', 'appearance', 'pointnet'):
+        assert hasattr(torch.ops.mmmot, name)
+    # Meta kernels: shapes without touching a device (FakeTensor / tracing)
+    det, link, new, end = torch.ops.mmmot.forward_batch(torch.empty(L, 3, c['S'], c['S'], device='meta'),
+                                                        torch.empty(P, 3, device='meta'), eh, ph)
+    assert det.shape == (3, L) and new.shape == (3, L) and end.shape == (3, L) and link.shape == (3 * c['N'] * c['M'],)
+    assert det.device.type == 'meta'
+    assert torch.ops.mmmot.appearance(torch.empty(L, 3, c['S'], c['S'], device='meta'), eh, ph).shape == (L, 512)
+    # CPU tensors: the dispatcher has no kernel to run
+    with pytest.raises(NotImplementedError):
+        torch.ops.mmmot.forward_batch(dets, info['points'].reshape(-1, 3), eh, ph)
+    # stale handles are refused
+    with pytest.raises(RuntimeError):
+        torch.ops.mmmot.forward_batch(torch.empty(1, device='meta'), None, 10 ** 9, ph)
