@@ -1,5 +1,5 @@
 #!/bin/bash
-# One gpurun call that refreshes every measurement kept under profiles/ (run from the repo root on the GPU box):
+# One gpurun call that refreshes the measurements kept under profiles/ (run from the repo root on the GPU box):
 #   tools/measure_round.sh <tag>      -> gpurun_out/<tag>/...
 # rocprofv3 --pmc passes are separate runs without trace domains (the pool refuses mixed runs).
 tag=${1:-final}
@@ -8,22 +8,17 @@ O=$R/gpurun_out/$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 400 python $R/bench.py > $O/bench_default.log 2>&1
-timeout 200 python $R/bench.py --trunk f16x3 --cpu-pairs 0 > $O/bench_trunk_f16x3.log 2>&1
-timeout 200 python $R/bench.py --trunk f32 --cpu-pairs 0 --pairs 4 > $O/bench_trunk_f32.log 2>&1
-timeout 200 python $R/bench.py --workload cfg2 --pairs 16 --cpu-pairs 0 > $O/bench_cfg2_pairs16.log 2>&1
-timeout 200 python $R/bench.py --workload cfg4 --pairs 8 --cpu-pairs 0 > $O/bench_cfg4_pairs8.log 2>&1
+Q="--cpu-pairs 0 --extra-trunks none --no-latency"
 rm -rf /tmp/prof_stats
-timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -- python $R/bench.py --steps 4 --warmup 1 --cpu-pairs 0 > $O/rocprof_stats_run.log 2>&1
-python $R/tools/rocpd_summary.py stats $(find /tmp/prof_stats -name "*_results.db" | head -1) > $O/rocprofv3_kernel_stats_cfg3_pairs8.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -- python $R/bench.py --steps 4 --warmup 1 $Q > $O/rocprof_stats_run.log 2>&1
+python $R/tools/rocpd_summary.py stats $(find /tmp/prof_stats -name "*_results.db" | head -1) > $O/rocprofv3_kernel_stats_cfg3_pairs8_f16x3.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   n=$(echo $c | cut -d' ' -f1)
   rm -rf /tmp/prof_pmc
-  timeout 300 rocprofv3 --pmc $c -d /tmp/prof_pmc -- python $R/bench.py --steps 2 --warmup 1 --pairs 1 --cpu-pairs 0 > $O/rocprof_pmc_$n.log 2>&1
-  python $R/tools/rocpd_summary.py pmc $(find /tmp/prof_pmc -name "*_results.db" | head -1) > $O/rocprofv3_pmc_${n}_cfg3_pairs1.txt 2>&1
+  timeout 300 rocprofv3 --pmc $c -d /tmp/prof_pmc -- python $R/bench.py --steps 2 --warmup 1 --pairs 1 $Q > $O/rocprof_pmc_$n.log 2>&1
+  python $R/tools/rocpd_summary.py pmc $(find /tmp/prof_pmc -name "*_results.db" | head -1) > $O/rocprofv3_pmc_${n}_cfg3_pairs1_f16x3.txt 2>&1
 done
+timeout 200 python $R/bench.py --workload cfg4 --pairs 8 --cpu-pairs 0 --no-latency > $O/bench_cfg4_pairs8.log 2>&1
+timeout 200 python $R/bench.py --workload cfg2 --pairs 16 --cpu-pairs 0 --no-latency > $O/bench_cfg2_pairs16.log 2>&1
 cd $R
-timeout 900 python -m pytest tests -q -m gpu 2>&1 | tail -8 > $O/pytest_gpu.log
-timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 > $O/smoke.log
-tail -c 400 $O/bench_default.log; tail -3 $O/pytest_gpu.log; cat $O/smoke.log; tail -4 $O/power_clock_during_bench.log | cut -c1-150
-timeout 200 tools/sample_power.sh > $O/power_clock_during_bench.log 2>&1
-timeout 200 python tools/patch_phase_timers.py > $O/patch_phase_timers.log 2>&1
+tail -c 1200 $O/bench_default.log; head -12 $O/rocprofv3_kernel_stats_cfg3_pairs8_f16x3.txt
