@@ -277,7 +277,9 @@ int mmmot_gn_finalize(const float* part, const int* grp_tile0, const int* grp_nt
  * modules/appear_net.py:15,30 and the mean(dim=-2/-1) of
  * modules/new_end.py:70-71.  C % 4 == 0. seg_group / sc / sh may be NULL.
  * seg_div (v2, may be NULL): divide the segment sum by seg_div[s] instead of count[s] (rows of X
- * that are already per-tile partial sums, see mmmot_gemm_args.colsum). */
+ * that are already per-tile partial sums, see mmmot_gemm_args.colsum).
+ * relu is a flag word (v4): bit 0 = ReLU after the affine, bit 1 = MAXIMUM over the segment instead of the
+ * mean (end_mode 'max' of NewEndIndicator_v2, modules/new_end.py:72-74). */
 int mmmot_segment_mean(const float* X, int ldx, int C,
                        const int* seg_start, const int* seg_count, const int* seg_stride,
                        const int* seg_group, const int* seg_div, int nseg,

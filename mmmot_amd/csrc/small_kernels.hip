@@ -140,8 +140,10 @@ extern "C" int mmmot_gn_finalize(const float* part, const int* grp_tile0, const 
 __global__ __launch_bounds__(256) void segment_mean_kernel(
     const float* __restrict__ X, int ldx, int C, const int* __restrict__ seg_start,
     const int* __restrict__ seg_count, const int* __restrict__ seg_stride, const int* __restrict__ seg_group,
-    const int* __restrict__ seg_div, const float* __restrict__ sc, const float* __restrict__ sh, int ldsc, int relu,
+    const int* __restrict__ seg_div, const float* __restrict__ sc, const float* __restrict__ sh, int ldsc, int flags,
     float* __restrict__ out, int ldo, int hl16) {
+  const int relu = flags & 1;
+  const bool take_max = (flags & 2) != 0;  // maximum over the segment instead of the mean (new_end.py:72-74)
   __shared__ __attribute__((aligned(16))) float red[4][256];
   const int s = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -155,7 +157,8 @@ __global__ __launch_bounds__(256) void segment_mean_kernel(
     s4 = *reinterpret_cast<const f32x4*>(&sc[(long)g * ldsc + c]);
     h4 = *reinterpret_cast<const f32x4*>(&sh[(long)g * ldsc + c]);
   }
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+  const float a0 = take_max ? -3.0e38f : 0.f;
+  f32x4 acc0 = {a0, a0, a0, a0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
   auto ld = [&](int t) -> f32x4 {
     f32x4 v;
     if (hl16 == 2) {
@@ -192,25 +195,40 @@ __global__ __launch_bounds__(256) void segment_mean_kernel(
     }
     return v;
   };
+  auto mx4 = [](f32x4 a, f32x4 b) -> f32x4 {
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = fmaxf(a[e], b[e]);
+    return r;
+  };
   if (cv) {
     int t = wave;
-    for (; t + 12 < count; t += 16) {
-      const f32x4 v0 = ld(t), v1 = ld(t + 4), v2 = ld(t + 8), v3 = ld(t + 12);
-      acc0 += v0; acc1 += v1; acc2 += v2; acc3 += v3;
+    if (take_max) {
+      for (; t < count; t += 4) acc0 = mx4(acc0, ld(t));
+    } else {
+      for (; t + 12 < count; t += 16) {
+        const f32x4 v0 = ld(t), v1 = ld(t + 4), v2 = ld(t + 8), v3 = ld(t + 12);
+        acc0 += v0; acc1 += v1; acc2 += v2; acc3 += v3;
+      }
+      for (; t < count; t += 4) acc0 += ld(t);
     }
-    for (; t < count; t += 4) acc0 += ld(t);
   }
-  const f32x4 acc = (acc0 + acc1) + (acc2 + acc3);
+  const f32x4 acc = take_max ? acc0 : (acc0 + acc1) + (acc2 + acc3);
   *reinterpret_cast<f32x4*>(&red[wave][lane * 4]) = acc;
   __syncthreads();
   if (wave == 0 && cv) {
     f32x4 r = *reinterpret_cast<const f32x4*>(&red[0][lane * 4]);
-    r += *reinterpret_cast<const f32x4*>(&red[1][lane * 4]);
-    r += *reinterpret_cast<const f32x4*>(&red[2][lane * 4]);
-    r += *reinterpret_cast<const f32x4*>(&red[3][lane * 4]);
-    const float inv = 1.f / (float)(seg_div ? seg_div[s] : count);
+    if (take_max) {
+      r = mx4(mx4(r, *reinterpret_cast<const f32x4*>(&red[1][lane * 4])),
+              mx4(*reinterpret_cast<const f32x4*>(&red[2][lane * 4]), *reinterpret_cast<const f32x4*>(&red[3][lane * 4])));
+    } else {
+      r += *reinterpret_cast<const f32x4*>(&red[1][lane * 4]);
+      r += *reinterpret_cast<const f32x4*>(&red[2][lane * 4]);
+      r += *reinterpret_cast<const f32x4*>(&red[3][lane * 4]);
+      const float inv = 1.f / (float)(seg_div ? seg_div[s] : count);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) r[e] *= inv;
+      for (int e = 0; e < 4; ++e) r[e] *= inv;
+    }
     *reinterpret_cast<f32x4*>(&out[(long)s * ldo + c]) = r;
   }
 }
@@ -222,7 +240,7 @@ extern "C" int mmmot_segment_mean(const float* X, int ldx, int C, const int* seg
   if (!X || !seg_start || !seg_count || !out || nseg <= 0 || C <= 0) return MMMOT_EINVAL;
   if (hl16 && (C % 8 != 0 || ldx % 8 != 0)) return MMMOT_EINVAL;
   if (hl16 == 2 && (C % 32 != 0 || ldx % 32 != 0)) return MMMOT_EINVAL;
-  if (hl16 < 0 || hl16 > 2) return MMMOT_EINVAL;
+  if (hl16 < 0 || hl16 > 2 || relu < 0 || relu > 3) return MMMOT_EINVAL;
   if (C % 4 != 0 || ldx % 4 != 0 || ldo % 4 != 0 || !mm_al16(X) || !mm_al16(out)) return MMMOT_EINVAL;
   if ((sc == nullptr) != (sh == nullptr)) return MMMOT_EINVAL;
   if (sc && (ldsc % 4 != 0 || !mm_al16(sc) || !mm_al16(sh))) return MMMOT_EINVAL;

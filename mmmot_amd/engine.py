@@ -67,8 +67,7 @@ class Engine:
             raise ValueError('unknown affinity_op %r' % (affinity_op,))
         if softmax_mode not in SOFTMAX_MODES and softmax_mode != 'none':
             softmax_mode = 'none'  # reference falls through to the raw logits (tracking_net.py:123-124)
-        if end_mode != 'avg':
-            raise NotImplementedError("end_mode='max' is not built (no shipped config uses it)")
+        self.end_mode = end_mode  # 'avg': mean over the prev / curr axis, anything else: maximum (new_end.py:69-74)
         self.P = packed
         self.ops = ops
         self.fusion = fusion
@@ -402,7 +401,8 @@ class Engine:
         sc1, sh1 = self._finalize('aff_1', part[:, :, 512:1024], PT, 512, 512, lk['g1'], lk['be1'])
         # new / end vectors: strided means of relu(gn(conv0)) over the prev / curr axis
         V = self.buf('aff_v', VT.R, 512)
-        ops.segment_mean(ya[:, 0:512], 512, plan.v_segs, V, sc=sc_ne, sh=sh_ne, relu=True)
+        ops.segment_mean(ya[:, 0:512], 512, plan.v_segs, V, sc=sc_ne, sh=sh_ne, relu=True,
+                         take_max=(self.end_mode != 'avg'))
         self._stash('aff_v', V)
         vh0 = self.buf('aff_vh0', VT.R, 512)
         part = self._part(VT, 512)

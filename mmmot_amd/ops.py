@@ -194,12 +194,13 @@ class HipOps:
                                         float(eps), _ptr(sc), _ptr(sh), self._stream())
         _lib.check(st, 'mmmot_gn_finalize')
 
-    def segment_mean(self, X, C, segs, out, sc=None, sh=None, relu=False, use_group=True, hl16=False):
-        """segs.div (optional int32 tensor): divisor per segment instead of its row count."""
+    def segment_mean(self, X, C, segs, out, sc=None, sh=None, relu=False, use_group=True, hl16=False, take_max=False):
+        """segs.div (optional int32 tensor): divisor per segment instead of its row count; take_max: maximum over the
+        segment instead of the mean."""
         st = self.lib.mmmot_segment_mean(_ptr(X), _ld(X), C, _iptr(segs.start), _iptr(segs.count),
                                          _iptr(segs.stride), _iptr(segs.group) if use_group else None,
                                          _iptr(getattr(segs, 'div', None)), segs.n,
-                                         _ptr(sc), _ptr(sh), _ld(sc), int(relu), _ptr(out), _ld(out),
+                                         _ptr(sc), _ptr(sh), _ld(sc), int(bool(relu)) | (2 if take_max else 0), _ptr(out), _ld(out),
                                          int(hl16), self._stream())
         _lib.check(st, 'mmmot_segment_mean')
 

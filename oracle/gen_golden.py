@@ -62,8 +62,9 @@ def import_reference():
     return ref_modules
 
 
-def build_reference(ref_modules, fusion, affinity_op, softmax_mode, seq_len=2):
-    kw = dict(BASE, score_fusion_arch=fusion, affinity_op=affinity_op, softmax_mode=softmax_mode, seq_len=seq_len)
+def build_reference(ref_modules, fusion, affinity_op, softmax_mode, seq_len=2, end_mode='avg'):
+    kw = dict(BASE, score_fusion_arch=fusion, affinity_op=affinity_op, softmax_mode=softmax_mode, seq_len=seq_len,
+              end_mode=end_mode)
     with contextlib.redirect_stdout(io.StringIO()):
         m = ref_modules.TrackingNet(**kw)
     sd = generate_state_dict(m.state_dict(), seed=0)
@@ -96,6 +97,11 @@ CASES.append(dict(name='s4_cfg4like_C', fusion='C', aff='minus_abs', sm='dual_ad
                   ragged=False, seed=1004))
 CASES.append(dict(name='s5_3frames_B', fusion='B', aff='multiply', sm='dual_add', counts=[3, 4, 2], S=32, pts=20,
                   ragged=True, seed=1005))
+# end_mode='max' of NewEndIndicator_v2 (modules/new_end.py:72-74; no shipped config uses it)
+CASES.append(dict(name='s6_endmax_C', fusion='C', aff='multiply', sm='none', N=9, M=6, S=32, pts=30, ragged=True,
+                  seed=1008, end_mode='max'))
+CASES.append(dict(name='s6_endmax_A', fusion='A', aff='minus_abs', sm='dual_add', N=4, M=11, S=32, pts=30, ragged=True,
+                  seed=1009, end_mode='max'))
 # full-size cases: outputs only ('full': True)
 CASES.append(dict(name='f_cfg3_C', fusion='C', aff='multiply', sm='none', N=64, M=64, S=128, pts=2048,
                   ragged=False, seed=1000, full=True))
@@ -143,9 +149,9 @@ def main():
             if c['name'] in old:
                 manifest.append(old[c['name']])
             continue
-        key = (c['fusion'], c['aff'], c['sm'], len(c.get('counts', [0, 0])))
+        key = (c['fusion'], c['aff'], c['sm'], len(c.get('counts', [0, 0])), c.get('end_mode', 'avg'))
         if key not in models:
-            models[key] = build_reference(ref_modules, c['fusion'], c['aff'], c['sm'], seq_len=key[3])
+            models[key] = build_reference(ref_modules, c['fusion'], c['aff'], c['sm'], seq_len=key[3], end_mode=key[4])
         model, sd = models[key]
         if 'counts' in c:
             dets, info, dsplit = make_multiframe(c['counts'], c['S'], c['pts'], c['seed'])
@@ -160,7 +166,7 @@ def main():
                 pnt, _ = model.point_net(info['points'].transpose(-1, -2), info['points_split'].long().squeeze(0))
         t_ref = time.time() - t0
         cfg = dict(fusion=c['fusion'], affinity_op=c['aff'], softmax_mode=c['sm'], neg_threshold=BASE['neg_threshold'],
-                   score_arch=BASE['score_arch'])
+                   score_arch=BASE['score_arch'], end_mode=c.get('end_mode', 'avg'))
         keep = {}
         t0 = time.time()
         with torch.no_grad():

@@ -153,11 +153,15 @@ def pairwise(a, b, op):
     return d.abs() if op == 'minus_abs' else d
 
 
-def new_end(x, sd, keep=None):
-    """reference modules/new_end.py:62-82 (v2, mode 'avg')."""
+def new_end(x, sd, keep=None, mode='avg'):
+    """reference modules/new_end.py:62-82 (v2): mode 'avg' means over the prev / curr axis (:69-71), anything else
+    takes the maximum (:72-74)."""
     p = 'w_link.w_new_end.'
     x = F.relu(_gn(F.conv2d(x, sd[p + 'conv0.0.weight'], sd[p + 'conv0.0.bias']), sd, p + 'conv0.1', 1))
-    new_vec, end_vec = x.mean(dim=-2), x.mean(dim=-1)
+    if mode == 'avg':
+        new_vec, end_vec = x.mean(dim=-2), x.mean(dim=-1)
+    else:
+        new_vec, end_vec = x.max(dim=-2)[0], x.max(dim=-1)[0]
 
     def head(v):
         v = F.relu(_gn(F.conv1d(v, sd[p + 'conv1.0.weight'], sd[p + 'conv1.0.bias']), sd, p + 'conv1.1', 1))
@@ -169,10 +173,10 @@ def new_end(x, sd, keep=None):
     return head(new_vec), head(end_vec)
 
 
-def affinity(a, b, sd, op, keep=None):
+def affinity(a, b, sd, op, keep=None, end_mode='avg'):
     """reference modules/gcn.py:68-82: link logits R x 1 x N x M, new R x M, end R x N."""
     x = pairwise(a, b, op)
-    new, end = new_end(x, sd, keep)
+    new, end = new_end(x, sd, keep, end_mode)
     p = 'w_link.conv1.'
     for i, g in ((0, 512), (3, 512), (6, 128)):
         x = F.relu(_gn(F.conv2d(x, sd[p + '%d.weight' % i], sd[p + '%d.bias' % i]), sd, p + '%d' % (i + 1), g))
@@ -218,7 +222,8 @@ def tracking_forward(sd, cfg, dets, points, points_split, dets_split, keep=None,
     start = 0
     for i in range(len(counts) - 1):                                             # :173-181
         mid, stop = start + counts[i], start + counts[i] + counts[i + 1]
-        logit, new, end = affinity(F3[:, :, start:mid], F3[:, :, mid:stop], sd, cfg['affinity_op'], keep)
+        logit, new, end = affinity(F3[:, :, start:mid], F3[:, :, mid:stop], sd, cfg['affinity_op'], keep,
+                                   cfg.get('end_mode', 'avg'))
         links.append(softmax_mode(logit, cfg['softmax_mode']).squeeze(1))
         news.append(new)
         ends.append(end)

@@ -45,7 +45,8 @@ def case_inputs(c):
 
 
 def case_kwargs(c, base):
-    kw = dict(base, score_fusion_arch=c['fusion'], affinity_op=c['aff'], softmax_mode=c['sm'])
+    kw = dict(base, score_fusion_arch=c['fusion'], affinity_op=c['aff'], softmax_mode=c['sm'],
+              end_mode=c.get('end_mode', base.get('end_mode', 'avg')))
     if 'counts' in c:
         kw['seq_len'] = len(c['counts'])
     return kw

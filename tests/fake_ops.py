@@ -238,7 +238,7 @@ class TorchOps:
             sc[g, :C] = scv.float()
             sh[g, :C] = (beta.double() - s1.repeat_interleave(CG) * scv).float()
 
-    def segment_mean(self, X, C, segs, out, sc=None, sh=None, relu=False, use_group=True, hl16=False):
+    def segment_mean(self, X, C, segs, out, sc=None, sh=None, relu=False, use_group=True, hl16=False, take_max=False):
         if int(hl16) == 2:
             from mmmot_amd.pack import from_hq8_act
             X = from_hq8_act(X[:, :C].contiguous())
@@ -254,7 +254,10 @@ class TorchOps:
             if relu:
                 rows = torch.relu(rows)
             div = getattr(segs, 'h_div', None)
-            out[s, :C] = rows.mean(0) if div is None else rows.sum(0) / float(div[s])
+            if take_max:
+                out[s, :C] = rows.max(0)[0]
+            else:
+                out[s, :C] = rows.mean(0) if div is None else rows.sum(0) / float(div[s])
 
     def rowdot(self, X, K, w, b, tiles, out, sc=None, sh=None, act=ACT_NONE, use_thr=False, thr=0.0, omap=None):
         R = tiles.R

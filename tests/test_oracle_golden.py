@@ -27,7 +27,7 @@ def test_oracle_matches_reference_golden(name):
     sd = state_dict_for(c, base)
     dets, info, ds = case_inputs(c)
     cfg = dict(fusion=c['fusion'], affinity_op=c['aff'], softmax_mode=c['sm'], neg_threshold=base['neg_threshold'],
-               score_arch=base['score_arch'])
+               score_arch=base['score_arch'], end_mode=c.get('end_mode', 'avg'))
     with torch.no_grad():
         out = R.tracking_forward(sd, cfg, dets, info['points'], info['points_split'], [int(d) for d in ds])
     errs = compare_outputs(out, golden(name), tol=5e-5)
