@@ -71,7 +71,8 @@ extern "C" {
  * mmmot_hq8_pack/unpack, mmmot_segment_mean hl16 = 2), patch-kernel test / timing knobs;
  * 4 = per-output-channel weight scales (oscale is a [Cout] vector in the hl16 / hq8 trunk entry points),
  * mmmot_trunk_range_read, the tile / LDS-DMA trunk kernels and their knobs removed, timing experiments only in
- * -DMMMOT_DEBUG builds. */
+ * -DMMMOT_DEBUG builds; 5 = training backward of the pairwise block (mmmot_gn_bwd_*, mmmot_gemm_tn,
+ * mmmot_pair_bwd, mmmot_pair_expand_bwd, mmmot_rowdot_bwd, mmmot_softmax_pairs_bwd). */
 int mmmot_abi_version(void);
 /* returns 0 and fills cu_count / gcn arch string (<=32 bytes) of device 0..; */
 int mmmot_device_info(int device, int* cu_count, char* arch, int arch_len);
@@ -381,6 +382,67 @@ int mmmot_points_scatter_batched(const float* pts, int F, int NS, int NPOLY, int
  * S <= 256. */
 int mmmot_crop_resize_norm(const unsigned char* img, int H, int W, const int* boxes, int N, int S, int kmax,
                            const float* mean_std, int* work, float* out, unsigned char* out_u8, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Training backward of the pairwise block (first slice; ABI 5): gradients of
+ * affinity_module.forward + NewEndIndicator_v2.forward + the softmax modes of TrackingNet.associate
+ * (reference modules/gcn.py:68-82, new_end.py:62-82, tracking_net.py:106-126; the step that needs them is
+ * tracking_model.py:50-66: forward -> loss -> backward).  Per layer  y = A W^T + b, yhat = (y - mean) rstd,
+ * z = yhat gamma + beta, a = relu(z):
+ *   dz = dA [z > 0];  dgamma = sum_r dz yhat;  dbeta = sum_r dz;  dy = rstd (gamma dz - m1 - yhat m2);
+ *   dA_in = dy W (mmmot_gemm_rows with W^T);  dW = dy^T A_in, db = sum_r dy (mmmot_gemm_tn).
+ * yhat is recomputed from the stored pre-norm y with sc1 = rstd, sh1 = -mean rstd, i.e. the output of
+ * mmmot_gn_finalize called with gamma = 1, beta = 0.  All fp32 (exact fp32 MFMA in mmmot_gemm_tn).
+ * ------------------------------------------------------------------------- */
+/* pass 1: P[t][0][c] = sum over the rows of tile t of dz, P[t][1][c] = sum of dz*yhat  (P is [T][2][C]) */
+int mmmot_gn_bwd_partial(const float* dA, int ldda, const float* Y, int ldy, int C, const float* sc1,
+                         const float* sh1, int ldsc, const float* gamma, const float* beta, int relu,
+                         const int* tile_row0, const int* tile_nrows, const int* tile_group, int T, float* P,
+                         void* stream);
+/* pass 2: S [G][2][C] = sums of P over the tiles of each group (mmmot_segment_mean with divisor 1) ->
+ * M [G][2][C]: m1 = sum_{c in norm group} gamma_c S[g][0][c] / cnt, m2 likewise from S[g][1], broadcast to the
+ * channels of the norm group; cnt = grp_count[g] * C / NG. */
+int mmmot_gn_bwd_finalize(const float* S, const int* grp_count, int G, int C, int NG, const float* gamma, float* M,
+                          void* stream);
+/* pass 3: dY[r][c] = sc1[g][c] * (gamma_c dz - M[g][0][c] - yhat M[g][1][c]) */
+int mmmot_gn_bwd_apply(const float* dA, int ldda, const float* Y, int ldy, int C, const float* sc1, const float* sh1,
+                       int ldsc, const float* gamma, const float* beta, int relu, const float* M,
+                       const int* tile_row0, const int* tile_nrows, const int* tile_group, int T, float* dY, int lddy,
+                       void* stream);
+/* dW[n][k] = sum_r dY[r][n] * A(r,k), db[n] = sum_r dY[r][n]; A(r,k) is regenerated like the forward's A operand
+ * (MMMOT_A_PLAIN / MMMOT_A_NORM_RELU / MMMOT_A_PAIR).  N % 64 == 0, K % 64 == 0.  Deterministic. */
+typedef struct mmmot_gemm_tn_args {
+  const float* dY; int lddy;            /* [rows][N] gradient of the layer's pre-norm output */
+  const float* X; int ldx;              /* PLAIN / NORM_RELU source rows                      */
+  const float* sc; const float* sh; int ldsc;
+  const float* FA; const float* FB; int ldf;   /* PAIR operands                               */
+  const int* tile_row0; const int* tile_nrows; const int* tile_group;
+  const int* grp_row0; const int* grp_M; const int* grp_aoff; const int* grp_boff;
+  int T; int N; int K; int amode; int pairop;
+  float* dW;                            /* [N][K]                                             */
+  float* db;                            /* [N] or NULL                                        */
+} mmmot_gemm_tn_args;
+int mmmot_gemm_tn(const mmmot_gemm_tn_args* a, void* stream);
+/* backward of the pairwise operand generation (gcn.py:6-41): side 0 accumulates d op / d a over j into
+ * dF[aoff[g] + i], side 1 d op / d b over i into dF[boff[g] + j]; one workgroup per entry of (blk_group, blk_idx)
+ * = every (group, i) resp. (group, j); dF is accumulated into (+=), rows of one launch are distinct. */
+int mmmot_pair_bwd(const float* dX, int lddx, const float* F, int ldf, float* dF, int lddf, int C,
+                   const int* grp_row0, const int* grp_N, const int* grp_M, const int* grp_aoff,
+                   const int* grp_boff, const int* blk_group, const int* blk_idx, int nblk, int pairop, int side,
+                   void* stream);
+/* backward of the strided means that make the new / end vectors (new_end.py:70-71):
+ * dA[(g,i,j)][c] = dV[vrow0[g] + j][c] / N + dV[vrow0[g] + M + i][c] / M */
+int mmmot_pair_expand_bwd(const float* dV, int lddv, float* dA, int ldda, int C, const int* tile_row0,
+                          const int* tile_nrows, const int* tile_group, int T, const int* grp_row0,
+                          const int* grp_N, const int* grp_M, const int* grp_vrow0, void* stream);
+/* backward of mmmot_rowdot (a = relu(X*sc + sh), act NONE or SIGMOID): gpre[r] = gout[gidx ? gidx[r] : r] * act';
+ * dA[r][k] = gpre[r] w[k]; PW[t][k] = sum_{r in tile t} gpre[r] a(r,k) (k < K), PW[t][K] = sum_r gpre[r]. */
+int mmmot_rowdot_bwd(const float* X, int ldx, int K, const float* w, float b, const float* sc, const float* sh,
+                     int ldsc, const int* tile_row0, const int* tile_nrows, const int* tile_group, int T, int act,
+                     const float* gout, const int* gidx, float* dA, int ldda, float* PW, int ldpw, void* stream);
+/* backward of mmmot_softmax_pairs: dlogits from dout, the row / column softmaxes are recomputed from the logits */
+int mmmot_softmax_pairs_bwd(const float* logits, const float* dout, float* dlogits, const int* grp_row0,
+                            const int* grp_N, const int* grp_M, int G, int max_nm, int mode, void* stream);
 
 /* MFMA fragment-layout self test: C[32][32] = A[32][K] * B[32][K]^T through
  * the same fragment mapping the GEMM kernels use (K % 8 == 0). */

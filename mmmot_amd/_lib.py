@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.environ.get('MMMOT_LIB_PATH', os.path.join(_HERE, 'libmmmot_hip.so'))  # override: tools' timing-experiment builds
 SOURCES = ['conv3x3.hip', 'hl16_format.hip', 'conv3x3_hl16_patch.hip', 'gemm_rows.hip',
-           'gemm_ares.hip', 'gram.hip', 'points_gather.hip', 'crop_resize.hip', 'small_kernels.hip']
+           'gemm_ares.hip', 'gram.hip', 'points_gather.hip', 'crop_resize.hip', 'small_kernels.hip', 'backward.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 HIPFLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
 
@@ -63,6 +63,20 @@ class GemmAresArgs(ctypes.Structure):
     ]
 
 
+class GemmTnArgs(ctypes.Structure):
+    """Mirror of ``mmmot_gemm_tn_args`` (include/mmmot_hip.h)."""
+    _fields_ = [
+        ('dY', c_f), ('lddy', c_i),
+        ('X', c_f), ('ldx', c_i),
+        ('sc', c_f), ('sh', c_f), ('ldsc', c_i),
+        ('FA', c_f), ('FB', c_f), ('ldf', c_i),
+        ('tile_row0', c_f), ('tile_nrows', c_f), ('tile_group', c_f),
+        ('grp_row0', c_f), ('grp_M', c_f), ('grp_aoff', c_f), ('grp_boff', c_f),
+        ('T', c_i), ('N', c_i), ('K', c_i), ('amode', c_i), ('pairop', c_i),
+        ('dW', c_f), ('db', c_f),
+    ]
+
+
 # name -> argtypes; every entry point declared in include/mmmot_hip.h
 SIGNATURES = {
     'mmmot_abi_version': [],
@@ -99,6 +113,15 @@ SIGNATURES = {
     'mmmot_points_count_batched': [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_f, c_f],
     'mmmot_points_scatter_batched': [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f],
     'mmmot_selftest_mfma': [c_f, c_f, c_f, c_i, c_f],
+    'mmmot_gn_bwd_partial': [c_f, c_i, c_f, c_i, c_i, c_f, c_f, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_f, c_f],
+    'mmmot_gn_bwd_finalize': [c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f],
+    'mmmot_gn_bwd_apply': [c_f, c_i, c_f, c_i, c_i, c_f, c_f, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_i, c_f, c_i, c_f],
+    'mmmot_gemm_tn': [ctypes.POINTER(GemmTnArgs), c_f],
+    'mmmot_pair_bwd': [c_f, c_i, c_f, c_i, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f],
+    'mmmot_pair_expand_bwd': [c_f, c_i, c_f, c_i, c_i, c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_f],
+    'mmmot_rowdot_bwd': [c_f, c_i, c_i, c_f, ctypes.c_float, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_i,
+                         c_f, c_i, c_f],
+    'mmmot_softmax_pairs_bwd': [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f],
 }
 
 

@@ -1,0 +1,284 @@
+"""Training backward of the pairwise block (first slice).
+
+Gradients of ``affinity_module.forward`` + ``NewEndIndicator_v2.forward`` + the softmax modes of
+``TrackingNet.associate`` (reference modules/gcn.py:68-82, new_end.py:62-82, tracking_net.py:106-126) with respect
+to the fused features F (3 x L x 512 in the reference, [nR*Lt][512] here) and to every ``w_link.*`` parameter - the
+part of the training step ``tracking_model.py:50-66`` (forward -> loss -> backward) that runs over the N x M pair
+space.  In training mode this block is identical to eval mode (GroupNorm only: no BatchNorm, no dropout), so the
+forward is the inference schedule of ``Engine.affinity`` with the pre-norm tensors kept on a tape.
+
+    link, new, end = affinity_autograd(model, plan, F)        # F requires grad / w_link parameters require grad
+    loss(link, new, end).backward()                           # fills F.grad and model.w_link.*.grad
+
+Everything numeric happens in libmmmot_hip.so (csrc/backward.hip + the forward kernels); torch does memory,
+views, transposes of weights (data movement) and the autograd bookkeeping.  Not built yet (next slices): the
+backward of w_det, fusion, PointNet and the VGG trunk (training-mode BatchNorm), the losses of cost.py:134-185.
+"""
+import numpy as np
+import torch
+
+from .engine import EPS
+from .ops import ACT_NONE, ACT_SIGMOID, A_NORM_RELU, A_PAIR, A_PLAIN, PAIR_OPS, SOFTMAX_MODES
+from .plan import Segments
+
+# packed name -> reference state_dict key (w_link.*); 'wa' / 'ba' are the stacked [new_end.conv0 ; conv1.0] layer
+PARAM_KEYS = {
+    'g_ne0': 'w_link.w_new_end.conv0.1.weight', 'be_ne0': 'w_link.w_new_end.conv0.1.bias',
+    'g1': 'w_link.conv1.1.weight', 'be1': 'w_link.conv1.1.bias',
+    'w3': 'w_link.conv1.3.weight', 'b3': 'w_link.conv1.3.bias',
+    'g4': 'w_link.conv1.4.weight', 'be4': 'w_link.conv1.4.bias',
+    'w6': 'w_link.conv1.6.weight', 'b6': 'w_link.conv1.6.bias',
+    'g7': 'w_link.conv1.7.weight', 'be7': 'w_link.conv1.7.bias',
+    'w9': 'w_link.conv1.9.weight', 'b9': 'w_link.conv1.9.bias',
+    'nw0': 'w_link.w_new_end.conv1.0.weight', 'nb0': 'w_link.w_new_end.conv1.0.bias',
+    'ng1': 'w_link.w_new_end.conv1.1.weight', 'nbe1': 'w_link.w_new_end.conv1.1.bias',
+    'nw3': 'w_link.w_new_end.conv1.3.weight', 'nb3': 'w_link.w_new_end.conv1.3.bias',
+    'ng4': 'w_link.w_new_end.conv1.4.weight', 'nbe4': 'w_link.w_new_end.conv1.4.bias',
+    'nw6': 'w_link.w_new_end.conv1.6.weight', 'nb6': 'w_link.w_new_end.conv1.6.bias',
+}
+
+
+class _PlanAux:
+    """Integer tables of the backward that the forward plan does not carry (built once per plan)."""
+
+    def __init__(self, plan):
+        dev = plan.device
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+        gN, gM = plan.h_pg_N, plan.h_pg_M
+        # V rows of group g: M "new" rows then N "end" rows (plan.v_tiles has two groups per pair group)
+        self.vrow0 = up(np.concatenate([[0], np.cumsum(gN + gM)])[:-1])
+        a_g, a_i, b_g, b_j = [], [], [], []
+        for g, (n, m) in enumerate(zip(gN, gM)):
+            a_g += [g] * int(n); a_i += list(range(int(n)))
+            b_g += [g] * int(m); b_j += list(range(int(m)))
+        self.a_grp, self.a_idx, self.b_grp, self.b_idx = up(a_g), up(a_i), up(b_g), up(b_j)
+        self._tsum = {}
+
+    def tile_sums(self, tiles, device):
+        """(per-group, total) Segments that sum the [T][2][C] partials of a tiling, viewed as [2T][C] rows."""
+        key = id(tiles)
+        if key not in self._tsum:
+            G = tiles.G
+            start = np.stack([2 * tiles.h_g_tile0, 2 * tiles.h_g_tile0 + 1], 1).reshape(-1)
+            count = np.repeat(tiles.h_g_ntiles, 2)
+            grp = Segments(start, count, np.full(2 * G, 2), np.zeros(2 * G), device, div=np.ones(2 * G))
+            tot = Segments([0, 1], [tiles.T, tiles.T], [2, 2], [0, 0], device, div=[1, 1])
+            self._tsum[key] = (grp, tot)
+        return self._tsum[key]
+
+
+def _aux(plan):
+    if not hasattr(plan, '_bwd_aux'):
+        plan._bwd_aux = _PlanAux(plan)
+    return plan._bwd_aux
+
+
+def _unit(eng, C, dev):
+    key = ('unit', C, str(dev))
+    if key not in eng.ws:
+        eng.ws[key] = (torch.ones(C, dtype=torch.float32, device=dev), torch.zeros(C, dtype=torch.float32, device=dev))
+    return eng.ws[key]
+
+
+class _Layer:
+    """One 'GEMM -> GroupNorm -> ReLU' layer on the tape: pre-norm output Y, its statistics, its parameters."""
+
+    def __init__(self, Y, C, NG, gamma, beta, sc, sh, sc1, sh1, tiles):
+        self.Y, self.C, self.NG, self.gamma, self.beta = Y, C, NG, gamma, beta
+        self.sc, self.sh, self.sc1, self.sh1, self.tiles = sc, sh, sc1, sh1, tiles
+
+
+def _norm_layer(eng, part, tiles, Y, C, NG, gamma, beta):
+    """finalize twice: (gamma, beta) -> sc/sh for the consumer's prologue, (1, 0) -> sc1 = rstd, sh1 = -mean*rstd"""
+    dev = Y.device
+    new = lambda: torch.empty(tiles.G, C, dtype=torch.float32, device=dev)
+    sc, sh, sc1, sh1 = new(), new(), new(), new()
+    one, zero = _unit(eng, C, dev)
+    eng.ops.gn_finalize(part, tiles, C, NG, gamma, beta, EPS, sc, sh)
+    eng.ops.gn_finalize(part, tiles, C, NG, one, zero, EPS, sc1, sh1)
+    return _Layer(Y, C, NG, gamma, beta, sc, sh, sc1, sh1, tiles)
+
+
+def affinity_forward_train(eng, plan, F):
+    """Engine.affinity with the tape the backward needs.  F: [nR, Lt, 512] (contiguous).  Returns
+    (link flat [R], new [nR, Lt], end [nR, Lt], tape)."""
+    ops, lk, PT, VT = eng.ops, eng.P['w_link'], plan.pair_tiles, plan.v_tiles
+    if eng.end_mode != 'avg':
+        raise NotImplementedError("the backward of end_mode='max' is not built")
+    nR, Lt, R = plan.nR, plan.Lt, plan.pair_tiles.R
+    dev = F.device
+    Ff = F.reshape(nR * Lt, 512)
+    new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    pair = dict(row0=PT.g_row0, M=plan.pg_M, aoff=plan.pg_aoff, boff=plan.pg_boff)
+    pairop = PAIR_OPS[eng.affinity_op]
+    t = dict(pair=pair, pairop=pairop)
+    # stacked [new_end.conv0 ; conv1.0] over the on-the-fly pairwise tensor
+    ya, part = new(R, 1024), new(PT.T, 2, 1024)
+    eng._gemm(lk, 'wa', PT, 1024, 512, FA=Ff, FB=Ff, pair=pair, amode=A_PAIR, pairop=pairop, bias=lk['ba'], Y=ya,
+              part=part)
+    t['ne0'] = _norm_layer(eng, part[:, :, 0:512], PT, ya[:, 0:512], 512, 1, lk['g_ne0'], lk['be_ne0'])
+    t['l1'] = _norm_layer(eng, part[:, :, 512:1024], PT, ya[:, 512:1024], 512, 512, lk['g1'], lk['be1'])
+    # new / end vectors and their head
+    V = new(VT.R, 512)
+    ops.segment_mean(ya[:, 0:512], 512, plan.v_segs, V, sc=t['ne0'].sc, sh=t['ne0'].sh, relu=True)
+    vh0, part = new(VT.R, 512), new(VT.T, 2, 512)
+    eng._gemm(lk, 'nw0', VT, 512, 512, X=V, bias=lk['nb0'], Y=vh0, part=part)
+    t['v1'] = _norm_layer(eng, part, VT, vh0, 512, 1, lk['ng1'], lk['nbe1'])
+    vh1, part = new(VT.R, 128), new(VT.T, 2, 128)
+    eng._gemm(lk, 'nw3', VT, 128, 512, X=vh0, bias=lk['nb3'], Y=vh1, part=part, sc=t['v1'].sc, sh=t['v1'].sh,
+              amode=A_NORM_RELU)
+    t['v4'] = _norm_layer(eng, part, VT, vh1, 128, 1, lk['ng4'], lk['nbe4'])
+    ne = torch.zeros(2, nR, Lt, dtype=torch.float32, device=dev)
+    ops.rowdot(vh1, 128, lk['nw6'], lk['nb6'], VT, ne.view(-1), sc=t['v4'].sc, sh=t['v4'].sh, act=ACT_SIGMOID,
+               omap=plan.v_omap)
+    # link branch
+    y3, part = new(R, 512), new(PT.T, 2, 512)
+    eng._gemm(lk, 'w3', PT, 512, 512, X=ya[:, 512:1024], bias=lk['b3'], Y=y3, part=part, sc=t['l1'].sc, sh=t['l1'].sh,
+              amode=A_NORM_RELU)
+    t['l4'] = _norm_layer(eng, part, PT, y3, 512, 512, lk['g4'], lk['be4'])
+    y6, part = new(R, 128), new(PT.T, 2, 128)
+    eng._gemm(lk, 'w6', PT, 128, 512, X=y3, bias=lk['b6'], Y=y6, part=part, sc=t['l4'].sc, sh=t['l4'].sh,
+              amode=A_NORM_RELU)
+    t['l7'] = _norm_layer(eng, part, PT, y6, 128, 128, lk['g7'], lk['be7'])
+    logits = new(R)
+    ops.rowdot(y6, 128, lk['w9'], lk['b9'], PT, logits, sc=t['l7'].sc, sh=t['l7'].sh)
+    link = logits
+    if eng.softmax_mode != 'none':
+        link = torch.empty_like(logits)
+        ops.softmax_pairs(logits, link, PT.g_row0, plan.pg_N, plan.pg_M, PT.G, plan.max_nm,
+                          SOFTMAX_MODES[eng.softmax_mode])
+    t.update(ya=ya, V=V, logits=logits)
+    return link, ne[0], ne[1], t
+
+
+def _colsum(eng, X):
+    """column sums of a [rows][C] tensor (C % 4 == 0) through the strided-mean kernel with divisor 1"""
+    seg = Segments([0], [X.shape[0]], [1], [0], X.device, div=[1])
+    out = torch.empty(1, X.shape[1], dtype=torch.float32, device=X.device)
+    eng.ops.segment_mean(X, X.shape[1], seg, out, use_group=False)
+    return out[0]
+
+
+def _gn_backward(eng, plan, L, dA, out=None):
+    """dA = gradient w.r.t. relu(GroupNorm(Y)) -> (dY, dgamma [C], dbeta [C]).  ``out``: view to write dY into."""
+    ops, tiles, C, dev = eng.ops, L.tiles, L.C, dA.device
+    P = torch.empty(tiles.T, 2, C, dtype=torch.float32, device=dev)
+    ops.gn_bwd_partial(dA, L.Y, C, L.sc1, L.sh1, L.gamma, L.beta, True, tiles, P)
+    seg_g, seg_t = _aux(plan).tile_sums(tiles, dev)
+    S = torch.empty(tiles.G * 2, C, dtype=torch.float32, device=dev)
+    tot = torch.empty(2, C, dtype=torch.float32, device=dev)
+    P2 = P.view(2 * tiles.T, C)
+    ops.segment_mean(P2, C, seg_g, S, use_group=False)
+    ops.segment_mean(P2, C, seg_t, tot, use_group=False)
+    M = torch.empty(tiles.G, 2, C, dtype=torch.float32, device=dev)
+    ops.gn_bwd_finalize(S, tiles, C, L.NG, L.gamma, M)
+    dY = out if out is not None else torch.empty(tiles.R, C, dtype=torch.float32, device=dev)
+    ops.gn_bwd_apply(dA, L.Y, C, L.sc1, L.sh1, L.gamma, L.beta, True, M, tiles, dY)
+    return dY, tot[1], tot[0]
+
+
+def affinity_backward(eng, plan, F, t, d_link, d_new, d_end):
+    """Returns (dF [nR, Lt, 512], {reference state_dict key: gradient tensor in the parameter's shape})."""
+    ops, lk, PT, VT = eng.ops, eng.P['w_link'], plan.pair_tiles, plan.v_tiles
+    nR, Lt, R = plan.nR, plan.Lt, plan.pair_tiles.R
+    dev = F.device
+    aux = _aux(plan)
+    Ff = F.reshape(nR * Lt, 512)
+    new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    tr = lambda name: lk[name].t().contiguous()  # transposed weight for dA_in = dY W (data movement)
+    g = {}
+
+    def weight_grad(name, bname, dY, tiles, N, K, **kw):
+        dW, db = new(N, K), new(N)
+        ops.gemm_tn(dY, tiles, N, K, dW, db, **kw)
+        g[name], g[bname] = dW, db
+
+    # ---- link branch, from the scores back to dYa[:, 512:] ----
+    d_link = d_link.reshape(-1).contiguous()
+    if eng.softmax_mode != 'none':
+        dlogits = new(R)
+        ops.softmax_pairs_bwd(t['logits'], d_link, dlogits, PT.g_row0, plan.pg_N, plan.pg_M, PT.G, plan.max_nm,
+                              SOFTMAX_MODES[eng.softmax_mode])
+    else:
+        dlogits = d_link
+    L7, L4, L1, NE0, V1, V4 = t['l7'], t['l4'], t['l1'], t['ne0'], t['v1'], t['v4']
+    dA6, PW = new(R, 128), new(PT.T, 132)
+    ops.rowdot_bwd(L7.Y, 128, lk['w9'], lk['b9'], L7.sc, L7.sh, PT, ACT_NONE, dlogits, None, dA6, PW)
+    pw = _colsum(eng, PW)
+    g['w9'], g['b9'] = pw[:128], pw[128:129]
+    dY6, g['g7'], g['be7'] = _gn_backward(eng, plan, L7, dA6)
+    weight_grad('w6', 'b6', dY6, PT, 128, 512, X=L4.Y, sc=L4.sc, sh=L4.sh, amode=A_NORM_RELU)
+    dA3 = new(R, 512)
+    ops.gemm(tr('w6'), PT, 512, 128, X=dY6, Y=dA3)
+    dY3, g['g4'], g['be4'] = _gn_backward(eng, plan, L4, dA3)
+    weight_grad('w3', 'b3', dY3, PT, 512, 512, X=L1.Y, sc=L1.sc, sh=L1.sh, amode=A_NORM_RELU)
+    dA1 = new(R, 512)
+    ops.gemm(tr('w3'), PT, 512, 512, X=dY3, Y=dA1)
+    dYa = new(R, 1024)
+    _, g['g1'], g['be1'] = _gn_backward(eng, plan, L1, dA1, out=dYa[:, 512:1024])
+    # ---- new / end branch, from the scores back to dYa[:, :512] ----
+    d_ne = torch.stack([d_new, d_end]).reshape(-1).contiguous()
+    dAv1, PW = new(VT.R, 128), new(VT.T, 132)
+    ops.rowdot_bwd(V4.Y, 128, lk['nw6'], lk['nb6'], V4.sc, V4.sh, VT, ACT_SIGMOID, d_ne, plan.v_omap, dAv1, PW)
+    pw = _colsum(eng, PW)
+    g['nw6'], g['nb6'] = pw[:128], pw[128:129]
+    dYv1, g['ng4'], g['nbe4'] = _gn_backward(eng, plan, V4, dAv1)
+    weight_grad('nw3', 'nb3', dYv1, VT, 128, 512, X=V1.Y, sc=V1.sc, sh=V1.sh, amode=A_NORM_RELU)
+    dAv0 = new(VT.R, 512)
+    ops.gemm(tr('nw3'), VT, 512, 128, X=dYv1, Y=dAv0)
+    dYv0, g['ng1'], g['nbe1'] = _gn_backward(eng, plan, V1, dAv0)
+    weight_grad('nw0', 'nb0', dYv0, VT, 512, 512, X=t['V'], amode=A_PLAIN)
+    dV = new(VT.R, 512)
+    ops.gemm(tr('nw0'), VT, 512, 512, X=dYv0, Y=dV)
+    dAne = new(R, 512)
+    ops.pair_expand_bwd(dV, dAne, 512, PT, PT.g_row0, plan.pg_N, plan.pg_M, aux.vrow0)
+    _, g['g_ne0'], g['be_ne0'] = _gn_backward(eng, plan, NE0, dAne, out=dYa[:, 0:512])
+    # ---- the stacked first layer over the pairwise tensor, and the pairwise operand generation ----
+    dWa, dba = new(1024, 512), new(1024)
+    ops.gemm_tn(dYa, PT, 1024, 512, dWa, dba, FA=Ff, FB=Ff, pair=t['pair'], amode=A_PAIR, pairop=t['pairop'])
+    dX = new(R, 512)
+    ops.gemm(tr('wa'), PT, 512, 1024, X=dYa, Y=dX)
+    dF = torch.zeros(nR * Lt, 512, dtype=torch.float32, device=dev)
+    common = (PT.g_row0, plan.pg_N, plan.pg_M, plan.pg_aoff, plan.pg_boff)
+    ops.pair_bwd(dX, Ff, dF, 512, *common, aux.a_grp, aux.a_idx, t['pairop'], 0)
+    ops.pair_bwd(dX, Ff, dF, 512, *common, aux.b_grp, aux.b_idx, t['pairop'], 1)
+    # ---- reference-keyed parameter gradients (flat / 2-D; the caller reshapes to the parameter's shape) ----
+    out = {'w_link.w_new_end.conv0.0.weight': dWa[0:512], 'w_link.w_new_end.conv0.0.bias': dba[0:512],
+           'w_link.conv1.0.weight': dWa[512:1024], 'w_link.conv1.0.bias': dba[512:1024]}
+    for name, key in PARAM_KEYS.items():
+        out[key] = g[name]
+    return dF.view(nR, Lt, 512), out
+
+
+class _AffinityFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, F, eng, plan, keys, *params):
+        link, new, end, tape = affinity_forward_train(eng, plan, F.detach().contiguous())
+        ctx.eng, ctx.plan, ctx.tape, ctx.keys = eng, plan, tape, keys
+        ctx.save_for_backward(F)
+        ctx.shapes = [tuple(p.shape) for p in params]
+        return link, new, end
+
+    @staticmethod
+    def backward(ctx, d_link, d_new, d_end):
+        (F,) = ctx.saved_tensors
+        zeros = lambda ref, shape: torch.zeros(shape, dtype=torch.float32, device=F.device)
+        nR, Lt = ctx.plan.nR, ctx.plan.Lt
+        d_link = d_link if d_link is not None else zeros(F, (ctx.plan.pair_tiles.R,))
+        d_new = d_new if d_new is not None else zeros(F, (nR, Lt))
+        d_end = d_end if d_end is not None else zeros(F, (nR, Lt))
+        dF, grads = affinity_backward(ctx.eng, ctx.plan, F.detach().contiguous(), ctx.tape, d_link.contiguous(),
+                                      d_new.contiguous(), d_end.contiguous())
+        pg = tuple(grads[k].reshape(s) for k, s in zip(ctx.keys, ctx.shapes))
+        return (dF, None, None, None) + pg
+
+
+def affinity_autograd(model, plan, F):
+    """Differentiable pairwise block of ``model`` (a TrackingNet on the device): F [nR, Lt, 512] ->
+    (link flat [sum nR*N*M], new [nR, Lt], end [nR, Lt]) attached to the autograd graph; ``backward()`` fills
+    ``F.grad`` and the ``.grad`` of every ``model.w_link`` parameter.  The packed weights are those of
+    ``model.engine()``: call ``model.invalidate()`` after an optimizer step."""
+    eng = model.engine()
+    named = [(k, p) for k, p in model.named_parameters() if k.startswith('w_link.')]
+    keys = tuple(k for k, _ in named)
+    return _AffinityFn.apply(F, eng, plan, keys, *[p for _, p in named])

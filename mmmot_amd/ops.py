@@ -238,6 +238,63 @@ class HipOps:
                                           max_nm, mode, self._stream())
         _lib.check(st, 'mmmot_softmax_pairs')
 
+    # ---- training backward of the pairwise block (include/mmmot_hip.h, csrc/backward.hip) -------------------
+    def gn_bwd_partial(self, dA, Y, C, sc1, sh1, gamma, beta, relu, tiles, P):
+        st = self.lib.mmmot_gn_bwd_partial(_ptr(dA), _ld(dA), _ptr(Y), _ld(Y), C, _ptr(sc1), _ptr(sh1), _ld(sc1),
+                                           _ptr(gamma), _ptr(beta), int(relu), _iptr(tiles.row0), _iptr(tiles.nrows),
+                                           _iptr(tiles.group), tiles.T, _ptr(P), self._stream())
+        _lib.check(st, 'mmmot_gn_bwd_partial')
+
+    def gn_bwd_finalize(self, S, tiles, C, NG, gamma, M):
+        st = self.lib.mmmot_gn_bwd_finalize(_ptr(S), _iptr(tiles.g_count), tiles.G, C, NG, _ptr(gamma), _ptr(M),
+                                            self._stream())
+        _lib.check(st, 'mmmot_gn_bwd_finalize')
+
+    def gn_bwd_apply(self, dA, Y, C, sc1, sh1, gamma, beta, relu, M, tiles, dY):
+        st = self.lib.mmmot_gn_bwd_apply(_ptr(dA), _ld(dA), _ptr(Y), _ld(Y), C, _ptr(sc1), _ptr(sh1), _ld(sc1),
+                                         _ptr(gamma), _ptr(beta), int(relu), _ptr(M), _iptr(tiles.row0),
+                                         _iptr(tiles.nrows), _iptr(tiles.group), tiles.T, _ptr(dY), _ld(dY),
+                                         self._stream())
+        _lib.check(st, 'mmmot_gn_bwd_apply')
+
+    def gemm_tn(self, dY, tiles, N, K, dW, db=None, X=None, sc=None, sh=None, FA=None, FB=None, pair=None,
+                amode=A_PLAIN, pairop=0):
+        a = _lib.GemmTnArgs()
+        a.dY, a.lddy = _ptr(dY), _ld(dY)
+        a.X, a.ldx = _ptr(X), _ld(X)
+        a.sc, a.sh, a.ldsc = _ptr(sc), _ptr(sh), _ld(sc)
+        a.FA, a.FB, a.ldf = _ptr(FA), _ptr(FB), _ld(FA)
+        a.tile_row0, a.tile_nrows, a.tile_group = _iptr(tiles.row0), _iptr(tiles.nrows), _iptr(tiles.group)
+        if pair is not None:
+            a.grp_row0, a.grp_M = _iptr(pair['row0']), _iptr(pair['M'])
+            a.grp_aoff, a.grp_boff = _iptr(pair['aoff']), _iptr(pair['boff'])
+        a.T, a.N, a.K, a.amode, a.pairop = tiles.T, N, K, amode, pairop
+        a.dW, a.db = _ptr(dW), _ptr(db)
+        _lib.check(self.lib.mmmot_gemm_tn(ctypes.byref(a), self._stream()), 'mmmot_gemm_tn')
+
+    def pair_bwd(self, dX, F, dF, C, row0, gN, gM, aoff, boff, blk_group, blk_idx, pairop, side):
+        st = self.lib.mmmot_pair_bwd(_ptr(dX), _ld(dX), _ptr(F), _ld(F), _ptr(dF), _ld(dF), C, _iptr(row0), _iptr(gN),
+                                     _iptr(gM), _iptr(aoff), _iptr(boff), _iptr(blk_group), _iptr(blk_idx),
+                                     blk_group.numel(), pairop, side, self._stream())
+        _lib.check(st, 'mmmot_pair_bwd')
+
+    def pair_expand_bwd(self, dV, dA, C, tiles, row0, gN, gM, vrow0):
+        st = self.lib.mmmot_pair_expand_bwd(_ptr(dV), _ld(dV), _ptr(dA), _ld(dA), C, _iptr(tiles.row0),
+                                            _iptr(tiles.nrows), _iptr(tiles.group), tiles.T, _iptr(row0), _iptr(gN),
+                                            _iptr(gM), _iptr(vrow0), self._stream())
+        _lib.check(st, 'mmmot_pair_expand_bwd')
+
+    def rowdot_bwd(self, X, K, w, b, sc, sh, tiles, act, gout, gidx, dA, PW):
+        st = self.lib.mmmot_rowdot_bwd(_ptr(X), _ld(X), K, _ptr(w), float(b), _ptr(sc), _ptr(sh), _ld(sc),
+                                       _iptr(tiles.row0), _iptr(tiles.nrows), _iptr(tiles.group), tiles.T, act,
+                                       _ptr(gout), _iptr(gidx), _ptr(dA), _ld(dA), _ptr(PW), _ld(PW), self._stream())
+        _lib.check(st, 'mmmot_rowdot_bwd')
+
+    def softmax_pairs_bwd(self, logits, dout, dlogits, row0, gN, gM, G, max_nm, mode):
+        st = self.lib.mmmot_softmax_pairs_bwd(_ptr(logits), _ptr(dout), _ptr(dlogits), _iptr(row0), _iptr(gN),
+                                              _iptr(gM), G, max_nm, mode, self._stream())
+        _lib.check(st, 'mmmot_softmax_pairs_bwd')
+
     def selftest_mfma(self, A, B, C, K):
         _lib.check(self.lib.mmmot_selftest_mfma(_ptr(A), _ptr(B), _ptr(C), K, self._stream()),
                    'mmmot_selftest_mfma')

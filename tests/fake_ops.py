@@ -259,6 +259,118 @@ class TorchOps:
             else:
                 out[s, :C] = rows.mean(0) if div is None else rows.sum(0) / float(div[s])
 
+    # ---- training backward of the pairwise block (csrc/backward.hip), in executable-specification form ----
+    @staticmethod
+    def _row_groups(tiles):
+        return _rows_groups(tiles)
+
+    def _dz_yhat(self, dA, Y, C, sc1, sh1, gamma, beta, relu, tiles):
+        grp = _rows_groups(tiles)
+        R = tiles.R
+        yh = Y[:R, :C].double() * sc1[grp, :C].double() + sh1[grp, :C].double()
+        z = yh * gamma[:C].double() + beta[:C].double()
+        dz = dA[:R, :C].double()
+        if relu:
+            dz = dz * (z > 0)
+        return dz, yh, grp
+
+    def gn_bwd_partial(self, dA, Y, C, sc1, sh1, gamma, beta, relu, tiles, P):
+        dz, yh, _ = self._dz_yhat(dA, Y, C, sc1, sh1, gamma, beta, relu, tiles)
+        for t in range(tiles.T):
+            r0, n = int(tiles.h_row0[t]), int(tiles.h_nrows[t])
+            P[t, 0, :C] = dz[r0:r0 + n].sum(0).float()
+            P[t, 1, :C] = (dz[r0:r0 + n] * yh[r0:r0 + n]).sum(0).float()
+
+    def gn_bwd_finalize(self, S, tiles, C, NG, gamma, M):
+        S3 = S.view(tiles.G, 2, C).double()
+        CG = C // NG
+        for g in range(tiles.G):
+            cnt = float(tiles.h_g_count[g]) * CG
+            for k in range(2):
+                m = (S3[g, k] * gamma[:C].double()).view(NG, CG).sum(1) / cnt
+                M[g, k, :C] = m.repeat_interleave(CG).float()
+
+    def gn_bwd_apply(self, dA, Y, C, sc1, sh1, gamma, beta, relu, M, tiles, dY):
+        dz, yh, grp = self._dz_yhat(dA, Y, C, sc1, sh1, gamma, beta, relu, tiles)
+        m1, m2 = M[grp, 0, :C].double(), M[grp, 1, :C].double()
+        dY[:tiles.R, :C] = (sc1[grp, :C].double() * (gamma[:C].double() * dz - m1 - yh * m2)).float()
+
+    def _a_operand(self, tiles, K, X, sc, sh, FA, FB, pair, amode, pairop):
+        grp = _rows_groups(tiles)
+        R = tiles.R
+        if amode == 2:  # pair
+            rows = []
+            for g in range(len(pair['row0'])):
+                N = None
+            A = torch.zeros(R, K, dtype=torch.float64)
+            row0, gM, aoff, boff = [t.cpu().numpy() for t in (pair['row0'], pair['M'], pair['aoff'], pair['boff'])]
+            for t in range(tiles.T):
+                r0, n, g = int(tiles.h_row0[t]), int(tiles.h_nrows[t]), int(tiles.h_group[t])
+                local = torch.arange(r0, r0 + n) - int(row0[g])
+                i, j = local // int(gM[g]), local % int(gM[g])
+                a, b = FA[int(aoff[g]) + i, :K].double(), FB[int(boff[g]) + j, :K].double()
+                A[r0:r0 + n] = a * b if pairop == 0 else ((a - b).abs() / 2 if pairop == 1 else (a - b) / 2)
+            return A
+        A = X[:R, :K].double()
+        if amode == 1:
+            A = torch.relu(A * sc[grp, :K].double() + sh[grp, :K].double())
+        return A
+
+    def gemm_tn(self, dY, tiles, N, K, dW, db=None, X=None, sc=None, sh=None, FA=None, FB=None, pair=None, amode=0,
+                pairop=0):
+        A = self._a_operand(tiles, K, X, sc, sh, FA, FB, pair, amode, pairop)
+        d = dY[:tiles.R, :N].double()
+        dW[:N, :K] = (d.t() @ A).float()
+        if db is not None:
+            db[:N] = d.sum(0).float()
+
+    def pair_bwd(self, dX, F, dF, C, row0, gN, gM, aoff, boff, blk_group, blk_idx, pairop, side):
+        for g in range(row0.numel()):
+            N, M, r0, ao, bo = int(gN[g]), int(gM[g]), int(row0[g]), int(aoff[g]), int(boff[g])
+            d = dX[r0:r0 + N * M, :C].double().view(N, M, C)
+            a, b = F[ao:ao + N, :C].double().unsqueeze(1), F[bo:bo + M, :C].double().unsqueeze(0)
+            if pairop == 0:
+                wa, wb = b.expand(N, M, C), a.expand(N, M, C)
+            elif pairop == 1:
+                sgn = torch.sign(a - b)
+                wa, wb = 0.5 * sgn, -0.5 * sgn
+            else:
+                wa, wb = torch.full((N, M, C), 0.5, dtype=torch.float64), torch.full((N, M, C), -0.5, dtype=torch.float64)
+            if side == 0:
+                dF[ao:ao + N, :C] += (d * wa).sum(1).float()
+            else:
+                dF[bo:bo + M, :C] += (d * wb).sum(0).float()
+
+    def pair_expand_bwd(self, dV, dA, C, tiles, row0, gN, gM, vrow0):
+        for g in range(row0.numel()):
+            N, M, r0, v0 = int(gN[g]), int(gM[g]), int(row0[g]), int(vrow0[g])
+            new, end = dV[v0:v0 + M, :C].double(), dV[v0 + M:v0 + M + N, :C].double()
+            dA[r0:r0 + N * M, :C] = (new.unsqueeze(0) / N + end.unsqueeze(1) / M).reshape(N * M, C).float()
+
+    def rowdot_bwd(self, X, K, w, b, sc, sh, tiles, act, gout, gidx, dA, PW):
+        grp = _rows_groups(tiles)
+        R = tiles.R
+        a = torch.relu(X[:R, :K].double() * sc[grp, :K].double() + sh[grp, :K].double())
+        pre = a @ w[:K].double() + b
+        gp = (gout[gidx[:R].long()] if gidx is not None else gout[:R]).double()
+        if act == ACT_SIGMOID:
+            s_ = torch.sigmoid(pre)
+            gp = gp * s_ * (1 - s_)
+        dA[:R, :K] = (gp.unsqueeze(1) * w[:K].double().unsqueeze(0)).float()
+        for t in range(tiles.T):
+            r0, n = int(tiles.h_row0[t]), int(tiles.h_nrows[t])
+            PW[t, :K] = (gp[r0:r0 + n].unsqueeze(1) * a[r0:r0 + n]).sum(0).float()
+            PW[t, K] = gp[r0:r0 + n].sum().float()
+
+    def softmax_pairs_bwd(self, logits, dout, dlogits, row0, gN, gM, G, max_nm, mode):
+        for g in range(G):
+            N, M, r0 = int(gN[g]), int(gM[g]), int(row0[g])
+            x = logits[r0:r0 + N * M].double().view(N, M).clone().requires_grad_(True)
+            p, q = torch.softmax(x, 1), torch.softmax(x, 0)
+            out = p if mode == 1 else (p * q if mode == 2 else ((p + q) / 2 if mode == 3 else torch.max(p, q)))
+            (gx,) = torch.autograd.grad(out, x, dout[r0:r0 + N * M].double().view(N, M))
+            dlogits[r0:r0 + N * M] = gx.reshape(-1).float()
+
     def rowdot(self, X, K, w, b, tiles, out, sc=None, sh=None, act=ACT_NONE, use_thr=False, thr=0.0, omap=None):
         R = tiles.R
         A = X[:R, :K]

@@ -1,0 +1,102 @@
+"""Host logic of the training backward of the pairwise block (mmmot_amd/backward.py) on the torch emulation of the
+C-ABI: the launch schedule, the tape, the table building and the gradient algebra must reproduce torch.autograd
+through the ORACLE's affinity / new_end / softmax (the CPU restatement of reference modules/gcn.py:68-82,
+new_end.py:62-82, tracking_net.py:106-126).  The GPU suite (tests/test_backward_gpu.py) runs the same comparison
+through the HIP kernels."""
+import pytest
+import torch
+
+from common import build_model, get_case
+from fake_ops import TorchOps
+from mmmot_amd.backward import affinity_autograd, affinity_backward, affinity_forward_train
+from oracle import restatement as R
+
+
+def oracle_block(sd, F3, counts, op, sm):
+    """link / new / end of the oracle for a list of frame counts, from F3 [nR, 512, L] (reference layout)"""
+    links, news, ends = [], [], []
+    start = 0
+    for i in range(len(counts) - 1):
+        mid, stop = start + counts[i], start + counts[i] + counts[i + 1]
+        logit, new, end = R.affinity(F3[:, :, start:mid], F3[:, :, mid:stop], sd, op)
+        links.append(R.softmax_mode(logit, sm).squeeze(1))
+        news.append(new)
+        ends.append(end)
+        start = mid
+    return links, news, ends
+
+
+def reference_grads(model, samples, F, op, sm, w_link, w_new, w_end):
+    """autograd through the oracle in float64; F [nR, Lt, 512] (ours) <-> [nR, 512, L] per sample (reference)"""
+    sd = {k: v.detach().double().clone().requires_grad_(k.startswith('w_link.')) for k, v in model.state_dict().items()}
+    Fd = F.detach().double().clone().requires_grad_(True)
+    loss = 0.0
+    off, lo = 0, 0
+    for counts in samples:
+        L = sum(counts)
+        F3 = Fd[:, off:off + L].permute(0, 2, 1)
+        links, news, ends = oracle_block(sd, F3, counts, op, sm)
+        d0 = off
+        for p, (lk, nw, en) in enumerate(zip(links, news, ends)):
+            N, M = counts[p], counts[p + 1]
+            n = lk.numel()
+            loss = loss + (lk.reshape(-1) * w_link[lo:lo + n].double()).sum()
+            lo += n
+            loss = loss + (nw * w_new[:, d0 + N:d0 + N + M].double()).sum() + (en * w_end[:, d0:d0 + N].double()).sum()
+            d0 += N
+        off += L
+    loss.backward()
+    return Fd.grad, {k: v.grad for k, v in sd.items() if k.startswith('w_link.')}
+
+
+@pytest.mark.parametrize('op,sm,samples', [
+    ('multiply', 'none', [[3, 4]]),
+    ('minus_abs', 'dual_add', [[5, 2], [1, 6]]),
+    ('minus', 'dual', [[2, 3, 2]]),
+    ('multiply', 'dual_max', [[4, 4]]),
+    ('minus_abs', 'single', [[1, 1], [3, 5]]),
+])
+def test_backward_matches_autograd_through_the_oracle(op, sm, samples):
+    from mmmot_amd.plan import BatchPlan
+    c, base = get_case('s2_C_multiply_none')
+    c = dict(c, aff=op, sm=sm)
+    if any(len(s) > 2 for s in samples):
+        c['counts'] = samples[0]
+    m = build_model(c, base, ops=TorchOps())
+    m.set_trunk('f32')  # exact-fp32 GEMMs in the emulated forward: the comparison is about the gradient algebra
+    eng = m.engine()
+    plan = BatchPlan([(s, None) for s in samples], 32, 'cpu', use_points=False)
+    g = torch.Generator().manual_seed(3)
+    F = torch.randn(3, plan.Lt, 512, generator=g) * 0.7
+    R_ = plan.pair_tiles.R
+    w_link, w_new, w_end = torch.randn(R_, generator=g), torch.randn(3, plan.Lt, generator=g), torch.randn(3, plan.Lt, generator=g)
+    link, new, end, tape = affinity_forward_train(eng, plan, F)
+    dF, grads = affinity_backward(eng, plan, F, tape, w_link, w_new, w_end)
+    dF_ref, g_ref = reference_grads(m, samples, F, op, sm, w_link, w_new, w_end)
+    scale = dF_ref.abs().max().item()
+    assert (dF.double() - dF_ref).abs().max().item() < 2e-4 * scale, 'dF'
+    assert set(grads) == set(g_ref)
+    gmax = max(v.abs().max().item() for v in g_ref.values())
+    for k, ref in g_ref.items():
+        got = grads[k].double().reshape(ref.shape)
+        # relative to the parameter's own largest gradient, plus fp32 rounding noise of the whole backward (the bias of
+        # a conv that feeds a per-channel GroupNorm has an exactly zero gradient: only noise is left to compare)
+        tol = 2e-4 * ref.abs().max().item() + 2e-6 * (1.0 + gmax)
+        assert (got - ref).abs().max().item() < tol, (k, (got - ref).abs().max().item(), ref.abs().max().item())
+
+
+def test_autograd_function_fills_grads():
+    from mmmot_amd.plan import BatchPlan
+    c, base = get_case('s2_C_multiply_none')
+    m = build_model(c, base, ops=TorchOps())
+    m.set_trunk('f32')
+    plan = BatchPlan([([3, 2], None)], 32, 'cpu', use_points=False)
+    F = (torch.randn(3, 5, 512, generator=torch.Generator().manual_seed(1)) * 0.7).requires_grad_(True)
+    link, new, end = affinity_autograd(m, plan, F)
+    (link.sum() + 2 * new.sum() - end.sum()).backward()
+    assert F.grad is not None and F.grad.shape == F.shape and torch.isfinite(F.grad).all()
+    for k, p in m.named_parameters():
+        if k.startswith('w_link.'):
+            assert p.grad is not None and p.grad.shape == p.shape, k
+        else:
+            assert p.grad is None, k

@@ -1,0 +1,182 @@
+"""Training backward of the pairwise block on the device (csrc/backward.hip through the C-ABI):
+* every backward kernel against its executable specification (tests/fake_ops.py);
+* end to end: dF and every w_link.* gradient against torch.autograd through the ORACLE (float64 CPU restatement of
+  reference modules/gcn.py:68-82, new_end.py:62-82, tracking_net.py:106-126), all pairwise ops / softmax modes, several
+  samples per batch, a 3-frame sample, N x M up to 32 x 32; through the autograd.Function as well."""
+import numpy as np
+import pytest
+import torch
+
+from common import build_model, get_case
+from fake_ops import TorchOps
+from mmmot_amd.backward import affinity_autograd, affinity_backward, affinity_forward_train
+from mmmot_amd.plan import BatchPlan, RowTiles
+from test_backward_cpu import reference_grads
+from test_kernels_gpu import close, hip, rnd  # noqa: F401  (hip is a fixture)
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def both(tiles_counts):
+    return RowTiles(tiles_counts, 'cpu'), RowTiles(tiles_counts, DEV)
+
+
+@pytest.mark.parametrize('C,NG', [(128, 128), (512, 1), (512, 512), (64, 4)])
+def test_gn_backward_kernels(hip, C, NG):
+    emu = TorchOps()
+    tc, tg = both([5, 300, 128, 1])
+    R, G = tc.R, tc.G
+    Y, dA = rnd(R, C, seed=1), rnd(R, C, seed=2)
+    sc1, sh1 = rnd(G, C, seed=3).abs() + 0.3, rnd(G, C, seed=4) * 0.2
+    gamma, beta = rnd(C, seed=5) + 1.0, rnd(C, seed=6) * 0.3
+    Pc, Pg = torch.zeros(tc.T, 2, C), torch.zeros(tc.T, 2, C, device=DEV)
+    emu.gn_bwd_partial(dA, Y, C, sc1, sh1, gamma, beta, True, tc, Pc)
+    hip.gn_bwd_partial(dA.cuda(), Y.cuda(), C, sc1.cuda(), sh1.cuda(), gamma.cuda(), beta.cuda(), True, tg, Pg)
+    close(Pg, Pc, 2e-5, 'gn_bwd_partial')
+    S = torch.stack([Pc[int(tc.h_g_tile0[g]):int(tc.h_g_tile0[g]) + int(tc.h_g_ntiles[g])].sum(0) for g in range(G)])
+    Mc, Mg = torch.zeros(G, 2, C), torch.zeros(G, 2, C, device=DEV)
+    emu.gn_bwd_finalize(S.reshape(G * 2, C), tc, C, NG, gamma, Mc)
+    hip.gn_bwd_finalize(S.reshape(G * 2, C).cuda(), tg, C, NG, gamma.cuda(), Mg)
+    close(Mg, Mc, 2e-6, 'gn_bwd_finalize')
+    dYc, dYg = torch.zeros(R, C), torch.full((R, C), float('nan'), device=DEV)
+    emu.gn_bwd_apply(dA, Y, C, sc1, sh1, gamma, beta, True, Mc, tc, dYc)
+    hip.gn_bwd_apply(dA.cuda(), Y.cuda(), C, sc1.cuda(), sh1.cuda(), gamma.cuda(), beta.cuda(), True, Mc.cuda(), tg, dYg)
+    close(dYg, dYc, 2e-6, 'gn_bwd_apply')
+
+
+@pytest.mark.parametrize('amode', [0, 1, 2])
+def test_gemm_tn(hip, amode):
+    emu = TorchOps()
+    N, K = 128, 192
+    if amode == 2:
+        plan_c = BatchPlan([([5, 7], None), ([3, 2, 4], None)], 32, 'cpu', use_points=False)
+        plan_g = BatchPlan([([5, 7], None), ([3, 2, 4], None)], 32, DEV, use_points=False)
+        tc, tg = plan_c.pair_tiles, plan_g.pair_tiles
+        F = rnd(3 * plan_c.Lt, K, seed=7)
+        pair_c = dict(row0=tc.g_row0, M=plan_c.pg_M, aoff=plan_c.pg_aoff, boff=plan_c.pg_boff)
+        pair_g = dict(row0=tg.g_row0, M=plan_g.pg_M, aoff=plan_g.pg_aoff, boff=plan_g.pg_boff)
+        kw_c, kw_g = dict(FA=F, FB=F, pair=pair_c, pairop=1), dict(FA=F.cuda(), FB=F.cuda(), pair=pair_g, pairop=1)
+    else:
+        tc, tg = both([7, 260, 128])
+        X, sc, sh = rnd(tc.R, K, seed=8), rnd(tc.G, K, seed=9) + 1.0, rnd(tc.G, K, seed=10) * 0.5
+        kw_c = dict(X=X, sc=sc, sh=sh) if amode else dict(X=X)
+        kw_g = {k: v.cuda() for k, v in kw_c.items()}
+    dY = rnd(tc.R, N, seed=11)
+    dWc, dbc = torch.zeros(N, K), torch.zeros(N)
+    dWg, dbg = torch.full((N, K), float('nan'), device=DEV), torch.full((N,), float('nan'), device=DEV)
+    emu.gemm_tn(dY, tc, N, K, dWc, dbc, amode=amode, **kw_c)
+    hip.gemm_tn(dY.cuda(), tg, N, K, dWg, dbg, amode=amode, **kw_g)
+    close(dWg, dWc, 2e-6, 'gemm_tn dW')
+    close(dbg, dbc, 2e-6, 'gemm_tn db')
+
+
+@pytest.mark.parametrize('pairop', [0, 1, 2])
+def test_pair_backward_kernels(hip, pairop):
+    from mmmot_amd.backward import _aux
+    emu = TorchOps()
+    samples = [([5, 7], None), ([3, 2, 4], None), ([1, 1], None)]
+    pc, pg = BatchPlan(samples, 32, 'cpu', use_points=False), BatchPlan(samples, 32, DEV, use_points=False)
+    C = 256
+    F = rnd(3 * pc.Lt, C, seed=12)
+    dX = rnd(pc.pair_tiles.R, C, seed=13)
+    dFc, dFg = torch.zeros(3 * pc.Lt, C), torch.zeros(3 * pc.Lt, C, device=DEV)
+    ac, ag = _aux(pc), _aux(pg)
+    for side, (bg_c, bi_c, bg_g, bi_g) in enumerate([(ac.a_grp, ac.a_idx, ag.a_grp, ag.a_idx), (ac.b_grp, ac.b_idx, ag.b_grp, ag.b_idx)]):
+        emu.pair_bwd(dX, F, dFc, C, pc.pair_tiles.g_row0, pc.pg_N, pc.pg_M, pc.pg_aoff, pc.pg_boff, bg_c, bi_c, pairop, side)
+        hip.pair_bwd(dX.cuda(), F.cuda(), dFg, C, pg.pair_tiles.g_row0, pg.pg_N, pg.pg_M, pg.pg_aoff, pg.pg_boff, bg_g, bi_g, pairop, side)
+    close(dFg, dFc, 2e-6, 'pair_bwd')
+    dV = rnd(pc.v_tiles.R, C, seed=14)
+    dAc, dAg = torch.zeros(pc.pair_tiles.R, C), torch.full((pc.pair_tiles.R, C), float('nan'), device=DEV)
+    emu.pair_expand_bwd(dV, dAc, C, pc.pair_tiles, pc.pair_tiles.g_row0, pc.pg_N, pc.pg_M, ac.vrow0)
+    hip.pair_expand_bwd(dV.cuda(), dAg, C, pg.pair_tiles, pg.pair_tiles.g_row0, pg.pg_N, pg.pg_M, ag.vrow0)
+    close(dAg, dAc, 1e-6, 'pair_expand_bwd')
+
+
+@pytest.mark.parametrize('act,use_idx', [(0, False), (2, True)])
+def test_rowdot_backward(hip, act, use_idx):
+    emu = TorchOps()
+    tc, tg = both([5, 300, 128])
+    K, R = 128, tc.R
+    X, w = rnd(R, K, seed=15), rnd(K, seed=16)
+    sc, sh = rnd(tc.G, K, seed=17) + 1.0, rnd(tc.G, K, seed=18) * 0.5
+    gidx = torch.randperm(2 * R, generator=torch.Generator().manual_seed(1))[:R].to(torch.int32) if use_idx else None
+    gout = rnd(2 * R if use_idx else R, seed=19)
+    dAc, PWc = torch.zeros(R, K), torch.zeros(tc.T, 132)
+    dAg, PWg = torch.full((R, K), float('nan'), device=DEV), torch.zeros(tc.T, 132, device=DEV)
+    emu.rowdot_bwd(X, K, w, 0.3, sc, sh, tc, act, gout, gidx, dAc, PWc)
+    hip.rowdot_bwd(X.cuda(), K, w.cuda(), 0.3, sc.cuda(), sh.cuda(), tg, act, gout.cuda(),
+                   None if gidx is None else gidx.cuda(), dAg, PWg)
+    close(dAg, dAc, 2e-6, 'rowdot_bwd dA')
+    close(PWg[:, :129], PWc[:, :129], 2e-5, 'rowdot_bwd partial dw / db')
+
+
+@pytest.mark.parametrize('mode', [1, 2, 3, 4])
+def test_softmax_backward(hip, mode):
+    emu = TorchOps()
+    samples = [([5, 7], None), ([32, 20], None), ([1, 1], None), ([1, 9], None)]
+    pc, pg = BatchPlan(samples, 32, 'cpu', use_points=False), BatchPlan(samples, 32, DEV, use_points=False)
+    R = pc.pair_tiles.R
+    logits, dout = rnd(R, seed=20) * 2.0, rnd(R, seed=21)
+    dc, dg = torch.zeros(R), torch.full((R,), float('nan'), device=DEV)
+    emu.softmax_pairs_bwd(logits, dout, dc, pc.pair_tiles.g_row0, pc.pg_N, pc.pg_M, pc.pair_tiles.G, pc.max_nm, mode)
+    hip.softmax_pairs_bwd(logits.cuda(), dout.cuda(), dg, pg.pair_tiles.g_row0, pg.pg_N, pg.pg_M, pg.pair_tiles.G, pg.max_nm, mode)
+    close(dg, dc, 3e-6, 'softmax_pairs_bwd')
+
+
+@pytest.mark.parametrize('trunk,rtol', [('f32', 2e-4), ('f16x3', 5e-4)])
+@pytest.mark.parametrize('op,sm,samples', [
+    ('multiply', 'none', [[3, 4]]),
+    ('minus_abs', 'dual_add', [[5, 2], [1, 6]]),
+    ('minus', 'dual', [[2, 3, 2]]),
+    ('multiply', 'dual_max', [[4, 4]]),
+    ('minus_abs', 'single', [[1, 1], [3, 5]]),
+    ('multiply', 'none', [[32, 32], [20, 31]]),
+    ('minus_abs', 'dual_add', [[32, 32]]),
+])
+def test_backward_matches_autograd_through_the_oracle(op, sm, samples, trunk, rtol):
+    c, base = get_case('s2_C_multiply_none')
+    c = dict(c, aff=op, sm=sm)
+    if any(len(s) > 2 for s in samples):
+        c['counts'] = samples[0]
+    m_cpu = build_model(c, base)
+    m = build_model(c, base, device=DEV)
+    m.set_trunk(trunk)
+    eng = m.engine()
+    assert eng.ops.name == 'hip'
+    plan = BatchPlan([(s, None) for s in samples], 32, DEV, use_points=False)
+    g = torch.Generator().manual_seed(3)
+    F = torch.randn(3, plan.Lt, 512, generator=g) * 0.7
+    R_ = plan.pair_tiles.R
+    w_link, w_new, w_end = torch.randn(R_, generator=g), torch.randn(3, plan.Lt, generator=g), torch.randn(3, plan.Lt, generator=g)
+    Fd = F.to(DEV)
+    link, new, end, tape = affinity_forward_train(eng, plan, Fd)
+    dF, grads = affinity_backward(eng, plan, Fd, tape, w_link.to(DEV), w_new.to(DEV), w_end.to(DEV))
+    dF_ref, g_ref = reference_grads(m_cpu, samples, F, op, sm, w_link, w_new, w_end)
+    err = (dF.cpu().double() - dF_ref).abs().max().item() / dF_ref.abs().max().item()
+    worst = {'dF': err}
+    assert err < rtol, ('dF', err)
+    gmax = max(v.abs().max().item() for v in g_ref.values())
+    for k, ref in g_ref.items():
+        got = grads[k].cpu().double().reshape(ref.shape)
+        e = (got - ref).abs().max().item()
+        tol = rtol * ref.abs().max().item() + 1e-2 * rtol * (1.0 + gmax)
+        worst[k] = e / max(ref.abs().max().item(), 1e-30)
+        assert e < tol, (k, e, ref.abs().max().item())
+    print('backward %s/%s %s %s: dF rel %.1e, worst parameter-gradient rel %.1e' % (
+        op, sm, samples, trunk, err, max(v for k, v in worst.items() if k != 'dF' and g_ref[k].abs().max() > 1e-6 * gmax)))
+
+
+def test_autograd_function_on_the_device():
+    c, base = get_case('s2_C_minus_abs_dual_add')
+    m = build_model(c, base, device=DEV)
+    plan = BatchPlan([([6, 5], None), ([2, 9], None)], 32, DEV, use_points=False)
+    F = (torch.randn(3, plan.Lt, 512, generator=torch.Generator().manual_seed(1)) * 0.7).to(DEV).requires_grad_(True)
+    link, new, end = affinity_autograd(m, plan, F)
+    # the training forward is the inference forward: same scores as Engine.affinity
+    l2, n2, e2 = m.engine().affinity(plan, F.detach())
+    assert torch.allclose(link, l2, atol=1e-6) and torch.allclose(new, n2, atol=1e-6) and torch.allclose(end, e2, atol=1e-6)
+    (link.square().sum() + 2 * new.sum() - end.sum()).backward()
+    assert F.grad is not None and torch.isfinite(F.grad).all() and F.grad.abs().max() > 0
+    for k, p in m.named_parameters():
+        assert (p.grad is not None and p.grad.shape == p.shape and torch.isfinite(p.grad).all()) == k.startswith('w_link.'), k
