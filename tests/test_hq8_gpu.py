@@ -198,9 +198,13 @@ def test_conv3x3_hq8_per_channel_scales(hip, pool, L, H, W, Cin, Cout):
     osc = torch.pow(2.0, -shifts.double()).float()
     xrec, wrec = to_hq8_act(x), to_hq8_w(w * torch.pow(2.0, shifts.double()).view(1, -1, 1))
     dec, ref, _ = run_records(hip, xrec, wrec, bias, pool, L, H, W, Cin, Cout, osc)
-    per_ch = ((dec.cpu().double() - ref.double()).abs().amax(dim=0) / ref.double().abs().amax(dim=0).clamp_min(1e-30))
-    print('hq8 per-channel scales: worst per-channel relative deviation from the emulation %.2e' % per_ch.max().item())
-    assert per_ch.max().item() < ENC_TOL, 'kernel differs from the emulation of the hq8 arithmetic'
+    # per channel: the encoding tolerance relative to the channel's largest output, plus the absolute quantum of the
+    # hq8 OUTPUT record (e4m3(512 lo) is subnormal below lo = 2^-15: 2^-18 absolute) - the low-gain channels' outputs
+    # are ~1e-3 here
+    err, chmax = (dec.cpu().double() - ref.double()).abs().amax(dim=0), ref.double().abs().amax(dim=0)
+    print('hq8 per-channel scales: worst per-channel relative deviation from the emulation %.2e (output maxima %.1e .. %.1e)'
+          % ((err / chmax.clamp_min(1e-30)).max().item(), chmax.min().item(), chmax.max().item()))
+    assert (err <= ENC_TOL * chmax + 2.0 ** -17).all(), 'kernel differs from the emulation of the hq8 arithmetic'
 
 
 @pytest.mark.parametrize('name', case_names())
