@@ -156,8 +156,9 @@ def test_backward_matches_autograd_through_the_oracle(op, sm, samples, trunk, rt
     # ReLU is not differentiable at 0: with ~1e6 pre-activations per forward, one of them can sit within fp32 rounding
     # of zero and take the other branch than in the float64 reference, which moves the gradients that flow through it
     # by a few per cent of their maximum (seen on the 32 x 32 cases; any fp32 implementation has this, and the
-    # emulation run in float64 agrees to 8e-8).  So: strict L-inf for every tensor unless a small fraction of its
-    # entries is off while its L2 error stays small - a wrong formula or index shows up in L2.
+    # emulation run in float64 agrees to 8e-8; a flip upstream of a GroupNorm touches every channel of its gamma / beta
+    # gradient a little).  So: strict L-inf for every tensor, or - when that fails - a small L2 error with a bounded
+    # L-inf: a wrong formula or index shows up as an O(1) L2 error.
     gmax = max(v.abs().max().item() for v in g_ref.values())
 
     def check(name, got, ref):
@@ -168,8 +169,7 @@ def test_backward_matches_autograd_through_the_oracle(op, sm, samples, trunk, rt
         if linf < tol:
             return linf / max(rmax, 1e-30), False
         l2 = (d.norm() / max(ref.norm().item(), 1e-30)).item()
-        frac = (d.abs() > tol).double().mean().item()
-        assert l2 < 5e-3 and frac < 0.03 and linf < 0.1 * rmax + tol, (name, linf, rmax, l2, frac)
+        assert l2 < 5e-3 and linf < 0.1 * rmax + tol, (name, linf, rmax, l2)
         return l2, True
 
     res = {'dF': check('dF', dF, dF_ref)}
@@ -190,6 +190,7 @@ def test_autograd_function_on_the_device():
     F = (torch.randn(3, plan.Lt, 512, generator=torch.Generator().manual_seed(1)) * 0.7).to(DEV).requires_grad_(True)
     link, new, end = affinity_autograd(m, plan, F)
     # the training forward is the inference forward: same scores as Engine.affinity
+    m.engine().dev = torch.device(DEV)  # Engine.forward sets it; affinity() is called on its own here
     l2, n2, e2 = m.engine().affinity(plan, F.detach())
     assert torch.allclose(link, l2, atol=1e-6) and torch.allclose(new, n2, atol=1e-6) and torch.allclose(end, e2, atol=1e-6)
     (link.square().sum() + 2 * new.sum() - end.sum()).backward()
