@@ -410,7 +410,8 @@ int mmmot_gn_bwd_apply(const float* dA, int ldda, const float* Y, int ldy, int C
                        const int* tile_row0, const int* tile_nrows, const int* tile_group, int T, float* dY, int lddy,
                        void* stream);
 /* dW[n][k] = sum_r dY[r][n] * A(r,k), db[n] = sum_r dY[r][n]; A(r,k) is regenerated like the forward's A operand
- * (MMMOT_A_PLAIN / MMMOT_A_NORM_RELU / MMMOT_A_PAIR).  N % 64 == 0, K % 64 == 0.  Deterministic. */
+ * (MMMOT_A_PLAIN / MMMOT_A_NORM_RELU / MMMOT_A_PAIR).  N % 64 == 0, K % 64 == 0.  Deterministic (row split with
+ * per-share partial outputs, no atomics). */
 typedef struct mmmot_gemm_tn_args {
   const float* dY; int lddy;            /* [rows][N] gradient of the layer's pre-norm output */
   const float* X; int ldx;              /* PLAIN / NORM_RELU source rows                      */
@@ -419,8 +420,10 @@ typedef struct mmmot_gemm_tn_args {
   const int* tile_row0; const int* tile_nrows; const int* tile_group;
   const int* grp_row0; const int* grp_M; const int* grp_aoff; const int* grp_boff;
   int T; int N; int K; int amode; int pairop;
-  float* dW;                            /* [N][K]                                             */
-  float* db;                            /* [N] or NULL                                        */
+  int nsplit;                           /* >= 1: the tiles are split into nsplit contiguous shares, share s writes
+                                           its partial sums to dW + s*N*K and db + s*N (the caller adds them up)   */
+  float* dW;                            /* [nsplit][N][K]                                     */
+  float* db;                            /* [nsplit][N] or NULL                                */
 } mmmot_gemm_tn_args;
 int mmmot_gemm_tn(const mmmot_gemm_tn_args* a, void* stream);
 /* backward of the pairwise operand generation (gcn.py:6-41): side 0 accumulates d op / d a over j into

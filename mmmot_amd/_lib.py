@@ -72,7 +72,7 @@ class GemmTnArgs(ctypes.Structure):
         ('FA', c_f), ('FB', c_f), ('ldf', c_i),
         ('tile_row0', c_f), ('tile_nrows', c_f), ('tile_group', c_f),
         ('grp_row0', c_f), ('grp_M', c_f), ('grp_aoff', c_f), ('grp_boff', c_f),
-        ('T', c_i), ('N', c_i), ('K', c_i), ('amode', c_i), ('pairop', c_i),
+        ('T', c_i), ('N', c_i), ('K', c_i), ('amode', c_i), ('pairop', c_i), ('nsplit', c_i),
         ('dW', c_f), ('db', c_f),
     ]
 

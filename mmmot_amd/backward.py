@@ -189,9 +189,12 @@ def affinity_backward(eng, plan, F, t, d_link, d_new, d_end):
     g = {}
 
     def weight_grad(name, bname, dY, tiles, N, K, **kw):
-        dW, db = new(N, K), new(N)
-        ops.gemm_tn(dY, tiles, N, K, dW, db, **kw)
-        g[name], g[bname] = dW, db
+        # the reduction over the rows is split into contiguous shares of the tiles (one workgroup walks one share
+        # for one 64 x 64 tile of dW); the partial sums are added by the strided-sum kernel: deterministic
+        ns = max(1, min(16, tiles.T // 8))
+        dWp, dbp = new(ns, N * K), new(ns, N)
+        ops.gemm_tn(dY, tiles, N, K, dWp, dbp, nsplit=ns, **kw)
+        g[name], g[bname] = (_colsum(eng, dWp).view(N, K), _colsum(eng, dbp)) if ns > 1 else (dWp.view(N, K), dbp.view(N))
 
     # ---- link branch, from the scores back to dYa[:, 512:] ----
     d_link = d_link.reshape(-1).contiguous()
@@ -234,8 +237,8 @@ def affinity_backward(eng, plan, F, t, d_link, d_new, d_end):
     ops.pair_expand_bwd(dV, dAne, 512, PT, PT.g_row0, plan.pg_N, plan.pg_M, aux.vrow0)
     _, g['g_ne0'], g['be_ne0'] = _gn_backward(eng, plan, NE0, dAne, out=dYa[:, 0:512])
     # ---- the stacked first layer over the pairwise tensor, and the pairwise operand generation ----
-    dWa, dba = new(1024, 512), new(1024)
-    ops.gemm_tn(dYa, PT, 1024, 512, dWa, dba, FA=Ff, FB=Ff, pair=t['pair'], amode=A_PAIR, pairop=t['pairop'])
+    weight_grad('wa', 'ba', dYa, PT, 1024, 512, FA=Ff, FB=Ff, pair=t['pair'], amode=A_PAIR, pairop=t['pairop'])
+    dWa, dba = g.pop('wa'), g.pop('ba')
     dX = new(R, 512)
     ops.gemm(tr('wa'), PT, 512, 1024, X=dYa, Y=dX)
     dF = torch.zeros(nR * Lt, 512, dtype=torch.float32, device=dev)

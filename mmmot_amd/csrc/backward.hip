@@ -155,7 +155,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(mmmot_gemm_tn_args a) {
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
   float bsum = 0.f;
   const int n = n0 + lr, k = k0 + lr;
-  for (int t = 0; t < a.T; ++t) {
+  // row split: workgroup z of gridDim.z walks its contiguous share of the tiles and writes its own partial
+  // dW / db (the caller sums the gridDim.z partials: deterministic, no atomics)
+  const int t_lo = (int)((long)a.T * blockIdx.z / gridDim.z), t_hi = (int)((long)a.T * (blockIdx.z + 1) / gridDim.z);
+  float* dW = a.dW + (long)blockIdx.z * a.N * a.K;
+  float* db = a.db ? a.db + (long)blockIdx.z * a.N : nullptr;
+  for (int t = t_lo; t < t_hi; ++t) {
     const int row0 = a.tile_row0[t], nrows = a.tile_nrows[t];
     const int g = a.tile_group ? a.tile_group[t] : 0;
     float s = 1.f, h = 0.f;
@@ -194,10 +199,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(mmmot_gemm_tn_args a) {
     }
   }
 #pragma unroll
-  for (int e = 0; e < 16; ++e) a.dW[(long)(n0 + mm_acc_row(e, lane)) * a.K + k0 + lr] = acc[e];
-  if (a.db && blockIdx.y == 0 && (wave & 1) == 0) {
+  for (int e = 0; e < 16; ++e) dW[(long)(n0 + mm_acc_row(e, lane)) * a.K + k0 + lr] = acc[e];
+  if (db && blockIdx.y == 0 && (wave & 1) == 0) {
     bsum += __shfl_xor(bsum, 32);
-    if (hf == 0) a.db[n] = bsum;
+    if (hf == 0) db[n] = bsum;
   }
 }
 
@@ -212,7 +217,8 @@ extern "C" int mmmot_gemm_tn(const mmmot_gemm_tn_args* a, void* stream) {
     if (a->amode == MMMOT_A_NORM_RELU && (!a->sc || !a->sh)) return MMMOT_EINVAL;
     if (a->amode != MMMOT_A_PLAIN && a->amode != MMMOT_A_NORM_RELU) return MMMOT_EINVAL;
   }
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(a->N / 64, a->K / 64), dim3(256), 0, (hipStream_t)stream, *a);
+  if (a->nsplit < 1 || a->nsplit > 1024) return MMMOT_EINVAL;
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(a->N / 64, a->K / 64, a->nsplit), dim3(256), 0, (hipStream_t)stream, *a);
   return mm_check(hipGetLastError());
 }
 

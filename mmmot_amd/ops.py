@@ -258,8 +258,10 @@ class HipOps:
         _lib.check(st, 'mmmot_gn_bwd_apply')
 
     def gemm_tn(self, dY, tiles, N, K, dW, db=None, X=None, sc=None, sh=None, FA=None, FB=None, pair=None,
-                amode=A_PLAIN, pairop=0):
+                amode=A_PLAIN, pairop=0, nsplit=1):
+        """dW [nsplit][N][K] / db [nsplit][N]: per-share partial sums when nsplit > 1 (see mmmot_gemm_tn)."""
         a = _lib.GemmTnArgs()
+        a.nsplit = int(nsplit)
         a.dY, a.lddy = _ptr(dY), _ld(dY)
         a.X, a.ldx = _ptr(X), _ld(X)
         a.sc, a.sh, a.ldsc = _ptr(sc), _ptr(sh), _ld(sc)

@@ -317,12 +317,21 @@ class TorchOps:
         return A
 
     def gemm_tn(self, dY, tiles, N, K, dW, db=None, X=None, sc=None, sh=None, FA=None, FB=None, pair=None, amode=0,
-                pairop=0):
+                pairop=0, nsplit=1):
         A = self._a_operand(tiles, K, X, sc, sh, FA, FB, pair, amode, pairop)
         d = dY[:tiles.R, :N].double()
-        dW[:N, :K] = (d.t() @ A).float()
-        if db is not None:
-            db[:N] = d.sum(0).float()
+        dWv = dW.view(nsplit, N, K)
+        dbv = None if db is None else db.view(nsplit, N)
+        for s_ in range(nsplit):  # share s = tiles [T*s/nsplit, T*(s+1)/nsplit)
+            t_lo, t_hi = tiles.T * s_ // nsplit, tiles.T * (s_ + 1) // nsplit
+            if t_hi > t_lo:
+                r_lo = int(tiles.h_row0[t_lo])
+                r_hi = int(tiles.h_row0[t_hi - 1]) + int(tiles.h_nrows[t_hi - 1])
+            else:
+                r_lo = r_hi = 0
+            dWv[s_] = (d[r_lo:r_hi].t() @ A[r_lo:r_hi]).float()
+            if dbv is not None:
+                dbv[s_] = d[r_lo:r_hi].sum(0).float()
 
     def pair_bwd(self, dX, F, dF, C, row0, gN, gM, aoff, boff, blk_group, blk_idx, pairop, side):
         for g in range(row0.numel()):

@@ -63,12 +63,14 @@ def test_gemm_tn(hip, amode):
         kw_c = dict(X=X, sc=sc, sh=sh) if amode else dict(X=X)
         kw_g = {k: v.cuda() for k, v in kw_c.items()}
     dY = rnd(tc.R, N, seed=11)
-    dWc, dbc = torch.zeros(N, K), torch.zeros(N)
-    dWg, dbg = torch.full((N, K), float('nan'), device=DEV), torch.full((N,), float('nan'), device=DEV)
-    emu.gemm_tn(dY, tc, N, K, dWc, dbc, amode=amode, **kw_c)
-    hip.gemm_tn(dY.cuda(), tg, N, K, dWg, dbg, amode=amode, **kw_g)
-    close(dWg, dWc, 2e-6, 'gemm_tn dW')
-    close(dbg, dbc, 2e-6, 'gemm_tn db')
+    for ns in (1, 3):
+        dWc, dbc = torch.zeros(ns, N, K), torch.zeros(ns, N)
+        dWg, dbg = torch.full((ns, N, K), float('nan'), device=DEV), torch.full((ns, N), float('nan'), device=DEV)
+        emu.gemm_tn(dY, tc, N, K, dWc, dbc, amode=amode, nsplit=ns, **kw_c)
+        hip.gemm_tn(dY.cuda(), tg, N, K, dWg, dbg, amode=amode, nsplit=ns, **kw_g)
+        close(dWg, dWc, 2e-6, 'gemm_tn dW (nsplit %d)' % ns)
+        close(dbg, dbc, 2e-6, 'gemm_tn db (nsplit %d)' % ns)
+        close(dWg.sum(0), dWc.sum(0), 2e-6, 'gemm_tn dW summed')
 
 
 @pytest.mark.parametrize('pairop', [0, 1, 2])
