@@ -439,6 +439,13 @@ class Engine:
     # ---- whole forward -------------------------------------------------------
     def forward(self, plan, crops=None, points=None):
         """Returns dict(det [nR,Lt], link flat, new [nR,Lt], end [nR,Lt], feats F, cat)."""
+        pin = getattr(self.ops, 'on_current_stream', None)
+        if pin is None:
+            return self._forward(plan, crops, points)
+        with pin():
+            return self._forward(plan, crops, points)
+
+    def _forward(self, plan, crops=None, points=None):
         rows = plan.rows
         need_img = (0 in rows) or (2 in rows)
         need_pts = (1 in rows) or (2 in rows)

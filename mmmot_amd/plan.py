@@ -22,6 +22,47 @@ import torch
 TILE = 128
 
 
+class TableUpload:
+    """Collects the int32 host tables of a plan and moves them to the device in ONE copy.
+
+    A plan holds ~100 small integer tables; uploading each with its own ``.to(device)`` costs ~35 us of host time
+    apiece (3.6 ms per reference-shaped call, measured with tools/profile_python_overhead.py) - more than the device
+    needs for the whole forward at B=1.  Pass a ``TableUpload`` instead of a device to ``RowTiles`` / ``Segments``;
+    ``flush()`` concatenates everything (16-byte aligned pieces), does one host-to-device copy and hands every owner
+    a view of the device buffer."""
+
+    def __init__(self, device):
+        self.device = device
+        self.items = []
+
+    def add(self, obj, attr, arr):
+        self.items.append((obj, attr, np.ascontiguousarray(arr, dtype=np.int32).reshape(-1)))
+
+    def flush(self):
+        if not self.items:
+            return
+        offs, total = [], 0
+        for _, _, a in self.items:
+            offs.append(total)
+            total += (a.size + 3) // 4 * 4
+        buf = np.zeros(max(total, 4), np.int32)
+        for o, (_, _, a) in zip(offs, self.items):
+            buf[o:o + a.size] = a
+        dev = torch.from_numpy(buf).to(self.device)
+        for o, (obj, attr, a) in zip(offs, self.items):
+            setattr(obj, attr, dev[o:o + a.size])
+        self.items = []
+
+
+def _put(obj, device, **tables):
+    """device tensors for the named int32 tables: immediately, or through a TableUpload"""
+    for attr, arr in tables.items():
+        if isinstance(device, TableUpload):
+            device.add(obj, attr, arr)
+        else:
+            setattr(obj, attr, torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int32)).to(device))
+
+
 class RowTiles:
     """Tiles of <=128 rows over contiguous groups of rows.
 
@@ -65,10 +106,8 @@ class RowTiles:
         self.h_g_row0 = np.asarray(g_row0, np.int32)
         self.h_sub_tile0 = np.asarray(sub_tile0, np.int32)
         self.h_sub_ntiles = np.asarray(sub_ntiles, np.int32)
-        up = lambda a: torch.from_numpy(a).to(device)
-        self.row0, self.nrows, self.group = up(self.h_row0), up(self.h_nrows), up(self.h_group)
-        self.g_tile0, self.g_ntiles = up(self.h_g_tile0), up(self.h_g_ntiles)
-        self.g_count, self.g_row0 = up(self.h_g_count), up(self.h_g_row0)
+        _put(self, device, row0=self.h_row0, nrows=self.h_nrows, group=self.h_group, g_tile0=self.h_g_tile0,
+             g_ntiles=self.h_g_ntiles, g_count=self.h_g_count, g_row0=self.h_g_row0)
 
 
 class HalfTiles:
@@ -79,19 +118,19 @@ class HalfTiles:
         self.h_nrows = np.stack([np.minimum(n, 64), np.clip(n - 64, 0, 64)], 1).reshape(-1).astype(np.int32)
         self.T, self.G, self.R, self.ragged = 2 * tiles.T, tiles.G, tiles.R, True
         self.h_g_tile0, self.h_g_ntiles, self.h_g_count = 2 * tiles.h_g_tile0, 2 * tiles.h_g_ntiles, tiles.h_g_count
-        up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
-        self.nrows, self.g_tile0, self.g_ntiles, self.g_count = up(self.h_nrows), up(self.h_g_tile0), up(self.h_g_ntiles), tiles.g_count
+        _put(self, device, nrows=self.h_nrows, g_tile0=self.h_g_tile0, g_ntiles=self.h_g_ntiles, g_count=self.h_g_count)
 
 
 class Segments:
     def __init__(self, start, count, stride, group, device, div=None):
-        up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
         self.h_div = None if div is None else np.asarray(div, np.int64)
-        self.div = None if div is None else up(div)  # divisor per segment (default: its row count)
+        self.div = None  # divisor per segment (default: its row count)
         self.n = len(start)
         self.h_start, self.h_count = np.asarray(start, np.int64), np.asarray(count, np.int64)
         self.h_stride, self.h_group = np.asarray(stride, np.int64), np.asarray(group, np.int64)
-        self.start, self.count, self.stride, self.group = up(start), up(count), up(stride), up(group)
+        _put(self, device, start=self.h_start, count=self.h_count, stride=self.h_stride, group=self.h_group)
+        if div is not None:
+            _put(self, device, div=self.h_div)
 
 
 class BatchPlan:
@@ -102,6 +141,7 @@ class BatchPlan:
 
     def __init__(self, samples, crop_hw, device, rows=(0, 1, 2), use_points=True, use_images=True):
         self.device = device
+        device = up_all = TableUpload(device)  # every table below goes to the device in one copy (flush at the end)
         self.rows = tuple(rows)
         self.nR = nR = len(self.rows)
         self.S = int(crop_hw)
@@ -118,7 +158,13 @@ class BatchPlan:
         self.L = L
         self.det_off = np.concatenate([[0], np.cumsum(L)]).astype(np.int64)
         self.Lt = Lt = int(self.det_off[-1])
-        up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
+        self._tbl = {}
+
+        def up(a, name=None):  # named int32 table of the plan itself -> attribute set by the flush
+            name = name or '_t%d' % len(self._tbl)
+            self._tbl[name] = True
+            up_all.add(self, name, a)
+            return name
 
         # ---- point space -------------------------------------------------
         self.use_points = use_points
@@ -143,7 +189,7 @@ class BatchPlan:
             self.P_b = P_b
             self.pt_tiles = RowTiles(P_b, device)
             cnts = np.diff(self.pt_split)
-            self.row_det = up(np.repeat(np.arange(Lt, dtype=np.int64), cnts))
+            up(np.repeat(np.arange(Lt, dtype=np.int64), cnts), 'row_det')
             det_sample = np.repeat(np.arange(self.B), L)
             self.det_segs = Segments(self.pt_split[:-1], cnts, np.ones(Lt), det_sample, device)
             # detection-aligned point tiles + "tiles of one detection" segments (fused PointNet epilogues:
@@ -160,7 +206,7 @@ class BatchPlan:
             self.det_half_segs = Segments(2 * self.ptd_tiles.h_sub_tile0, 2 * self.ptd_tiles.h_sub_ntiles,
                                           np.ones(Lt), det_sample, device, div=cnts)
             # tile t belongs to detection tile_det[t]
-            self.tile_det = up(np.repeat(np.arange(Lt, dtype=np.int64), self.ptd_tiles.h_sub_ntiles))
+            up(np.repeat(np.arange(Lt, dtype=np.int64), self.ptd_tiles.h_sub_ntiles), 'tile_det')
 
         # ---- detection spaces -------------------------------------------
         self.det_tiles = RowTiles(L, device)
@@ -184,8 +230,7 @@ class BatchPlan:
         self.pair_tiles = RowTiles(g_cnt, device)
         if self.pair_tiles.R >= 2 ** 31 - TILE:
             raise ValueError('too many detection pairs for int32 row indices')
-        self.pg_N, self.pg_M = up(g_N), up(g_M)
-        self.pg_aoff, self.pg_boff = up(g_aoff), up(g_boff)
+        up(g_N, 'pg_N'); up(g_M, 'pg_M'); up(g_aoff, 'pg_aoff'); up(g_boff, 'pg_boff')
         self.h_pg_N, self.h_pg_M = np.asarray(g_N), np.asarray(g_M)
         self.h_pg_aoff, self.h_pg_boff = np.asarray(g_aoff), np.asarray(g_boff)
         self.max_nm = int(max(n + m for n, m in zip(g_N, g_M)))
@@ -209,11 +254,20 @@ class BatchPlan:
                     omap.append(1 * nR * Lt + ri * Lt + a0 + i)
         self.v_tiles = RowTiles(v_cnt, device)
         self.v_segs = Segments(s_start, s_count, s_stride, s_group, device)
-        self.v_omap = up(omap)
+        up(omap, 'v_omap')
+        # global-average-pool segments of the four VGG stages (S/4 .. S/32 maps): built now, with everything else
+        if use_images and self.S >= 32:
+            for sh in (4, 8, 16, 32):
+                self._crop_segments((self.S // sh) ** 2, device)
+        up_all.flush()
+
+    def _crop_segments(self, hw, device):
+        Lt = self.Lt
+        self.crop_segs[hw] = Segments(np.arange(Lt) * hw, np.full(Lt, hw), np.ones(Lt), np.zeros(Lt), device)
+        return self.crop_segs[hw]
 
     def crop_segments(self, hw):
         """Segments 'all pixels of one crop' for the global average pool."""
         if hw not in self.crop_segs:
-            Lt = self.Lt
-            self.crop_segs[hw] = Segments(np.arange(Lt) * hw, np.full(Lt, hw), np.ones(Lt), np.zeros(Lt), self.device)
+            self._crop_segments(hw, self.device)
         return self.crop_segs[hw]
