@@ -303,10 +303,11 @@ int mmmot_rowdot(const float* X, int ldx, int K, const float* w, float b,
 int mmmot_row_layernorm(const float* X, int ldx, int C, const float* gamma, const float* beta,
                         float eps, int relu, float* Y, int ldy, int R, void* stream);
 
-/* PointNet first shared-MLP layer with the 3x3 STN transform folded into the
- * weights (point_net.py:119-125): Y[p][0..63] = W[64][3] x[p] + b, plus
- * per-tile statistics like mmmot_gemm_rows. */
-int mmmot_pointnet_layer1(const float* X, const float* W, const float* bias,
+/* PointNet first shared-MLP layer with the K x K STN transform folded into the
+ * weights (point_net.py:119-125): Y[p][0..63] = W[64][K] x[p] + b, plus
+ * per-tile statistics like mmmot_gemm_rows.  K = 3 (xyz; every shipped config sets without_reflectivity) or 4
+ * (xyz + reflectivity, tracking_net.py:41); X is [P][K] as delivered in det_info['points']. */
+int mmmot_pointnet_layer1(const float* X, int K, const float* W, const float* bias,
                           float* Y, float* part,
                           const int* tile_row0, const int* tile_nrows, int T, void* stream);
 

@@ -339,25 +339,35 @@ extern "C" int mmmot_row_layernorm(const float* X, int ldx, int C, const float* 
 }
 
 // ---------------------------------------------------------------------------
-// PointNet first shared-MLP layer (K = 3): VALU, output-write bound.
+// PointNet first shared-MLP layer (K = 3 xyz, or 4 with the reflectivity channel): VALU, output-write bound.
+template <int K>
 __global__ __launch_bounds__(256) void pointnet_layer1_kernel(
     const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
     float* __restrict__ Y, float* __restrict__ part, const int* __restrict__ tile_row0,
     const int* __restrict__ tile_nrows) {
-  __shared__ float xs[MM_BM * 3];
+  __shared__ float xs[MM_BM * K];
   __shared__ float red[4][2][64];
   const int t = blockIdx.x;
   const int row0 = tile_row0[t], nrows = tile_nrows[t];
   const int tid = threadIdx.x;
-  for (int idx = tid; idx < nrows * 3; idx += 256) xs[idx] = X[(long)row0 * 3 + idx];
+  for (int idx = tid; idx < nrows * K; idx += 256) xs[idx] = X[(long)row0 * K + idx];
   __syncthreads();
   const int c = tid & 63, rq = tid >> 6;
-  const float w0 = W[c * 3 + 0], w1 = W[c * 3 + 1], w2 = W[c * 3 + 2], bv = bias[c];
+  float w[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) w[k] = W[c * K + k];
+  const float bv = bias[c];
+  auto val = [&](int r) {
+    float y = bv;
+#pragma unroll
+    for (int k = 0; k < K; ++k) y = fmaf(w[k], xs[r * K + k], y);  // same order as the K = 3 kernel of round 1
+    return y;
+  };
   float s1 = 0.f;
   for (int i = 0; i < 32; ++i) {
     const int r = rq * 32 + i;
     if (r < nrows) {
-      const float y = fmaf(w2, xs[r * 3 + 2], fmaf(w1, xs[r * 3 + 1], fmaf(w0, xs[r * 3 + 0], bv)));
+      const float y = val(r);
       Y[(long)(row0 + r) * 64 + c] = y;
       s1 += y;
     }
@@ -371,8 +381,7 @@ __global__ __launch_bounds__(256) void pointnet_layer1_kernel(
   for (int i = 0; i < 32; ++i) {
     const int r = rq * 32 + i;
     if (r < nrows) {
-      const float y = fmaf(w2, xs[r * 3 + 2], fmaf(w1, xs[r * 3 + 1], fmaf(w0, xs[r * 3 + 0], bv)));
-      const float d = y - mu;
+      const float d = val(r) - mu;
       s2 += d * d;
     }
   }
@@ -384,11 +393,15 @@ __global__ __launch_bounds__(256) void pointnet_layer1_kernel(
   }
 }
 
-extern "C" int mmmot_pointnet_layer1(const float* X, const float* W, const float* bias, float* Y, float* part,
+extern "C" int mmmot_pointnet_layer1(const float* X, int K, const float* W, const float* bias, float* Y, float* part,
                                      const int* tile_row0, const int* tile_nrows, int T, void* stream) {
-  if (!X || !W || !bias || !Y || !part || !tile_row0 || !tile_nrows || T <= 0) return MMMOT_EINVAL;
-  hipLaunchKernelGGL(pointnet_layer1_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream, X, W, bias, Y, part,
-                     tile_row0, tile_nrows);
+  if (!X || !W || !bias || !Y || !part || !tile_row0 || !tile_nrows || T <= 0 || (K != 3 && K != 4)) return MMMOT_EINVAL;
+  if (K == 3)
+    hipLaunchKernelGGL(pointnet_layer1_kernel<3>, dim3(T), dim3(256), 0, (hipStream_t)stream, X, W, bias, Y, part,
+                       tile_row0, tile_nrows);
+  else
+    hipLaunchKernelGGL(pointnet_layer1_kernel<4>, dim3(T), dim3(256), 0, (hipStream_t)stream, X, W, bias, Y, part,
+                       tile_row0, tile_nrows);
   return mm_check(hipGetLastError());
 }
 

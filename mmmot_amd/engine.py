@@ -458,8 +458,9 @@ class Engine:
                 raise ValueError('crops must be a contiguous [%d,3,%d,%d] tensor' % (Lt, plan.S, plan.S))
             self._guarded_appearance(plan, crops, cat)
         if need_pts:
-            if points is None or tuple(points.shape) != (plan.P, 3) or not points.is_contiguous():
-                raise ValueError('points must be a contiguous [%d,3] tensor' % plan.P)
+            kin = int(self.P['pointnet']['w1'].shape[1])  # 3 (xyz) or 4 (xyz + reflectivity)
+            if points is None or tuple(points.shape) != (plan.P, kin) or not points.is_contiguous():
+                raise ValueError('points must be a contiguous [%d,%d] tensor' % (plan.P, kin))
             self.pointnet(plan, points, cat)
         F = self.buf('F', plan.nR, Lt, 512)
         if rows == (0, 1, 2):

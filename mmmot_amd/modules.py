@@ -118,8 +118,9 @@ class PointNet_v1(nn.Module):
 
     def __init__(self, in_channels, out_channels=512, use_dropout=False):
         super().__init__()
-        if in_channels != 3 or out_channels != 512:
-            raise NotImplementedError('HIP path builds PointNet_v1(3 -> 512) (without_reflectivity=True, point_len=512)')
+        if in_channels not in (3, 4) or out_channels != 512:
+            raise NotImplementedError('HIP path builds PointNet_v1(3 | 4 -> 512) (point_len=512)')
+        self.in_channels = in_channels
         self.out_channels = out_channels
         self.feat = PointNetfeatGN(in_channels, out_channels)
         self.conv1 = nn.Conv1d(1088, 512, 1)
@@ -442,7 +443,8 @@ class TrackingNet(nn.Module):
         if need_pts:
             ps_t = det_info['points_split'].reshape(-1)
             ps = ps_t.detach().to('cpu').numpy().astype(np.int64)  # one D2H copy (reference: 2 .item() per detection)
-            points = det_info['points'].reshape(-1, 3).contiguous()
+            points = det_info['points']
+            points = points.reshape(-1, points.shape[-1]).contiguous()  # [P][3] or [P][4] (with reflectivity)
         S = int(dets.shape[-1]) if dets is not None else 0
         dev = points.device if points is not None else dets.device
         key = (tuple(fc), None if ps is None else ps.tobytes(), S, rows, str(dev))

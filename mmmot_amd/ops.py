@@ -230,7 +230,8 @@ class HipOps:
         _lib.check(st, 'mmmot_row_layernorm')
 
     def pointnet_layer1(self, X, W, bias, Y, part, tiles):
-        st = self.lib.mmmot_pointnet_layer1(_ptr(X), _ptr(W), _ptr(bias), _ptr(Y), _ptr(part),
+        """X [P][K] with K = W.shape[1] in (3, 4)."""
+        st = self.lib.mmmot_pointnet_layer1(_ptr(X), int(W.shape[1]), _ptr(W), _ptr(bias), _ptr(Y), _ptr(part),
                                             _iptr(tiles.row0), _iptr(tiles.nrows), tiles.T, self._stream())
         _lib.check(st, 'mmmot_pointnet_layer1')
 

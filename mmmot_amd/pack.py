@@ -211,11 +211,12 @@ def pack_weights(sd, fusion, device, eps=1e-5):
     # ---- PointNet ----------------------------------------------------------
     if 'point_net.feat.conv1.weight' in sd:
         q = 'point_net.feat.'
-        T1 = stn_transform(sd, q + 'stn1.', 3)
+        kin = int(sd[q + 'conv1.weight'].shape[1])  # 3 (xyz) or 4 (xyz + reflectivity, tracking_net.py:41)
+        T1 = stn_transform(sd, q + 'stn1.', kin)
         T2 = stn_transform(sd, q + 'stn2.', 64)
         cw = lambda name: _d(sd[name]).flatten(1)
         pn = dict(trans1=f32(T1), trans2=f32(T2))
-        pn['w1'] = f32(cw(q + 'conv1.weight') @ T1.t())          # [64][3]
+        pn['w1'] = f32(cw(q + 'conv1.weight') @ T1.t())          # [64][3 | 4]
         pn['b1'] = f32(_d(sd[q + 'conv1.bias']))
         pn['w2'] = f32(cw(q + 'conv2.weight') @ T2.t())          # [64][64] acts on relu(gn1(.))
         pn['b2'] = f32(_d(sd[q + 'conv2.bias']))

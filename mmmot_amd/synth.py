@@ -10,9 +10,10 @@ import numpy as np
 import torch
 
 
-def make_pair(N, M, S, pts_per_det, seed, ragged=False):
+def make_pair(N, M, S, pts_per_det, seed, ragged=False, reflectivity=False):
     """One synthetic frame pair.  ``ragged`` draws per-detection point counts
-    from a geometric law clipped to [1, 4*pts]; otherwise fixed."""
+    from a geometric law clipped to [1, 4*pts]; otherwise fixed.  ``reflectivity`` appends the 4th LiDAR
+    channel (drawn after everything else, so the xyz / crops of a seed do not depend on it)."""
     g = np.random.Generator(np.random.Philox(key=[0x5eed, int(seed)]))
     L = N + M
     # every detection gets its own appearance (contrast, colour cast, a smooth pattern) on top of
@@ -43,6 +44,8 @@ def make_pair(N, M, S, pts_per_det, seed, ragged=False):
     sig = np.array([1.6, 0.7, 0.6], dtype=np.float32)
     pts = g.standard_normal((P, 3), dtype=np.float32) * sig
     pts += np.repeat(centres, cnt, axis=0)
+    if reflectivity:  # 4th LiDAR channel in [0, 1] (without_reflectivity=False, point_cloud/preprocess.py:96-99)
+        pts = np.concatenate([pts, g.uniform(0.0, 1.0, (P, 1)).astype(np.float32)], axis=1)
     dets = torch.from_numpy(crops)
     det_info = {
         'points': torch.from_numpy(pts).unsqueeze(0),

@@ -62,9 +62,9 @@ def import_reference():
     return ref_modules
 
 
-def build_reference(ref_modules, fusion, affinity_op, softmax_mode, seq_len=2, end_mode='avg'):
+def build_reference(ref_modules, fusion, affinity_op, softmax_mode, seq_len=2, end_mode='avg', refl=False):
     kw = dict(BASE, score_fusion_arch=fusion, affinity_op=affinity_op, softmax_mode=softmax_mode, seq_len=seq_len,
-              end_mode=end_mode)
+              end_mode=end_mode, without_reflectivity=not refl)
     with contextlib.redirect_stdout(io.StringIO()):
         m = ref_modules.TrackingNet(**kw)
     sd = generate_state_dict(m.state_dict(), seed=0)
@@ -102,6 +102,11 @@ CASES.append(dict(name='s6_endmax_C', fusion='C', aff='multiply', sm='none', N=9
                   seed=1008, end_mode='max'))
 CASES.append(dict(name='s6_endmax_A', fusion='A', aff='minus_abs', sm='dual_add', N=4, M=11, S=32, pts=30, ragged=True,
                   seed=1009, end_mode='max'))
+# 4-channel LiDAR input (without_reflectivity=False, tracking_net.py:41: PointNet_v1(4), 4 x 4 STN; no shipped config)
+CASES.append(dict(name='s7_refl_B', fusion='B', aff='multiply', sm='none', N=6, M=4, S=32, pts=50, ragged=True,
+                  seed=1010, refl=True))
+CASES.append(dict(name='s7_refl_C', fusion='C', aff='minus_abs', sm='dual_add', N=3, M=8, S=32, pts=50, ragged=True,
+                  seed=1011, refl=True))
 # full-size cases: outputs only ('full': True)
 CASES.append(dict(name='f_cfg3_C', fusion='C', aff='multiply', sm='none', N=64, M=64, S=128, pts=2048,
                   ragged=False, seed=1000, full=True))
@@ -149,14 +154,16 @@ def main():
             if c['name'] in old:
                 manifest.append(old[c['name']])
             continue
-        key = (c['fusion'], c['aff'], c['sm'], len(c.get('counts', [0, 0])), c.get('end_mode', 'avg'))
+        key = (c['fusion'], c['aff'], c['sm'], len(c.get('counts', [0, 0])), c.get('end_mode', 'avg'), bool(c.get('refl')))
         if key not in models:
-            models[key] = build_reference(ref_modules, c['fusion'], c['aff'], c['sm'], seq_len=key[3], end_mode=key[4])
+            models[key] = build_reference(ref_modules, c['fusion'], c['aff'], c['sm'], seq_len=key[3], end_mode=key[4],
+                                          refl=key[5])
         model, sd = models[key]
         if 'counts' in c:
             dets, info, dsplit = make_multiframe(c['counts'], c['S'], c['pts'], c['seed'])
         else:
-            dets, info, dsplit = make_pair(c['N'], c['M'], c['S'], c['pts'], c['seed'], c['ragged'])
+            dets, info, dsplit = make_pair(c['N'], c['M'], c['S'], c['pts'], c['seed'], c['ragged'],
+                                           reflectivity=bool(c.get('refl')))
         t0 = time.time()
         with torch.no_grad():
             det, links, new, end, trans = model(dets, info, dsplit)

@@ -94,7 +94,7 @@ def _segment_avg(x, split):
 def pointnet(points, split, sd, keep=None):
     """reference modules/point_net.py:25-44 + 115-153.  points 1 x 3 x P, split (L+1,) -> L x 512, trans."""
     q = 'point_net.feat.'
-    t1 = stn_transform(sd, q + 'stn1.', 3)
+    t1 = stn_transform(sd, q + 'stn1.', points.shape[1])  # 3 x 3, or 4 x 4 with the reflectivity channel
     x = torch.bmm(points.transpose(2, 1), t1).transpose(2, 1)                       # :119-123
     x = F.relu(_gn(F.conv1d(x, sd[q + 'conv1.weight'], sd[q + 'conv1.bias']), sd, q + 'bn1', 64))  # :125
     t2 = stn_transform(sd, q + 'stn2.', 64)

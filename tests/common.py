@@ -41,12 +41,14 @@ def case_inputs(c):
     if 'counts' in c:
         dets, info, _ = make_pair(c['counts'][0], sum(c['counts'][1:]), c['S'], c['pts'], c['seed'], ragged=True)
         return dets, info, [torch.tensor([x]) for x in c['counts']]
-    return make_pair(c['N'], c['M'], c['S'], c['pts'], c['seed'], c['ragged'])
+    return make_pair(c['N'], c['M'], c['S'], c['pts'], c['seed'], c['ragged'], reflectivity=bool(c.get('refl')))
 
 
 def case_kwargs(c, base):
     kw = dict(base, score_fusion_arch=c['fusion'], affinity_op=c['aff'], softmax_mode=c['sm'],
               end_mode=c.get('end_mode', base.get('end_mode', 'avg')))
+    if c.get('refl'):
+        kw['without_reflectivity'] = False
     if 'counts' in c:
         kw['seq_len'] = len(c['counts'])
     return kw

@@ -237,13 +237,14 @@ def test_row_layernorm(hip, C):
     close(Yg, Y, 3e-6, 'row_layernorm')
 
 
-def test_pointnet_layer1(hip):
+@pytest.mark.parametrize('K', [3, 4])
+def test_pointnet_layer1(hip, K):
     emu = TorchOps()
     counts = [1000, 3, 129]
     tl = DevTiles(counts)
     R = sum(counts)
-    X = rnd(R, 3, seed=80) * 10 + torch.tensor([30.0, -5.0, -1.0])
-    W, b = rnd(64, 3, seed=81), rnd(64, seed=82)
+    X = rnd(R, K, seed=80) * 10 + torch.tensor([30.0, -5.0, -1.0, 0.5][:K])
+    W, b = rnd(64, K, seed=81), rnd(64, seed=82)
     Y, part = torch.zeros(R, 64), torch.zeros(tl.cpu.T, 2, 64)
     emu.pointnet_layer1(X, W, b, Y, part, tl.cpu)
     Yg, pg = torch.zeros(R, 64).cuda(), torch.zeros(tl.cpu.T, 2, 64).cuda()

@@ -14,7 +14,7 @@ _SD = {}
 
 
 def state_dict_for(c, base):
-    key = (c['fusion'], len(c.get('counts', [0, 0])))
+    key = (c['fusion'], len(c.get('counts', [0, 0])), bool(c.get('refl')))
     if key not in _SD:
         spec = TrackingNet(**case_kwargs(c, base)).state_dict()
         _SD[key] = generate_state_dict(spec, seed=0)
