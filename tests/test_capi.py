@@ -47,18 +47,24 @@ def test_abi_version_and_argument_checks_without_gpu():
     assert lib.mmmot_softmax_pairs(None, None, None, None, None, 1, 4, 3, None) == -1
 
 
-def test_gemm_args_struct_layout_matches_header(tmp_path):
-    """The ctypes mirror must have the C struct's size and field offsets: compile the header with gcc
+import pytest
+
+
+@pytest.mark.parametrize('cname,mirror', [('mmmot_gemm_args', 'GemmArgs'), ('mmmot_gemm_ares_args', 'GemmAresArgs'),
+                                          ('mmmot_gemm_tn_args', 'GemmTnArgs')])
+def test_args_struct_layouts_match_header(tmp_path, cname, mirror):
+    """The ctypes mirrors must have the C structs' sizes and field offsets: compile the header with gcc
     (which also proves include/mmmot_hip.h is plain C) and compare."""
     import subprocess
-    fields = [f[0] for f in _lib.GemmArgs._fields_]
+    cls = getattr(_lib, mirror)
+    fields = [f[0] for f in cls._fields_]
     src = tmp_path / 'layout.c'
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mmmot_hip.h"\nint main(void){\n'
-                   'printf("%zu\\n", sizeof(mmmot_gemm_args));\n' +
-                   ''.join('printf("%%zu\\n", offsetof(mmmot_gemm_args, %s));\n' % f for f in fields) +
+                   'printf("%%zu\\n", sizeof(%s));\n' % cname +
+                   ''.join('printf("%%zu\\n", offsetof(%s, %s));\n' % (cname, f) for f in fields) +
                    'return 0;}\n')
     exe = tmp_path / 'layout'
     subprocess.check_call(['gcc', '-std=c99', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
     nums = [int(x) for x in subprocess.check_output([str(exe)]).split()]
-    assert nums[0] == ctypes.sizeof(_lib.GemmArgs)
-    assert nums[1:] == [getattr(_lib.GemmArgs, f).offset for f in fields]
+    assert nums[0] == ctypes.sizeof(cls)
+    assert nums[1:] == [getattr(cls, f).offset for f in fields]

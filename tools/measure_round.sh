@@ -21,4 +21,7 @@ done
 timeout 200 python $R/bench.py --workload cfg4 --pairs 8 --cpu-pairs 0 --no-latency > $O/bench_cfg4_pairs8.log 2>&1
 timeout 200 python $R/bench.py --workload cfg2 --pairs 16 --cpu-pairs 0 --no-latency > $O/bench_cfg2_pairs16.log 2>&1
 cd $R
-tail -c 1200 $O/bench_default.log; head -12 $O/rocprofv3_kernel_stats_cfg3_pairs8_f16x3.txt
+# the tree compiles from clean on the box (no prebuilt objects reused), then the smoke check runs on that build
+( MMMOT_FORCE_BUILD=1 timeout 900 python -c "import time, __graft_entry__ as g; t = time.time(); print(g.build()); print('forced rebuild of every HIP source: %.0f s' % (time.time() - t)); g.smoke()" ) > $O/smoke_forced_build.log 2>&1
+timeout 300 python tools/bench_backward.py > $O/bench_backward.log 2>&1
+tail -c 1200 $O/bench_default.log; head -12 $O/rocprofv3_kernel_stats_cfg3_pairs8_f16x3.txt; tail -4 $O/smoke_forced_build.log
