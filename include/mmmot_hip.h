@@ -72,7 +72,8 @@ extern "C" {
  * 4 = per-output-channel weight scales (oscale is a [Cout] vector in the hl16 / hq8 trunk entry points),
  * mmmot_trunk_range_read, the tile / LDS-DMA trunk kernels and their knobs removed, timing experiments only in
  * -DMMMOT_DEBUG builds; 5 = training backward of the pairwise block (mmmot_gn_bwd_*, mmmot_gemm_tn,
- * mmmot_pair_bwd, mmmot_pair_expand_bwd, mmmot_rowdot_bwd, mmmot_softmax_pairs_bwd). */
+ * mmmot_pair_bwd, mmmot_pair_expand_bwd, mmmot_rowdot_bwd, mmmot_softmax_pairs_bwd, mmmot_fusion_c_bwd, mmmot_add_rows),
+ * mmmot_pointnet_layer1 takes K = 3 | 4. */
 int mmmot_abi_version(void);
 /* returns 0 and fills cu_count / gcn arch string (<=32 bytes) of device 0..; */
 int mmmot_device_info(int device, int* cu_count, char* arch, int arch_len);
@@ -447,6 +448,16 @@ int mmmot_rowdot_bwd(const float* X, int ldx, int K, const float* w, float b, co
 /* backward of mmmot_softmax_pairs: dlogits from dout, the row / column softmaxes are recomputed from the logits */
 int mmmot_softmax_pairs_bwd(const float* logits, const float* dout, float* dlogits, const int* grp_row0,
                             const int* grp_N, const int* grp_M, int G, int max_nm, int mode, void* stream);
+
+/* backward of the fusion module C combine (fusion_net.py:31-42; Y_j = [gate_j | input_j] rows as in the forward):
+ * DY_j[:, 0:C] = dL/d gate pre-activation, DN_j = dL/d normalised input (goes through mmmot_gn_bwd_* with relu = 0
+ * into DY_j[:, C:2C]).  Modes A / B need no kernel (dn = dfused). */
+int mmmot_fusion_c_bwd(const float* dFu, const float* Y0, int ld0, const float* Y1, int ld1, const float* sc0,
+                       const float* sh0, const float* sc1, const float* sh1, int ldsc, const int* tile_row0,
+                       const int* tile_nrows, const int* tile_group, int T, float* DY0, float* DY1, int lddy,
+                       float* DN0, float* DN1, int C, void* stream);
+/* Y[r][c] = A[r][c] + B[r][c] (two gradient paths into one feature); C % 4 == 0 */
+int mmmot_add_rows(const float* A, int lda, const float* B, int ldb, float* Y, int ldy, long R, int C, void* stream);
 
 /* MFMA fragment-layout self test: C[32][32] = A[32][K] * B[32][K]^T through
  * the same fragment mapping the GEMM kernels use (K % 8 == 0). */

@@ -122,6 +122,8 @@ SIGNATURES = {
     'mmmot_rowdot_bwd': [c_f, c_i, c_i, c_f, ctypes.c_float, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_i,
                          c_f, c_i, c_f],
     'mmmot_softmax_pairs_bwd': [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f],
+    'mmmot_fusion_c_bwd': [c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_f, c_f, c_i, c_f, c_f, c_i, c_f],
+    'mmmot_add_rows': [c_f, c_i, c_f, c_i, c_f, c_i, ctypes.c_long, c_i, c_f],
 }
 
 

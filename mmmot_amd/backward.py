@@ -159,11 +159,12 @@ def _colsum(eng, X):
     return out[0]
 
 
-def _gn_backward(eng, plan, L, dA, out=None):
-    """dA = gradient w.r.t. relu(GroupNorm(Y)) -> (dY, dgamma [C], dbeta [C]).  ``out``: view to write dY into."""
+def _gn_backward(eng, plan, L, dA, out=None, relu=True):
+    """dA = gradient w.r.t. relu(GroupNorm(Y)) (or GroupNorm(Y) when ``relu`` is False) -> (dY, dgamma [C],
+    dbeta [C]).  ``out``: view to write dY into."""
     ops, tiles, C, dev = eng.ops, L.tiles, L.C, dA.device
     P = torch.empty(tiles.T, 2, C, dtype=torch.float32, device=dev)
-    ops.gn_bwd_partial(dA, L.Y, C, L.sc1, L.sh1, L.gamma, L.beta, True, tiles, P)
+    ops.gn_bwd_partial(dA, L.Y, C, L.sc1, L.sh1, L.gamma, L.beta, relu, tiles, P)
     seg_g, seg_t = _aux(plan).tile_sums(tiles, dev)
     S = torch.empty(tiles.G * 2, C, dtype=torch.float32, device=dev)
     tot = torch.empty(2, C, dtype=torch.float32, device=dev)
@@ -173,7 +174,7 @@ def _gn_backward(eng, plan, L, dA, out=None):
     M = torch.empty(tiles.G, 2, C, dtype=torch.float32, device=dev)
     ops.gn_bwd_finalize(S, tiles, C, L.NG, L.gamma, M)
     dY = out if out is not None else torch.empty(tiles.R, C, dtype=torch.float32, device=dev)
-    ops.gn_bwd_apply(dA, L.Y, C, L.sc1, L.sh1, L.gamma, L.beta, True, M, tiles, dY)
+    ops.gn_bwd_apply(dA, L.Y, C, L.sc1, L.sh1, L.gamma, L.beta, relu, M, tiles, dY)
     return dY, tot[1], tot[0]
 
 
@@ -251,6 +252,236 @@ def affinity_backward(eng, plan, F, t, d_link, d_new, d_end):
     for name, key in PARAM_KEYS.items():
         out[key] = g[name]
     return dF.view(nR, Lt, 512), out
+
+
+# ======================================================================================================================
+# Second slice: the rest of the head - fusion module A / B / C and the negative-rejection head w_det in TRAINING mode
+# (reference modules/fusion_net.py:31-42,62-70,85-92; tracking_net.py:91-100,149-163 with self.training: BatchNorm1d on
+# batch statistics over the 3 modality rows x L detections, no sigmoid, no neg_threshold mask).  Together with the
+# pairwise block this is everything between the encoder features `cat` [Lt][1024] and the four score tensors.
+# ======================================================================================================================
+def _t2(p):
+    """conv weight [N, K, 1(, 1)] -> [N][K] fp32 view on the parameter's device"""
+    return p.detach().reshape(p.shape[0], -1).contiguous()
+
+
+def fusion_forward_train(eng, plan, cat):
+    """Engine.fuse with the tape: cat [Lt][1024] -> F [3][Lt][512] (GroupNorm only: identical to eval)."""
+    ops, fu, D, Lt = eng.ops, eng.P['fusion'], plan.det_tiles, plan.Lt
+    dev = cat.device
+    new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    F = new(3, Lt, 512)
+    from .ops import FUSION_MODES
+    mode = FUSION_MODES[eng.fusion]
+    t = dict(mode=eng.fusion)
+    if eng.fusion == 'A':
+        y0, part = new(Lt, 512), new(D.T, 2, 512)
+        eng._gemm(fu, 'w0', D, 512, 1024, X=cat, bias=fu['b0'], Y=y0, part=part)
+        L0 = _norm_layer(eng, part, D, y0, 512, 512, fu['g0'], fu['be0'])
+        ops.fusion_combine(mode, cat, y0, None, L0.sc, L0.sh, None, None, D, F, Lt, 512)
+        t['L'] = [L0]
+        return F, t
+    N = 512 if eng.fusion == 'B' else 1024
+    Ls, ys = [], []
+    for j, x in enumerate((cat[:, 0:512], cat[:, 512:1024])):
+        y, part = new(Lt, N), new(D.T, 2, N)
+        eng._gemm(fu, 'w%d' % j, D, N, 512, X=x, bias=fu['b%d' % j], Y=y, part=part)
+        # the GroupNorm acts on the `input` half only (fusion C: columns 512.. of the stacked [gate ; input] layer)
+        Ls.append(_norm_layer(eng, part[:, :, N - 512:], D, y[:, N - 512:], 512, 512, fu['g%d' % j][N - 512:],
+                              fu['be%d' % j][N - 512:]))
+        ys.append(y)
+    ops.fusion_combine(mode, cat, ys[0], ys[1], Ls[0].sc, Ls[0].sh, Ls[1].sc, Ls[1].sh, D, F, Lt, 512)
+    t['L'], t['ys'] = Ls, ys
+    return F, t
+
+
+def fusion_backward(eng, plan, cat, t, dF):
+    """dF [3][Lt][512] -> (dcat [Lt][1024], {fusion_module.* key: grad})."""
+    ops, fu, D, Lt = eng.ops, eng.P['fusion'], plan.det_tiles, plan.Lt
+    dev = cat.device
+    new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    fm = 'fusion_module.'
+    out = {}
+    dcat = new(Lt, 1024)
+
+    def wgrad(dY, N, K, X):
+        dW, db = new(1, N * K), new(1, N)
+        ops.gemm_tn(dY, D, N, K, dW, db, X=X, amode=A_PLAIN)
+        return dW.view(N, K), db.view(N)
+
+    if t['mode'] == 'A':
+        L0 = t['L'][0]
+        dy0, out[fm + 'input_w.1.weight'], out[fm + 'input_w.1.bias'] = _gn_backward(eng, plan, L0, dF[2], relu=False)
+        out[fm + 'input_w.0.weight'], out[fm + 'input_w.0.bias'] = wgrad(dy0, 512, 1024, cat)
+        dconv = new(Lt, 1024)
+        ops.gemm(fu['w0'].t().contiguous(), D, 1024, 512, X=dy0, Y=dconv)
+        ops.add_rows(dconv[:, 0:512], dF[0], dcat[:, 0:512], 512)
+        ops.add_rows(dconv[:, 512:1024], dF[1], dcat[:, 512:1024], 512)
+        return dcat, out
+    names = (('gate_p', 'input_p'), ('gate_i', 'input_i'))  # *_p acts on the IMAGE half (naming trap, SURVEY a10)
+    if t['mode'] == 'B':
+        for j in range(2):
+            Lj = t['L'][j]
+            dy, out[fm + names[j][1] + '.1.weight'], out[fm + names[j][1] + '.1.bias'] = _gn_backward(
+                eng, plan, Lj, dF[2], relu=False)
+            out[fm + names[j][1] + '.0.weight'], out[fm + names[j][1] + '.0.bias'] = wgrad(
+                dy, 512, 512, cat[:, 512 * j:512 * (j + 1)])
+            dconv = new(Lt, 512)
+            ops.gemm(fu['w%d' % j].t().contiguous(), D, 512, 512, X=dy, Y=dconv)
+            ops.add_rows(dconv, dF[j], dcat[:, 512 * j:512 * (j + 1)], 512)
+        return dcat, out
+    # C: gates + normalised inputs
+    L0, L1 = t['L']
+    y0, y1 = t['ys']
+    DY = [new(Lt, 1024), new(Lt, 1024)]
+    DN = [new(Lt, 512), new(Lt, 512)]
+    ops.fusion_c_bwd(dF[2], y0, y1, L0.sc, L0.sh, L1.sc, L1.sh, D, DY[0], DY[1], DN[0], DN[1], 512)
+    for j in range(2):
+        Lj = t['L'][j]
+        _, out[fm + names[j][1] + '.1.weight'], out[fm + names[j][1] + '.1.bias'] = _gn_backward(
+            eng, plan, Lj, DN[j], out=DY[j][:, 512:1024], relu=False)
+        dW, db = wgrad(DY[j], 1024, 512, cat[:, 512 * j:512 * (j + 1)])
+        out[fm + names[j][0] + '.0.weight'], out[fm + names[j][0] + '.0.bias'] = dW[0:512], db[0:512]
+        out[fm + names[j][1] + '.0.weight'], out[fm + names[j][1] + '.0.bias'] = dW[512:1024], db[512:1024]
+        dconv = new(Lt, 512)
+        ops.gemm(fu['w%d' % j].t().contiguous(), D, 512, 1024, X=DY[j], Y=dconv)
+        ops.add_rows(dconv, dF[j], dcat[:, 512 * j:512 * (j + 1)], 512)
+    return dcat, out
+
+
+def det_forward_train(eng, model, plan, F):
+    """w_det in TRAINING mode (tracking_net.py:149-151 with self.training): conv -> BatchNorm1d on the batch statistics of
+    the 3 x L positions -> ReLU, twice, then the 1-channel conv; raw scores (no sigmoid, no threshold mask).
+    F [nR][Lt][512] -> det [nR][Lt].  One sample per call, like the reference (its batch is 1: the BatchNorm statistics
+    are those of one sample)."""
+    if plan.B != 1:
+        raise NotImplementedError('training-mode w_det: one sample per call (BatchNorm statistics are per forward)')
+    ops, T = eng.ops, plan.F_tiles
+    R = plan.nR * plan.Lt
+    dev = F.device
+    new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    wd = model.w_det
+    X = F.reshape(R, 512)
+    t = {}
+    h0, part = new(R, 512), new(T.T, 2, 512)
+    ops.gemm(_t2(wd[0].weight), T, 512, 512, X=X, bias=wd[0].bias.detach(), Y=h0, part=part)
+    t['d0'] = _norm_layer(eng, part, T, h0, 512, 512, wd[1].weight.detach(), wd[1].bias.detach())
+    h1, part = new(R, 256), new(T.T, 2, 256)
+    ops.gemm(_t2(wd[3].weight), T, 256, 512, X=h0, bias=wd[3].bias.detach(), Y=h1, part=part, sc=t['d0'].sc,
+             sh=t['d0'].sh, amode=A_NORM_RELU)
+    t['d1'] = _norm_layer(eng, part, T, h1, 256, 256, wd[4].weight.detach(), wd[4].bias.detach())
+    det = new(plan.nR, plan.Lt)
+    t['w6'], t['b6'] = wd[6].weight.detach().reshape(-1).contiguous(), float(wd[6].bias.item())
+    ops.rowdot(h1, 256, t['w6'], t['b6'], T, det.view(-1), sc=t['d1'].sc, sh=t['d1'].sh, act=ACT_NONE)
+    return det, t
+
+
+def det_batch_stats(layer, n):
+    """(mean, unbiased variance) of a training-mode BatchNorm layer from its unit statistics - what
+    ``running_mean`` / ``running_var`` are updated with (momentum update left to the caller)."""
+    rstd = layer.sc1[0]
+    mean = -layer.sh1[0] / rstd
+    var = (1.0 / (rstd * rstd) - EPS) * (n / max(n - 1, 1))
+    return mean, var
+
+
+def det_backward(eng, model, plan, F, t, d_det):
+    """d_det [nR][Lt] -> (dF [nR][Lt][512], {w_det.* key: grad})."""
+    ops, T = eng.ops, plan.F_tiles
+    R = plan.nR * plan.Lt
+    dev = F.device
+    new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    wd = model.w_det
+    X = F.reshape(R, 512)
+    out = {}
+    D0, D1 = t['d0'], t['d1']
+    dA1, PW = new(R, 256), new(T.T, 260)
+    ops.rowdot_bwd(D1.Y, 256, t['w6'], t['b6'], D1.sc, D1.sh, T, ACT_NONE, d_det.reshape(-1).contiguous(), None, dA1, PW)
+    pw = _colsum(eng, PW)
+    out['w_det.6.weight'], out['w_det.6.bias'] = pw[:256], pw[256:257]
+    dY1, out['w_det.4.weight'], out['w_det.4.bias'] = _gn_backward(eng, plan, D1, dA1)
+    dW, db = new(1, 256 * 512), new(1, 256)
+    ops.gemm_tn(dY1, T, 256, 512, dW, db, X=D0.Y, sc=D0.sc, sh=D0.sh, amode=A_NORM_RELU)
+    out['w_det.3.weight'], out['w_det.3.bias'] = dW.view(256, 512), db.view(256)
+    dA0 = new(R, 512)
+    ops.gemm(_t2(wd[3].weight).t().contiguous(), T, 512, 256, X=dY1, Y=dA0)
+    dY0, out['w_det.1.weight'], out['w_det.1.bias'] = _gn_backward(eng, plan, D0, dA0)
+    dW, db = new(1, 512 * 512), new(1, 512)
+    ops.gemm_tn(dY0, T, 512, 512, dW, db, X=X, amode=A_PLAIN)
+    out['w_det.0.weight'], out['w_det.0.bias'] = dW.view(512, 512), db.view(512)
+    dF = new(R, 512)
+    ops.gemm(_t2(wd[0].weight).t().contiguous(), T, 512, 512, X=dY0, Y=dF)
+    return dF.view(plan.nR, plan.Lt, 512), out
+
+
+def head_forward_train(eng, model, plan, cat):
+    """cat [Lt][1024] (encoder features) -> (det, link, new, end, tape): fusion -> w_det (training mode) + pairwise block"""
+    F, tf = fusion_forward_train(eng, plan, cat)
+    det, td = det_forward_train(eng, model, plan, F)
+    link, new, end, ta = affinity_forward_train(eng, plan, F)
+    return det, link, new, end, dict(F=F, fusion=tf, det=td, aff=ta)
+
+
+def head_backward(eng, model, plan, cat, tape, d_det, d_link, d_new, d_end):
+    """-> (dcat [Lt][1024], {state_dict key: grad} for fusion_module.*, w_det.*, w_link.*)"""
+    F = tape['F']
+    dF_a, grads = affinity_backward(eng, plan, F, tape['aff'], d_link, d_new, d_end)
+    dF_d, g_d = det_backward(eng, model, plan, F, tape['det'], d_det)
+    dF = torch.empty_like(dF_a)
+    eng.ops.add_rows(dF_a.view(-1, 512), dF_d.view(-1, 512), dF.view(-1, 512), 512)
+    dcat, g_f = fusion_backward(eng, plan, cat, tape['fusion'], dF)
+    grads.update(g_d)
+    grads.update(g_f)
+    return dcat, grads
+
+
+class _HeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cat, eng, model, plan, keys, *params):
+        c = cat.detach().contiguous()
+        det, link, new, end, tape = head_forward_train(eng, model, plan, c)
+        ctx.eng, ctx.model, ctx.plan, ctx.tape, ctx.keys = eng, model, plan, tape, keys
+        ctx.save_for_backward(cat)
+        ctx.shapes = [tuple(p.shape) for p in params]
+        return det, link, new, end
+
+    @staticmethod
+    def backward(ctx, d_det, d_link, d_new, d_end):
+        (cat,) = ctx.saved_tensors
+        pl = ctx.plan
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=cat.device)
+        d_det = d_det if d_det is not None else z(pl.nR, pl.Lt)
+        d_link = d_link if d_link is not None else z(pl.pair_tiles.R)
+        d_new = d_new if d_new is not None else z(pl.nR, pl.Lt)
+        d_end = d_end if d_end is not None else z(pl.nR, pl.Lt)
+        dcat, grads = head_backward(ctx.eng, ctx.model, pl, cat.detach().contiguous(), ctx.tape, d_det.contiguous(),
+                                    d_link.contiguous(), d_new.contiguous(), d_end.contiguous())
+        pg = tuple(grads[k].reshape(s) for k, s in zip(ctx.keys, ctx.shapes))
+        return (dcat, None, None, None, None) + pg
+
+
+def head_autograd(model, plan, cat, update_running_stats=True):
+    """Differentiable head of ``model`` in training mode: encoder features cat [Lt][1024] (image | LiDAR) ->
+    (det [nR, Lt] raw scores, link flat, new [nR, Lt], end [nR, Lt]); ``backward()`` fills ``cat.grad`` and the ``.grad``
+    of every fusion_module / w_det / w_link parameter.  With ``update_running_stats`` the BatchNorm buffers of w_det take
+    the momentum update PyTorch's training mode does."""
+    eng = model.engine()
+    named = [(k, p) for k, p in model.named_parameters() if k.split('.')[0] in ('fusion_module', 'w_det', 'w_link')]
+    keys = tuple(k for k, _ in named)
+    out = _HeadFn.apply(cat, eng, model, plan, keys, *[p for _, p in named])
+    if update_running_stats:
+        tape = out[0].grad_fn.tape if hasattr(out[0].grad_fn, 'tape') else None
+        if tape is not None:
+            n = plan.nR * plan.Lt
+            with torch.no_grad():
+                for idx, name in ((1, 'd0'), (4, 'd1')):
+                    bn = model.w_det[idx]
+                    mean, var = det_batch_stats(tape['det'][name], n)
+                    m = bn.momentum if bn.momentum is not None else 0.1
+                    bn.running_mean.mul_(1 - m).add_(m * mean)
+                    bn.running_var.mul_(1 - m).add_(m * var)
+                    bn.num_batches_tracked += 1
+    return out
 
 
 class _AffinityFn(torch.autograd.Function):

@@ -471,3 +471,86 @@ extern "C" int mmmot_softmax_pairs_bwd(const float* logits, const float* dout, f
                      grp_row0, grp_N, grp_M, mode);
   return mm_check(hipGetLastError());
 }
+
+// ---------------------------------------------------------------------------
+// Backward of the fusion module C combine (modules/fusion_net.py:31-42; forward: mmmot_fusion_combine mode C):
+//   fused = (a0*n0 + a1*n1) / (a0 + a1),  a_j = sigmoid(g_j),  n_j = i_j*sc_j + sh_j   (Y_j = [g_j | i_j] per row)
+// given dfu = dL/dfused:  dn_j = dfu*a_j/den,  da_j = dfu*(n_j - fused)/den,  dg_j = da_j*a_j*(1 - a_j).
+// Writes dg_j into DY_j[:, 0:C] (final: the gates have no norm) and dn_j into DN_j (to be passed through the
+// GroupNorm backward into DY_j[:, C:2C]).  Modes A / B need no kernel: dn = dfu.
+__global__ __launch_bounds__(256) void fusion_c_bwd_kernel(
+    const float* __restrict__ dFu, const float* __restrict__ Y0, int ld0, const float* __restrict__ Y1, int ld1,
+    const float* __restrict__ sc0, const float* __restrict__ sh0, const float* __restrict__ sc1,
+    const float* __restrict__ sh1, int ldsc, const int* __restrict__ tile_row0, const int* __restrict__ tile_nrows,
+    const int* __restrict__ tile_group, float* __restrict__ DY0, float* __restrict__ DY1, int lddy,
+    float* __restrict__ DN0, float* __restrict__ DN1, int C) {
+  const int t = blockIdx.x;
+  const int row0 = tile_row0[t], nrows = tile_nrows[t];
+  const int g = tile_group ? tile_group[t] : 0;
+  const int C4 = C >> 2;
+  for (int idx = threadIdx.x + 256 * blockIdx.y; idx < nrows * C4; idx += 256 * gridDim.y) {
+    const int r = idx / C4, c = (idx - r * C4) * 4;
+    const long d = row0 + r;
+    const f32x4 df = *reinterpret_cast<const f32x4*>(&dFu[d * C + c]);
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(&Y0[d * ld0 + c]);
+    const f32x4 i0 = *reinterpret_cast<const f32x4*>(&Y0[d * ld0 + C + c]);
+    const f32x4 g1 = *reinterpret_cast<const f32x4*>(&Y1[d * ld1 + c]);
+    const f32x4 i1 = *reinterpret_cast<const f32x4*>(&Y1[d * ld1 + C + c]);
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(&sc0[(long)g * ldsc + c]);
+    const f32x4 h0 = *reinterpret_cast<const f32x4*>(&sh0[(long)g * ldsc + c]);
+    const f32x4 s1 = *reinterpret_cast<const f32x4*>(&sc1[(long)g * ldsc + c]);
+    const f32x4 h1 = *reinterpret_cast<const f32x4*>(&sh1[(long)g * ldsc + c]);
+    f32x4 dg0, dg1, dn0, dn1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a0 = mm_sigmoid(g0[e]), a1 = mm_sigmoid(g1[e]);
+      const float n0 = fmaf(i0[e], s0[e], h0[e]), n1 = fmaf(i1[e], s1[e], h1[e]);
+      const float inv = 1.f / (a0 + a1);
+      const float fused = (a0 * n0 + a1 * n1) * inv;
+      const float w = df[e] * inv;
+      dn0[e] = w * a0;
+      dn1[e] = w * a1;
+      dg0[e] = w * (n0 - fused) * a0 * (1.f - a0);
+      dg1[e] = w * (n1 - fused) * a1 * (1.f - a1);
+    }
+    *reinterpret_cast<f32x4*>(&DY0[d * lddy + c]) = dg0;
+    *reinterpret_cast<f32x4*>(&DY1[d * lddy + c]) = dg1;
+    *reinterpret_cast<f32x4*>(&DN0[d * C + c]) = dn0;
+    *reinterpret_cast<f32x4*>(&DN1[d * C + c]) = dn1;
+  }
+}
+
+extern "C" int mmmot_fusion_c_bwd(const float* dFu, const float* Y0, int ld0, const float* Y1, int ld1,
+                                  const float* sc0, const float* sh0, const float* sc1, const float* sh1, int ldsc,
+                                  const int* tile_row0, const int* tile_nrows, const int* tile_group, int T, float* DY0,
+                                  float* DY1, int lddy, float* DN0, float* DN1, int C, void* stream) {
+  if (!dFu || !Y0 || !Y1 || !sc0 || !sh0 || !sc1 || !sh1 || !tile_row0 || !tile_nrows || !DY0 || !DY1 || !DN0 || !DN1)
+    return MMMOT_EINVAL;
+  if (T <= 0 || C <= 0 || C % 4 != 0 || ld0 % 4 != 0 || ld1 % 4 != 0 || ldsc % 4 != 0 || lddy % 4 != 0) return MMMOT_EINVAL;
+  hipLaunchKernelGGL(fusion_c_bwd_kernel, dim3(T, 16), dim3(256), 0, (hipStream_t)stream, dFu, Y0, ld0, Y1, ld1, sc0,
+                     sh0, sc1, sh1, ldsc, tile_row0, tile_nrows, tile_group, DY0, DY1, lddy, DN0, DN1, C);
+  return mm_check(hipGetLastError());
+}
+
+// Y[r][c] = A[r][c] + B[r][c]  (accumulation of the two gradient paths into a feature: skip connection + conv)
+__global__ __launch_bounds__(256) void add_rows_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
+                                                       int ldb, float* __restrict__ Y, int ldy, long R, int C) {
+  const int C4 = C >> 2;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < R * C4; idx += (long)gridDim.x * 256) {
+    const long r = idx / C4;
+    const int c = (int)(idx - r * C4) * 4;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(&A[r * lda + c]);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(&B[r * ldb + c]);
+    *reinterpret_cast<f32x4*>(&Y[r * ldy + c]) = a + b;
+  }
+}
+
+extern "C" int mmmot_add_rows(const float* A, int lda, const float* B, int ldb, float* Y, int ldy, long R, int C,
+                              void* stream) {
+  if (!A || !B || !Y || R <= 0 || C <= 0 || C % 4 != 0 || lda % 4 != 0 || ldb % 4 != 0 || ldy % 4 != 0) return MMMOT_EINVAL;
+  if (!mm_al16(A) || !mm_al16(B) || !mm_al16(Y)) return MMMOT_EINVAL;
+  const long n4 = R * (C / 4);
+  const int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(add_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, A, lda, B, ldb, Y, ldy, R, C);
+  return mm_check(hipGetLastError());
+}

@@ -312,6 +312,17 @@ class HipOps:
                                               _iptr(gM), G, max_nm, mode, self._stream())
         _lib.check(st, 'mmmot_softmax_pairs_bwd')
 
+    def fusion_c_bwd(self, dFu, Y0, Y1, sc0, sh0, sc1, sh1, tiles, DY0, DY1, DN0, DN1, C):
+        st = self.lib.mmmot_fusion_c_bwd(_ptr(dFu), _ptr(Y0), _ld(Y0), _ptr(Y1), _ld(Y1), _ptr(sc0), _ptr(sh0),
+                                         _ptr(sc1), _ptr(sh1), _ld(sc0), _iptr(tiles.row0), _iptr(tiles.nrows),
+                                         _iptr(tiles.group), tiles.T, _ptr(DY0), _ptr(DY1), _ld(DY0), _ptr(DN0),
+                                         _ptr(DN1), C, self._stream())
+        _lib.check(st, 'mmmot_fusion_c_bwd')
+
+    def add_rows(self, A, B, Y, C):
+        st = self.lib.mmmot_add_rows(_ptr(A), _ld(A), _ptr(B), _ld(B), _ptr(Y), _ld(Y), A.shape[0], C, self._stream())
+        _lib.check(st, 'mmmot_add_rows')
+
     def selftest_mfma(self, A, B, C, K):
         _lib.check(self.lib.mmmot_selftest_mfma(_ptr(A), _ptr(B), _ptr(C), K, self._stream()),
                    'mmmot_selftest_mfma')

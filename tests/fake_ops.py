@@ -380,6 +380,23 @@ class TorchOps:
             (gx,) = torch.autograd.grad(out, x, dout[r0:r0 + N * M].double().view(N, M))
             dlogits[r0:r0 + N * M] = gx.reshape(-1).float()
 
+    def fusion_c_bwd(self, dFu, Y0, Y1, sc0, sh0, sc1, sh1, tiles, DY0, DY1, DN0, DN1, C):
+        grp = _rows_groups(tiles)
+        R = tiles.R
+        g0, i0, g1, i1 = (Y0[:R, :C].double(), Y0[:R, C:2 * C].double(), Y1[:R, :C].double(), Y1[:R, C:2 * C].double())
+        a0, a1 = torch.sigmoid(g0), torch.sigmoid(g1)
+        n0 = i0 * sc0[grp, :C].double() + sh0[grp, :C].double()
+        n1 = i1 * sc1[grp, :C].double() + sh1[grp, :C].double()
+        den = a0 + a1
+        fused = (a0 * n0 + a1 * n1) / den
+        w = dFu[:R, :C].double() / den
+        DN0[:R, :C], DN1[:R, :C] = (w * a0).float(), (w * a1).float()
+        DY0[:R, :C] = (w * (n0 - fused) * a0 * (1 - a0)).float()
+        DY1[:R, :C] = (w * (n1 - fused) * a1 * (1 - a1)).float()
+
+    def add_rows(self, A, B, Y, C):
+        Y[:, :C] = A[:, :C] + B[:, :C]
+
     def rowdot(self, X, K, w, b, tiles, out, sc=None, sh=None, act=ACT_NONE, use_thr=False, thr=0.0, omap=None):
         R = tiles.R
         A = X[:R, :K]

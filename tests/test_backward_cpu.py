@@ -100,3 +100,79 @@ def test_autograd_function_fills_grads():
             assert p.grad is not None and p.grad.shape == p.shape, k
         else:
             assert p.grad is None, k
+
+
+# ---- second slice: fusion module + training-mode w_det + pairwise block = the whole head -------------------------------
+def head_reference(model, counts, cat, fusion, op, sm, w):
+    """autograd through the oracle's fusion / affinity and a float64 training-mode w_det (BatchNorm1d on batch statistics,
+    no sigmoid: reference tracking_net.py:149-151 with self.training)"""
+    import torch.nn.functional as Fn
+    heads = ('fusion_module.', 'w_det.', 'w_link.')
+    sd = {k: v.detach().double().clone().requires_grad_(k.startswith(heads) and v.dtype.is_floating_point and
+                                                        'running' not in k and 'num_batches' not in k)
+          for k, v in model.state_dict().items()}
+    c = cat.detach().double().clone().requires_grad_(True)
+    F3 = R.fusion(c.t().unsqueeze(0), sd, fusion)                    # 3 x 512 x L
+    x = F3
+    for i, bn in ((0, 1), (3, 4)):
+        x = Fn.conv1d(x, sd['w_det.%d.weight' % i], sd['w_det.%d.bias' % i])
+        x = Fn.relu(Fn.batch_norm(x, None, None, sd['w_det.%d.weight' % bn], sd['w_det.%d.bias' % bn], True, 0.0, 1e-5))
+    det = Fn.conv1d(x, sd['w_det.6.weight'], sd['w_det.6.bias']).squeeze(1)
+    links, news, ends = oracle_block(sd, F3, counts, op, sm)
+    N, M = counts
+    loss = (det * w['det'].double()).sum() + (links[0].reshape(-1) * w['link'].double()).sum() + \
+        (news[0] * w['new'][:, N:].double()).sum() + (ends[0] * w['end'][:, :N].double()).sum()
+    loss.backward()
+    return c.grad, {k: v.grad for k, v in sd.items() if v.requires_grad}, det.detach()
+
+
+@pytest.mark.parametrize('fusion,op,sm', [('A', 'multiply', 'none'), ('B', 'minus_abs', 'dual_add'), ('C', 'multiply', 'none'),
+                                          ('C', 'minus_abs', 'dual_add')])
+def test_head_backward_matches_autograd(fusion, op, sm):
+    from mmmot_amd.backward import head_backward, head_forward_train
+    from mmmot_amd.plan import BatchPlan
+    c, base = get_case('s2_C_multiply_none')
+    c = dict(c, fusion=fusion, aff=op, sm=sm)
+    m = build_model(c, base, ops=TorchOps())
+    m.set_trunk('f32')
+    eng = m.engine()
+    counts = [4, 5]
+    plan = BatchPlan([(counts, None)], 32, 'cpu', use_points=False)
+    g = torch.Generator().manual_seed(5)
+    cat = torch.randn(plan.Lt, 1024, generator=g) * 0.8
+    w = dict(det=torch.randn(3, plan.Lt, generator=g), link=torch.randn(plan.pair_tiles.R, generator=g),
+             new=torch.randn(3, plan.Lt, generator=g), end=torch.randn(3, plan.Lt, generator=g))
+    det, link, new, end, tape = head_forward_train(eng, m, plan, cat)
+    dcat, grads = head_backward(eng, m, plan, cat, tape, w['det'], w['link'], w['new'], w['end'])
+    dcat_ref, g_ref, det_ref = head_reference(m, counts, cat, fusion, op, sm, w)
+    assert (det.double() - det_ref).abs().max().item() < 2e-4  # training-mode scores: raw, batch-statistics BatchNorm
+    assert (dcat.double() - dcat_ref).abs().max().item() < 3e-4 * dcat_ref.abs().max().item(), 'dcat'
+    assert set(grads) == set(g_ref), sorted(set(grads) ^ set(g_ref))
+    gmax = max(v.abs().max().item() for v in g_ref.values())
+    for k, ref in g_ref.items():
+        got = grads[k].double().reshape(ref.shape)
+        tol = 3e-4 * ref.abs().max().item() + 3e-6 * (1.0 + gmax)
+        assert (got - ref).abs().max().item() < tol, (k, (got - ref).abs().max().item(), ref.abs().max().item())
+
+
+def test_head_autograd_updates_batchnorm_buffers_like_torch():
+    from mmmot_amd.backward import head_autograd
+    from mmmot_amd.plan import BatchPlan
+    c, base = get_case('s2_C_multiply_none')
+    m = build_model(c, base, ops=TorchOps())
+    m.set_trunk('f32')
+    plan = BatchPlan([([3, 4], None)], 32, 'cpu', use_points=False)
+    cat = (torch.randn(plan.Lt, 1024, generator=torch.Generator().manual_seed(2)) * 0.8).requires_grad_(True)
+    rm0, rv0 = m.w_det[1].running_mean.clone(), m.w_det[1].running_var.clone()
+    det, link, new, end = head_autograd(m, plan, cat)
+    (det.sum() + link.sum() + new.sum() - end.sum()).backward()
+    assert cat.grad is not None and torch.isfinite(cat.grad).all()
+    for k, p in m.named_parameters():
+        assert (p.grad is not None) == (k.split('.')[0] in ('fusion_module', 'w_det', 'w_link')), k
+    # running statistics: the momentum update of torch's training-mode BatchNorm1d on the same conv output
+    import torch.nn.functional as Fn
+    F3 = R.fusion(cat.detach().t().unsqueeze(0), {k: v.detach() for k, v in m.state_dict().items()}, 'C')
+    x = Fn.conv1d(F3, m.w_det[0].weight.detach(), m.w_det[0].bias.detach())
+    rm, rv = rm0.clone(), rv0.clone()
+    Fn.batch_norm(x, rm, rv, None, None, True, 0.1, 1e-5)
+    assert torch.allclose(m.w_det[1].running_mean, rm, atol=1e-5) and torch.allclose(m.w_det[1].running_var, rv, atol=1e-5)

@@ -199,3 +199,77 @@ def test_autograd_function_on_the_device():
     assert F.grad is not None and torch.isfinite(F.grad).all() and F.grad.abs().max() > 0
     for k, p in m.named_parameters():
         assert (p.grad is not None and p.grad.shape == p.shape and torch.isfinite(p.grad).all()) == k.startswith('w_link.'), k
+
+
+# ---- second slice: fusion + training-mode w_det + pairwise block -------------------------------------------------------
+def test_fusion_c_bwd_and_add_rows_kernels(hip):
+    emu = TorchOps()
+    tc, tg = both([40, 7])
+    R, C = tc.R, 512
+    Y0, Y1, dFu = rnd(R, 1024, seed=30), rnd(R, 1024, seed=31), rnd(R, C, seed=32)
+    sc0, sh0, sc1, sh1 = rnd(tc.G, C, seed=33) + 1.0, rnd(tc.G, C, seed=34), rnd(tc.G, C, seed=35) + 1.0, rnd(tc.G, C, seed=36)
+    outs_c = [torch.zeros(R, 1024), torch.zeros(R, 1024), torch.zeros(R, C), torch.zeros(R, C)]
+    outs_g = [torch.zeros(R, 1024, device=DEV), torch.zeros(R, 1024, device=DEV), torch.zeros(R, C, device=DEV),
+              torch.zeros(R, C, device=DEV)]
+    emu.fusion_c_bwd(dFu, Y0, Y1, sc0, sh0, sc1, sh1, tc, *outs_c, C)
+    hip.fusion_c_bwd(dFu.cuda(), Y0.cuda(), Y1.cuda(), sc0.cuda(), sh0.cuda(), sc1.cuda(), sh1.cuda(), tg, *outs_g, C)
+    for a, b, what in zip(outs_g, outs_c, ('dgate0', 'dgate1', 'dn0', 'dn1')):
+        close(a[:, :C], b[:, :C], 3e-6, 'fusion_c_bwd ' + what)
+    A, B = rnd(R, 1024, seed=37), rnd(R, C, seed=38)
+    Yg = torch.zeros(R, 1024, device=DEV)
+    hip.add_rows(A.cuda()[:, 512:], B.cuda(), Yg[:, 512:], C)
+    assert torch.equal(Yg[:, 512:].cpu(), A[:, 512:] + B) and (Yg[:, :512] == 0).all()
+
+
+@pytest.mark.parametrize('trunk,rtol', [('f32', 3e-4), ('f16x3', 6e-4)])
+@pytest.mark.parametrize('fusion,op,sm,counts', [('A', 'multiply', 'none', [4, 5]), ('B', 'minus_abs', 'dual_add', [7, 3]),
+                                                 ('C', 'multiply', 'none', [6, 6]), ('C', 'minus_abs', 'dual_add', [24, 17])])
+def test_head_backward_matches_autograd(fusion, op, sm, counts, trunk, rtol):
+    from mmmot_amd.backward import head_backward, head_forward_train
+    from test_backward_cpu import head_reference
+    c, base = get_case('s2_C_multiply_none')
+    c = dict(c, fusion=fusion, aff=op, sm=sm)
+    m_cpu = build_model(c, base)
+    m = build_model(c, base, device=DEV)
+    m.set_trunk(trunk)
+    eng = m.engine()
+    plan = BatchPlan([(counts, None)], 32, DEV, use_points=False)
+    g = torch.Generator().manual_seed(5)
+    cat = torch.randn(plan.Lt, 1024, generator=g) * 0.8
+    w = dict(det=torch.randn(3, plan.Lt, generator=g), link=torch.randn(plan.pair_tiles.R, generator=g),
+             new=torch.randn(3, plan.Lt, generator=g), end=torch.randn(3, plan.Lt, generator=g))
+    cd = cat.to(DEV)
+    det, link, new, end, tape = head_forward_train(eng, m, plan, cd)
+    dcat, grads = head_backward(eng, m, plan, cd, tape, *[w[k].to(DEV) for k in ('det', 'link', 'new', 'end')])
+    dcat_ref, g_ref, det_ref = head_reference(m_cpu, counts, cat, fusion, op, sm, w)
+    assert (det.cpu().double() - det_ref).abs().max().item() < 5e-4
+    gmax = max(v.abs().max().item() for v in g_ref.values())
+    worst = 0.0
+    for name, got, ref in [('dcat', dcat, dcat_ref)] + [(k, grads[k], g_ref[k]) for k in g_ref]:
+        d = got.cpu().double().reshape(ref.shape) - ref
+        linf, rmax = d.abs().max().item(), ref.abs().max().item()
+        tol = rtol * rmax + 1e-2 * rtol * (1.0 + gmax)
+        if linf >= tol:  # an isolated ReLU-branch flip against the float64 reference (see the pairwise test above)
+            l2 = (d.norm() / max(ref.norm().item(), 1e-30)).item()
+            assert l2 < 5e-3 and linf < 0.1 * rmax + tol, (name, linf, rmax, l2)
+        elif rmax > 1e-6 * gmax:
+            worst = max(worst, linf / rmax)
+    assert set(grads) == set(g_ref)
+    print('head backward fusion %s %s/%s %s %s: worst relative gradient error %.1e over dcat + %d parameter tensors' % (
+        fusion, op, sm, counts, trunk, worst, len(g_ref)))
+
+
+def test_head_autograd_on_the_device():
+    from mmmot_amd.backward import head_autograd
+    c, base = get_case('s2_C_minus_abs_dual_add')
+    m = build_model(c, base, device=DEV)
+    plan = BatchPlan([([6, 5], None)], 32, DEV, use_points=False)
+    cat = (torch.randn(plan.Lt, 1024, generator=torch.Generator().manual_seed(1)) * 0.8).to(DEV).requires_grad_(True)
+    rv0 = m.w_det[4].running_var.clone()
+    det, link, new, end = head_autograd(m, plan, cat)
+    (det.sum() + link.square().sum() + 2 * new.sum() - end.sum()).backward()
+    assert cat.grad is not None and torch.isfinite(cat.grad).all() and cat.grad.abs().max() > 0
+    heads = ('fusion_module', 'w_det', 'w_link')
+    for k, p in m.named_parameters():
+        assert (p.grad is not None and torch.isfinite(p.grad).all()) == (k.split('.')[0] in heads), k
+    assert not torch.equal(m.w_det[4].running_var, rv0)  # training-mode BatchNorm updated its buffers
