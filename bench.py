@@ -159,8 +159,9 @@ def roofline_of(trunk, events, eng, B, workload, dt):
         peak_basis = ('%.0f TFLOP/s dense f16 MFMA / 3 MFMAs per algorithmic product (a_hi*w_hi + a_hi*w_lo + '
                       'a_lo*w_hi, fp32 accumulate)' % PEAK_F16_MFMA_TFLOPS)
     elif trunk == 'f16q8':
-        dom = {li: a for li, a in per_layer.items() if li != 0}
-        kname = 'conv3x3_hl16_patch_kernel<Q8> (VGG16-BN trunk layers 2-13, 12 launches/step)'
+        ql = getattr(eng, 'q8_layers', None)  # the layers that run the hq8 arithmetic (default conv3_1 .. conv5_3)
+        dom = {li: a for li, a in per_layer.items() if li != 0 and (ql is None or li in ql)}
+        kname = 'conv3x3_hl16_patch_kernel<Q8> (the %d VGG16-BN trunk launches per step that run the hq8 arithmetic)' % len(dom)
         peak = PEAK_F16_MFMA_TFLOPS / 2.0
         peak_basis = ('%.0f TFLOP/s dense f16 MFMA / 2 f16-MFMA equivalents per algorithmic product (a_hi*w_hi on the '
                       'f16 cores + both correction terms in one block-scaled fp8 K=64 MFMA at twice the f16 rate)'
