@@ -273,3 +273,33 @@ def test_head_autograd_on_the_device():
     for k, p in m.named_parameters():
         assert (p.grad is not None and torch.isfinite(p.grad).all()) == (k.split('.')[0] in heads), k
     assert not torch.equal(m.w_det[4].running_var, rv0)  # training-mode BatchNorm updated its buffers
+
+
+def test_sgd_on_the_head_reduces_a_loss():
+    """A few plain SGD steps on the head's parameters through head_autograd (forward + backward on the device): a
+    regression loss on the link scores and a logistic loss on the det scores both go down - the gradients point the
+    right way end to end (packed weights are rebuilt from the updated parameters by model.invalidate())."""
+    from mmmot_amd.backward import head_autograd
+    c, base = get_case('s2_C_multiply_none')
+    m = build_model(c, base, device=DEV)
+    plan = BatchPlan([([8, 7], None)], 32, DEV, use_points=False)
+    g = torch.Generator().manual_seed(4)
+    cat = (torch.randn(plan.Lt, 1024, generator=g) * 0.8).to(DEV)
+    tgt_link = torch.randn(plan.pair_tiles.R, generator=g).to(DEV)
+    tgt_det = (torch.rand(3, plan.Lt, generator=g) > 0.5).float().to(DEV)
+    params = [p for k, p in m.named_parameters() if k.split('.')[0] in ('fusion_module', 'w_det', 'w_link')]
+    losses = []
+    for step in range(6):
+        for p in params:
+            p.grad = None
+        det, link, new, end = head_autograd(m, plan, cat, update_running_stats=False)
+        loss = torch.nn.functional.mse_loss(link, tgt_link) + \\
+            torch.nn.functional.binary_cross_entropy_with_logits(det, tgt_det)
+        loss.backward()
+        losses.append(loss.item())
+        with torch.no_grad():
+            for p in params:
+                p.add_(p.grad, alpha=-0.02)
+        m.invalidate()
+    print('head SGD losses', ['%.4f' % v for v in losses])
+    assert losses[-1] < 0.9 * losses[0] and all(b < a * 1.02 for a, b in zip(losses, losses[1:]))
