@@ -293,8 +293,8 @@ def test_sgd_on_the_head_reduces_a_loss():
         for p in params:
             p.grad = None
         det, link, new, end = head_autograd(m, plan, cat, update_running_stats=False)
-        loss = torch.nn.functional.mse_loss(link, tgt_link) + \\
-            torch.nn.functional.binary_cross_entropy_with_logits(det, tgt_det)
+        loss = (torch.nn.functional.mse_loss(link, tgt_link) +
+                torch.nn.functional.binary_cross_entropy_with_logits(det, tgt_det))
         loss.backward()
         losses.append(loss.item())
         with torch.no_grad():
