@@ -132,6 +132,10 @@ class Engine:
             # (dataset/test_seq_dataset.py:218); its MaxPool2d floors odd maps, which is not built here.
             raise ValueError('crop side %d is not supported: the HIP VGG trunk needs a multiple of 32 '
                              '(32, 64, ..., 224, 256); resize the crops (mmmot_amd.crops.crop_resize_normalize)' % S)
+        if Lt * S * S * 16 >= 2 ** 31 - 64:
+            # the trunk kernels address activations with 32-bit offsets in 16-byte pieces (largest tensor: L x S x S x 64)
+            raise ValueError('%d crops of %dx%d in one launch sequence exceed the 32-bit piece offsets of the trunk kernels '
+                             '(L*S*S*16 < 2^31): split the batch' % (Lt, S, S))
         x, H, W = crops, S, S
         # q8: activations travel as hq8 records (fp16 hi + two e4m3 copies, same bytes)
         q8 = (self.trunk == 'f16q8') and S >= self.q8_min_crop
