@@ -281,6 +281,10 @@ class GraphedForward:
                     self.result = model.forward_batch(plan, self.crops, self.points)
             finally:
                 eng.range_guard = guard
+        # the graph holds raw pointers into the engine's packed weights and workspace arena: keep them alive even if
+        # the model is re-packed or a later, larger forward re-allocates workspace buffers
+        self._engine = eng
+        self._keep = list(eng.ws.values())
 
     def __call__(self, crops=None, points=None):
         if crops is not None and crops.data_ptr() != self.crops.data_ptr():
