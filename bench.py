@@ -91,6 +91,7 @@ def parse_args(argv=None):
                     help="comma list of further trunk modes timed in the same run and reported under 'extra' "
                          "(default: the other one of f16x3 / f16q8; 'none' disables)")
     ap.add_argument('--no-latency', action='store_true', help='skip the B=1 reference-call latency extra')
+    ap.add_argument('--latency-only', action='store_true', help='run only the B=1 latency leg (profiling)')
     ap.add_argument('--dry', action='store_true',
                     help='CPU / gloo dry run of the launcher, sharding, gather, timing and JSON with a stub step')
     return ap.parse_args(argv)
@@ -372,6 +373,9 @@ def main():
     from mmmot_amd.weights import init_module
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    if args.latency_only:
+        print(json.dumps(latency_b1(dev, args.trunk)), flush=True)
+        return
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=dev)
