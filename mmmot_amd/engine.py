@@ -245,7 +245,13 @@ class Engine:
         """reference modules/appear_net.py:9-32 for stage s -> cat[:, 128 s : 128 (s+1)]."""
         ops, Lt, hd, T = self.ops, plan.Lt, self.P['skippool'][s], plan.det_tiles
         pooled = self.buf('sp_pool', Lt, C)
-        ops.segment_mean(x, C, plan.crop_segments(hw), pooled, use_group=False, hl16=hl16)
+        first, second, npart = plan.crop_segments(hw)
+        if second is None:
+            ops.segment_mean(x, C, first, pooled, use_group=False, hl16=hl16)
+        else:  # two-level pool: row chunks of a crop -> partial sums -> mean (few crops: see plan._crop_segments)
+            partial = self.buf('sp_partial', npart, C)
+            ops.segment_mean(x, C, first, partial, use_group=False, hl16=hl16)
+            ops.segment_mean(partial, C, second, pooled, use_group=False)
         ln0 = self.buf('sp_ln0', Lt, C)
         ops.row_layernorm(pooled, C, hd['g0'], hd['b0'], EPS, False, ln0, Lt)
         C4 = hd['w1'].shape[0]

@@ -72,12 +72,14 @@ class RowTiles:
     and the finalize kernel is handed the per-tile row counts."""
 
     def __init__(self, counts, device, sub_counts=None, tile=TILE):
-        TILE = int(tile)  # rows per tile (128 for the GEMM kernels; 4096 for the Gram super-tiles)
         counts = [int(c) for c in counts]
+        # rows per tile (128 for the GEMM kernels; up to 4096 for the Gram super-tiles), optionally one value per group
+        tiles_g = [int(t) for t in tile] if isinstance(tile, (list, tuple, np.ndarray)) else [int(tile)] * len(counts)
         row0, nrows, group, g_tile0, g_ntiles, g_row0 = [], [], [], [], [], []
         sub_tile0, sub_ntiles = [], []
         r = 0
         for g, c in enumerate(counts):
+            TILE = tiles_g[g]
             g_tile0.append(len(row0))
             g_row0.append(r)
             subs = [c] if sub_counts is None else [int(x) for x in sub_counts[g]]
@@ -199,8 +201,14 @@ class BatchPlan:
             self.ptd_tiles = RowTiles(P_b, device, sub_counts=per_sample)
             self.det_tile_segs = Segments(self.ptd_tiles.h_sub_tile0, self.ptd_tiles.h_sub_ntiles, np.ones(Lt),
                                           det_sample, device, div=cnts)
-            # super-tiles of <= 4096 rows inside a sample: second-moment (Gram) statistics of a layer's input
-            self.gram_tiles = RowTiles(P_b, device, tile=4096)
+            # super-tiles of <= 4096 rows inside a sample: second-moment (Gram) statistics of a layer's input.  One
+            # workgroup walks one super-tile, so small point clouds (a single reference-shaped pair: ~7 000 points)
+            # get shorter super-tiles - 4096-row ones would leave two workgroups to do the whole pass (0.21 ms at
+            # B = 1, profiles/README.md); large batches keep 4096 (fewer float64 partials to merge)
+            # (chosen per SAMPLE, from its own point count: a sample's statistics do not depend on what it is batched
+            # with - tests/test_parity_gpu.py::test_batched_equals_single_and_is_deterministic)
+            gt = [min(4096, max(128, 128 * -(-p_b // (32 * 128)))) for p_b in P_b]
+            self.gram_tiles = RowTiles(P_b, device, tile=gt)
             # 64-row half tiles of ptd_tiles (the A-resident GEMM emits its partials per wave = per half tile)
             self.ptd_half = HalfTiles(self.ptd_tiles, device)
             self.det_half_segs = Segments(2 * self.ptd_tiles.h_sub_tile0, 2 * self.ptd_tiles.h_sub_ntiles,
@@ -262,12 +270,26 @@ class BatchPlan:
         up_all.flush()
 
     def _crop_segments(self, hw, device):
+        """Global average pool of every crop's hw pixels.  One workgroup reduces one segment, so with few crops (a single
+        reference-shaped pair: 22 crops x 3136 pixels at stage 0) a segment per crop leaves 22 workgroups walking 3136
+        rows each - 0.3 ms at B = 1.  Maps of more than 256 pixels are therefore pooled in two levels: 256-row chunks of a crop are summed (divisor 1),
+        a second pass adds a crop's S partial rows and divides by hw.  Returns (first, second | None, rows of partials)."""
         Lt = self.Lt
-        self.crop_segs[hw] = Segments(np.arange(Lt) * hw, np.full(Lt, hw), np.ones(Lt), np.zeros(Lt), device)
+        S = -(-hw // 256)  # fixed 256-row chunks: the summation order of a crop does not depend on the batch it is in
+        if S <= 1:
+            self.crop_segs[hw] = (Segments(np.arange(Lt) * hw, np.full(Lt, hw), np.ones(Lt), np.zeros(Lt), device), None, 0)
+            return self.crop_segs[hw]
+        chunk = 256
+        l, c = np.repeat(np.arange(Lt), S), np.tile(np.arange(S), Lt)
+        start = l * hw + c * chunk
+        count = np.minimum(chunk, hw - c * chunk)
+        first = Segments(start, count, np.ones(Lt * S), np.zeros(Lt * S), device, div=np.ones(Lt * S))
+        second = Segments(np.arange(Lt) * S, np.full(Lt, S), np.ones(Lt), np.zeros(Lt), device, div=np.full(Lt, hw))
+        self.crop_segs[hw] = (first, second, Lt * S)
         return self.crop_segs[hw]
 
     def crop_segments(self, hw):
-        """Segments 'all pixels of one crop' for the global average pool."""
+        """see _crop_segments"""
         if hw not in self.crop_segs:
             self._crop_segments(hw, self.device)
         return self.crop_segs[hw]
