@@ -511,7 +511,7 @@ def affinity_autograd(model, plan, F):
     """Differentiable pairwise block of ``model`` (a TrackingNet on the device): F [nR, Lt, 512] ->
     (link flat [sum nR*N*M], new [nR, Lt], end [nR, Lt]) attached to the autograd graph; ``backward()`` fills
     ``F.grad`` and the ``.grad`` of every ``model.w_link`` parameter.  The packed weights are those of
-    ``model.engine()``: call ``model.invalidate()`` after an optimizer step."""
+    ``model.engine()``: call ``model.refresh_head()`` after an optimizer step."""
     eng = model.engine()
     named = [(k, p) for k, p in model.named_parameters() if k.startswith('w_link.')]
     keys = tuple(k for k, _ in named)

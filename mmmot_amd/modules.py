@@ -374,6 +374,18 @@ class TrackingNet(nn.Module):
         self._engine = None
         self._plans = {}
 
+    def refresh_head(self):
+        """Re-pack only the head's weights (fusion_module, w_det, w_link: 3 M of the 21 M parameters) into the live
+        engine - what a training step on the head needs after ``optimizer.step()`` (mmmot_amd/backward.py); the
+        encoders' packed weights (VGG hl16 / hq8 copies, PointNet) stay as they are."""
+        eng = self.engine()
+        heads = ('fusion_module', 'w_det', 'w_link')
+        sd = {k: v for k, v in self.state_dict().items() if k.split('.')[0] in heads}
+        P = pack_weights(sd, self.score_fusion_arch, next(self.parameters()).device)
+        for k in ('fusion', 'w_det', 'w_link'):
+            eng.P[k] = P[k]
+        return eng
+
     def _apply(self, fn, *a, **k):
         self.invalidate()  # .to() / .cuda(): packed weights and the cached plans' tables live on the old device
         return super()._apply(fn, *a, **k)

@@ -176,3 +176,17 @@ def test_head_autograd_updates_batchnorm_buffers_like_torch():
     rm, rv = rm0.clone(), rv0.clone()
     Fn.batch_norm(x, rm, rv, None, None, True, 0.1, 1e-5)
     assert torch.allclose(m.w_det[1].running_mean, rm, atol=1e-5) and torch.allclose(m.w_det[1].running_var, rv, atol=1e-5)
+
+
+def test_refresh_head_repacks_only_the_head():
+    c, base = get_case('s2_C_multiply_none')
+    m = build_model(c, base, ops=TorchOps())
+    eng = m.engine()
+    vgg_before, pn_before = eng.P['vgg'], eng.P['pointnet']
+    wa_before = eng.P['w_link']['wa'].clone()
+    with torch.no_grad():
+        m.w_link.conv1[0].weight.mul_(1.5)
+    assert m.refresh_head() is eng and eng.P['vgg'] is vgg_before and eng.P['pointnet'] is pn_before
+    wa = eng.P['w_link']['wa']
+    assert torch.allclose(wa[512:], wa_before[512:] * 1.5) and torch.equal(wa[:512], wa_before[:512])
+    assert 'wa_h16' in eng.P['w_link']  # the fp16-split copies are rebuilt too

@@ -278,7 +278,7 @@ def test_head_autograd_on_the_device():
 def test_sgd_on_the_head_reduces_a_loss():
     """A few plain SGD steps on the head's parameters through head_autograd (forward + backward on the device): a
     regression loss on the link scores and a logistic loss on the det scores both go down - the gradients point the
-    right way end to end (packed weights are rebuilt from the updated parameters by model.invalidate())."""
+    right way end to end (the head's packed weights are rebuilt from the updated parameters by model.refresh_head())."""
     from mmmot_amd.backward import head_autograd
     c, base = get_case('s2_C_multiply_none')
     m = build_model(c, base, device=DEV)
@@ -300,6 +300,6 @@ def test_sgd_on_the_head_reduces_a_loss():
         with torch.no_grad():
             for p in params:
                 p.add_(p.grad, alpha=-0.02)
-        m.invalidate()
+        m.refresh_head()  # re-pack the 3 M head parameters only
     print('head SGD losses', ['%.4f' % v for v in losses])
     assert losses[-1] < 0.9 * losses[0] and all(b < a * 1.02 for a, b in zip(losses, losses[1:]))
