@@ -1094,6 +1094,32 @@ extern "C" int mmmot_set_patch_variant(int v) {
 }
 #endif
 
+static int pt_num_cu() {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    n_cu = prop.multiProcessorCount;
+  }
+  return n_cu;
+}
+
+// 128- or 64-channel tiles?  128 halves the LDS traffic per MFMA, but a small problem (one reference-shaped frame pair:
+// 22 crops, 14 x 14 maps at conv5 = 88 tiles of 128 channels on 256 CUs) fills the chip better with twice as many
+// 64-channel tiles.  Same arithmetic per output element either way (bitwise identical results).
+static bool pt_use_bn64(int L, int H, int W, int Cout) {
+  if (Cout % 128 != 0) return true;
+  const int n_cu = pt_num_cu();
+  if (n_cu <= 0) return false;
+  const bool big = (H > 8 || W > 8);
+  const int bs = big ? 16 : 8, nb = big ? 1 : 4;
+  const long nblk = (long)L * ((H + bs - 1) / bs) * ((W + bs - 1) / bs);
+  const long i128 = ((nblk + nb - 1) / nb) * (Cout / 128), i64 = 2 * i128;
+  auto eff = [&](long items) { return (double)items / (double)(((items + n_cu - 1) / n_cu) * n_cu); };
+  return 0.85 * eff(i64) > eff(i128);  // a 64-channel tile does half the work of a 128-channel one in ~0.59 of the time
+}
+
 template <int BN, int BS, bool POOL, int EXP, bool FUSE1 = false, bool Q8 = false>
 static int launch_patch_e(const void* in, const void* wp, const float* bias, void* out, int L, int H, int W, int Cin,
                         int Cout, const float* oscale, hipStream_t s, Fuse1Args fz = Fuse1Args{nullptr, nullptr, nullptr, 1.f}) {
@@ -1102,13 +1128,8 @@ static int launch_patch_e(const void* in, const void* wp, const float* bias, voi
   constexpr int NB = PatchGeom<BS>::NB;
   const int ntm = (nblk + NB - 1) / NB;
   const int ntn = Cout / BN;
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MMMOT_EINVAL;
-    n_cu = prop.multiProcessorCount;
-  }
+  const int n_cu = pt_num_cu();
+  if (n_cu <= 0) return MMMOT_EINVAL;
   const int nitems = ntm * ntn;
   int grid = (n_cu / 8) * 8;                       // one persistent workgroup per CU, whole XCDs
   const int glimit = g_patch_grid_limit.load();
@@ -1156,7 +1177,7 @@ extern "C" int mmmot_conv3x3_bn_relu_hl16_patch(const void* in, const void* wp, 
   if (!mm_al16(in) || !mm_al16(wp) || !mm_al16(out)) return MMMOT_EINVAL;
   if ((long)L * H * W * (Cin / 4) >= (1L << 31) - 64) return MMMOT_EINVAL;  // 32-bit piece offsets
   const bool big = (H > 8 || W > 8);  // 16x16 blocks unless the whole map fits an 8x8 block
-  if (Cout % 128 == 0)
+  if (!pt_use_bn64(L, H, W, Cout))
     return big ? launch_patch_p<128, 16>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s)
                : launch_patch_p<128, 8>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
   return big ? launch_patch_p<64, 16>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s)
@@ -1201,7 +1222,7 @@ extern "C" int mmmot_conv3x3_bn_relu_hq8(const void* in, const void* wp, const f
   if (!mm_al16(in) || !mm_al16(wp) || !mm_al16(out)) return MMMOT_EINVAL;
   if ((long)L * H * W * (Cin / 4) >= (1L << 31) - 64) return MMMOT_EINVAL;
   const bool big = (H > 8 || W > 8);
-  if (Cout % 128 == 0)
+  if (!pt_use_bn64(L, H, W, Cout))
     return big ? launch_q8_p<128, 16>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s)
                : launch_q8_p<128, 8>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
   return big ? launch_q8_p<64, 16>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s)

@@ -166,3 +166,23 @@ def test_conv1_fused_many_tiles_per_workgroup(hip, small_grid):
     """persistent grid capped at 8 workgroups: every workgroup walks 10+ tiles (raw-window prefetch of the next tile)"""
     test_conv1_fused_matches_two_layer_reference(hip, 5, 64, 64)
     test_conv1_fused_matches_two_layer_reference(hip, 3, 32, 48)
+
+
+def test_tile_width_heuristic_is_bitwise_neutral(hip):
+    """Small problems run 64-channel tiles (twice as many items for the 256 CUs), large ones 128-channel tiles: the
+    launcher decides from the problem size alone (pt_use_bn64) and the per-element arithmetic is the same - the first
+    two crops of a 512-crop launch (128-channel tiles) equal a 2-crop launch (64-channel tiles) bit for bit."""
+    H = W = 16
+    Cin, Cout = 64, 128
+    x = torch.relu(rnd(512 * H * W, Cin, seed=600)) * 3.0
+    w = rnd(9, Cout, Cin, seed=601, scale=(2.0 / (9 * Cin)) ** 0.5)
+    bias = rnd(Cout, seed=602, scale=0.1)
+    shift = hl16_weight_shift(w)
+    x16, w16 = to_hl16(x).cuda(), to_hl16(w.double() * 2.0 ** shift).cuda()
+    for pool in (False, True):
+        Ho = H // 2 if pool else H
+        big = torch.full((512 * Ho * Ho, Cout), float('nan')).cuda()
+        small = torch.full((2 * Ho * Ho, Cout), float('nan')).cuda()
+        hip.conv3x3_hl16_patch(x16, w16, bias.cuda(), big, 512, H, W, Cin, Cout, pool, 2.0 ** -shift)
+        hip.conv3x3_hl16_patch(x16[:2 * H * W], w16, bias.cuda(), small, 2, H, W, Cin, Cout, pool, 2.0 ** -shift)
+        assert torch.equal(big[:2 * Ho * Ho], small), 'tile width changed the result (pool=%s)' % pool
