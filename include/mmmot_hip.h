@@ -73,7 +73,7 @@ extern "C" {
  * mmmot_trunk_range_read, the tile / LDS-DMA trunk kernels and their knobs removed, timing experiments only in
  * -DMMMOT_DEBUG builds; 5 = training backward of the pairwise block (mmmot_gn_bwd_*, mmmot_gemm_tn,
  * mmmot_pair_bwd, mmmot_pair_expand_bwd, mmmot_rowdot_bwd, mmmot_softmax_pairs_bwd, mmmot_fusion_c_bwd, mmmot_add_rows),
- * mmmot_pointnet_layer1 takes K = 3 | 4. */
+ * mmmot_pointnet_layer1 takes K = 3 | 4; mmmot_pn_mlp64 added (additive, still 5). */
 int mmmot_abi_version(void);
 /* returns 0 and fills cu_count / gcn arch string (<=32 bytes) of device 0..; */
 int mmmot_device_info(int device, int* cu_count, char* arch, int arch_len);
@@ -311,6 +311,15 @@ int mmmot_row_layernorm(const float* X, int ldx, int C, const float* gamma, cons
 int mmmot_pointnet_layer1(const float* X, int K, const float* W, const float* bias,
                           float* Y, float* part,
                           const int* tile_row0, const int* tile_nrows, int T, void* stream);
+
+/* PointNet shared-MLP layer with 64 input channels (feat.conv2 / conv3 / conv4, point_net.py:134-137):
+ *   v[r][n] = sum_k relu(X[r][k]*sc[g][k] + sh[g][k]) * W[n][k] * oscale + bias[n],   k < 64, N = 64 | 128
+ * Y[r][n] = v (raw, the next layer normalises it) and part[t] = per-tile (sum, tile-centred M2) of v - exactly what
+ * mmmot_gemm_rows computes for amode = MMMOT_A_NORM_RELU, w_hl16 = 1, K = 64 - from persistent workgroups that keep
+ * W16 ([N][8] hl16 units, host-scaled by 1/oscale) in LDS and prefetch the next tile's rows.  tile_group may be NULL. */
+int mmmot_pn_mlp64(const float* X, int ldx, const float* sc, const float* sh, int ldsc, const void* W16,
+                   float oscale, const float* bias, float* Y, int ldy, float* part, const int* tile_row0,
+                   const int* tile_nrows, const int* tile_group, int T, int N, void* stream);
 
 /* Y[r][c] = act(X[r][c]*sc[g][c] + sh[g][c]); g from the tile table. C % 4 == 0 */
 int mmmot_affine_act(const float* X, int ldx, int C, const float* sc, const float* sh, int ldsc,

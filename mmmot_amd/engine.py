@@ -55,6 +55,8 @@ class Engine:
         self.pn_fused = os.environ.get('MMMOT_PN_FUSED', '1') != '0'
         # conv5 statistics from the Gram matrix of its input instead of a statistics pass of the GEMM
         self.pn_gram = os.environ.get('MMMOT_PN_GRAM', '1') != '0'
+        # conv2..conv4 (K = 64) from the persistent weight-resident kernel (pn_mlp64.hip) instead of the generic row GEMM
+        self.pn_mlp64 = os.environ.get('MMMOT_PN_MLP64', '1') != '0'
         # conv1_1 evaluated inside conv1_2's patch prologue (MMMOT_FUSE_CONV1=0: two launches)
         self.fuse_conv1 = os.environ.get('MMMOT_FUSE_CONV1', '1') != '0'
         # f16q8 applies to crops of at least this side; smaller crops run the f16x3 trunk.  The e4m3 correction
@@ -278,8 +280,11 @@ class Engine:
         for i, (N, K) in zip((2, 3, 4), ((64, 64), (64, 64), (128, 64))):
             y = self.buf('pn_y%d' % i, Pn, N)
             part = self._part(T, N)
-            self._gemm(pn, 'w%d' % i, T, N, K, X=x, bias=pn['b%d' % i], Y=y, part=part, sc=sc, sh=sh,
-                     amode=A_NORM_RELU)
+            if self.pn_mlp64 and self.mlp == 'f16x3' and ('w%d_h16' % i) in pn:
+                ops.pn_mlp64(pn['w%d_h16' % i], pn['w%d_os' % i], T, N, x, sc, sh, pn['b%d' % i], y, part)
+            else:
+                self._gemm(pn, 'w%d' % i, T, N, K, X=x, bias=pn['b%d' % i], Y=y, part=part, sc=sc, sh=sh,
+                           amode=A_NORM_RELU)
             sc, sh = self._finalize('pn%d' % i, part, T, N, N, pn['g%d' % i], pn['be%d' % i])
             x = y
         # conv5 128->1024 + GN + ReLU + per-detection average (named max_feats in the reference,

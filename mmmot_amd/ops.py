@@ -183,6 +183,14 @@ class HipOps:
         a.T, a.N, a.K, a.oscale = tiles.T, N, K, float(oscale)
         _lib.check(self.lib.mmmot_gemm_ares(ctypes.byref(a), self._stream()), 'mmmot_gemm_ares')
 
+    def pn_mlp64(self, W16, oscale, tiles, N, X, sc, sh, bias, Y, part):
+        """PointNet K = 64 layer: Y / part of relu(X*sc+sh) W^T + b from the persistent weight-resident kernel (same
+        results contract as gemm(amode=A_NORM_RELU, w_hl16=True, K=64); see mmmot_pn_mlp64)."""
+        st = self.lib.mmmot_pn_mlp64(_ptr(X), _ld(X), _ptr(sc), _ptr(sh), _ld(sc), _ptr(W16), float(oscale),
+                                     _ptr(bias), _ptr(Y), _ld(Y), _ptr(part), _iptr(tiles.row0), _iptr(tiles.nrows),
+                                     _iptr(tiles.group), tiles.T, N, self._stream())
+        _lib.check(st, 'mmmot_pn_mlp64')
+
     def gram_rows(self, X, K, sc, sh, tiles, Gout, Sout):
         """Per super-tile Gram matrix / column sums (float64) of relu(X*sc+sh); see mmmot_gram_rows."""
         st = self.lib.mmmot_gram_rows(_ptr(X), _ld(X), K, _ptr(sc), _ptr(sh), _ld(sc), _iptr(tiles.row0),

@@ -180,6 +180,9 @@ class TorchOps:
         if Y is not None:
             Y[:R, :N] = _act(v, act).to(Y.dtype)
 
+    def pn_mlp64(self, W16, oscale, tiles, N, X, sc, sh, bias, Y, part):
+        self.gemm(W16, tiles, N, 64, X=X, bias=bias, Y=Y, part=part, sc=sc, sh=sh, amode=1, w_hl16=True, oscale=oscale)
+
     def gemm_ares(self, W16, oscale, tiles, N, K, X, sc, sh, bias=None, dbias=None, tile_dbrow=None, part=None,
                   osc=None, osh=None, colsum=None):
         from mmmot_amd.pack import from_hl16

@@ -552,3 +552,34 @@ def test_gram_statistics_match_direct_statistics(hip, K, N):
     hip.gn_finalize_gram(Gp, Sp, gpu, K, W.cuda(), bias.cuda(), N, gamma.cuda(), beta.cuda(), 1e-5, work, scg, shg)
     close(scg, sc_ref.float(), 5e-6, 'scale from the Gram route')
     close(shg, sh_ref.float(), 5e-6, 'shift from the Gram route')
+
+
+@pytest.mark.parametrize('N', [64, 128])
+@pytest.mark.parametrize('counts', [[5, 300, 128], [1], [70001, 257]])
+def test_pn_mlp64_matches_row_gemm_contract(hip, N, counts):
+    """Persistent weight-resident K = 64 PointNet layer: raw output and per-tile statistics vs the fp64 emulation
+    and vs mmmot_gemm_rows on the same hl16 weights; more tiles than resident workgroups ([70001, 257] -> 550 tiles
+    on 512 slots) so the grid-stride loop and the register prefetch of a later tile are exercised."""
+    from mmmot_amd.pack import hl16_weight_shift, to_hl16
+    emu = TorchOps(torch.float64)
+    t = DevTiles(counts)
+    R, G_ = sum(counts), len(counts)
+    X = rnd(R, 64, seed=90) + 0.3
+    W = rnd(N, 64, seed=91, scale=0.125)
+    bias = rnd(N, seed=92)
+    sc, sh = rnd(G_, 64, seed=93).abs() + 0.5, rnd(G_, 64, seed=94)
+    shift = hl16_weight_shift(W)
+    W16 = to_hl16(W.double() * 2.0 ** shift)
+    osv = 2.0 ** -shift
+    Yr, pr = torch.zeros(R, N, dtype=torch.float64), torch.zeros(t.cpu.T, 2, N, dtype=torch.float64)
+    emu.pn_mlp64(W16, osv, t.cpu, N, X, sc, sh, bias, Yr, pr)
+    Yg, pg = torch.full((R, N), float('nan')).cuda(), torch.full((t.gpu.T, 2, N), float('nan')).cuda()
+    hip.pn_mlp64(W16.cuda(), osv, t.gpu, N, X.cuda(), sc.cuda(), sh.cuda(), bias.cuda(), Yg, pg)
+    close(Yg, Yr.float(), 2e-6, 'pn_mlp64 output')
+    close(pg[:, 0], pr[:, 0].float(), 1e-5, 'pn_mlp64 tile sums')
+    close(pg[:, 1], pr[:, 1].float(), 1e-4, 'pn_mlp64 tile M2')
+    Y2, p2 = torch.full((R, N), float('nan')).cuda(), torch.full((t.gpu.T, 2, N), float('nan')).cuda()
+    hip.gemm(W16.cuda(), t.gpu, N, 64, X=X.cuda(), bias=bias.cuda(), Y=Y2, part=p2, sc=sc.cuda(), sh=sh.cuda(),
+             amode=1, w_hl16=True, oscale=osv)
+    close(Yg, Y2, 1e-6, 'pn_mlp64 vs gemm_rows output')
+    close(pg[:, 0], p2[:, 0], 1e-5, 'pn_mlp64 vs gemm_rows sums')

@@ -45,6 +45,24 @@ def main():
     eng.pointnet(plan, points, cat)
     torch.cuda.synchronize()
     print('Engine.pointnet, %d points: %.3f ms' % (plan.P, timed(lambda: eng.pointnet(plan, points, cat))))
+    eng.pn_mlp64 = not eng.pn_mlp64
+    eng.pointnet(plan, points, cat)
+    print('  with pn_mlp64 = %s: %.3f ms' % (eng.pn_mlp64, timed(lambda: eng.pointnet(plan, points, cat))))
+    eng.pn_mlp64 = not eng.pn_mlp64
+    eng.pointnet(plan, points, cat)
+    # the K = 64 layers alone, both kernels (conv3 64->64 and conv4 64->128 on the live buffers)
+    pn, T = eng.P['pointnet'], plan.pt_tiles
+    y1 = eng.ws['pn_y1'][:plan.P * 64].view(plan.P, 64)
+    s1, h1 = eng.ws['pn1_sc'][:T.G * 64].view(T.G, 64), eng.ws['pn1_sh'][:T.G * 64].view(T.G, 64)
+    for i, N_ in ((2, 64), (4, 128)):
+        y = torch.empty(plan.P, N_, device=dev)
+        part = torch.empty(T.T, 2, N_, device=dev)
+        nbytes = plan.P * 4 * (64 + N_)
+        ta = timed(lambda: eng.ops.pn_mlp64(pn['w%d_h16' % i], pn['w%d_os' % i], T, N_, y1, s1, h1, pn['b%d' % i], y, part))
+        tb = timed(lambda: eng.ops.gemm(pn['w%d_h16' % i], T, N_, 64, X=y1, bias=pn['b%d' % i], Y=y, part=part, sc=s1,
+                                        sh=h1, amode=1, w_hl16=True, oscale=pn['w%d_os' % i]))
+        print('  64->%d: pn_mlp64 %.3f ms (%.2f TB/s) | gemm_rows %.3f ms (%.2f TB/s)' % (
+            N_, ta, nbytes / ta / 1e9, tb, nbytes / tb / 1e9))
     # the Gram pass alone on the conv4 output of the run above
     x, sc, sh = eng.ws['pn_y4'][:plan.P * 128].view(plan.P, 128), eng.ws['pn4_sc'], eng.ws['pn4_sh']
     GT = plan.gram_tiles
