@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.environ.get('MMMOT_LIB_PATH', os.path.join(_HERE, 'libmmmot_hip.so'))  # override: tools' timing-experiment builds
 SOURCES = ['conv3x3.hip', 'hl16_format.hip', 'conv3x3_hl16_patch.hip', 'gemm_rows.hip',
-           'gemm_ares.hip', 'pn_mlp64.hip', 'gram.hip', 'points_gather.hip', 'crop_resize.hip', 'small_kernels.hip', 'backward.hip']
+           'gemm_ares.hip', 'gemm_wres.hip', 'pn_mlp64.hip', 'gram.hip', 'points_gather.hip', 'crop_resize.hip', 'small_kernels.hip', 'backward.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 HIPFLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
 

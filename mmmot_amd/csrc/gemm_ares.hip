@@ -15,6 +15,7 @@
 // stage), the per-tile epilogue is register-only (each wave owns 64 rows x 32 channels: column sums by
 // lane-half shuffle, statistics centred on the wave's own 64-row mean), nothing but the partials is stored.
 // Arithmetic: fp16 matrix cores with the 3-term hi/lo split (same as gemm_rows F16 / conv3x3_hl16).
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -178,6 +179,8 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
 
   // per-tile epilogue state (set by begin_tile)
   int nrows = 0, nsub = 0, grp = 0;
+  int lim = 0;  // accumulator element (tm, e) is a valid row <=> tm * 32 + (e & 3) + 8 * (e >> 2) < lim (immediates
+                // against one register instead of 32 hoisted row indices)
   float inv_nsub = 0.f;
   long prow = 0;
   bool full = false;
@@ -205,6 +208,7 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
     inv_nsub = nsub > 0 ? 1.f / (float)nsub : 0.f;
     prow = (long)(2 * tt + wm);
     full = (nsub == 64);
+    lim = nrows - (wm * 64 + 4 * (lane >> 5));
   };
   begin_tile(cur, t);
 
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
           for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-              if (wm * 64 + tm * 32 + mm_acc_row(e, lane) < nrows) s1 += acc[tm][e];
+              if (tm * 32 + (e & 3) + 8 * (e >> 2) < lim) s1 += acc[tm][e];
         }
         s1 += __shfl_xor(s1, 32);
         const float mu = s1 * inv_nsub;  // mean of the raw accumulators over the half tile
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
               const float d = acc[tm][e] - mu;
-              if (wm * 64 + tm * 32 + mm_acc_row(e, lane) < nrows) s2 = fmaf(d, d, s2);
+              if (tm * 32 + (e & 3) + 8 * (e >> 2) < lim) s2 = fmaf(d, d, s2);
             }
         }
         s2 += __shfl_xor(s2, 32);
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
           for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-              if (wm * 64 + tm * 32 + mm_acc_row(e, lane) < nrows) s3 += fmaxf(fmaf(acc[tm][e], m1, m0), 0.f);
+              if (tm * 32 + (e & 3) + 8 * (e >> 2) < lim) s3 += fmaxf(fmaf(acc[tm][e], m1, m0), 0.f);
         }
         s3 += __shfl_xor(s3, 32);
         if (lane < 32) a.colsum[prow * a.N + n] = s3;
@@ -375,6 +379,8 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
   }
 }
 
+int mmmot_gemm_wres64_launch(const mmmot_gemm_ares_args* a, int mode, int n_cu, hipStream_t s);  // gemm_wres.hip
+
 extern "C" int mmmot_gemm_ares(const mmmot_gemm_ares_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!a || !a->X || !a->W || !a->sc || !a->sh || !a->tile_row0 || !a->tile_nrows || a->T <= 0) return MMMOT_EINVAL;
@@ -393,6 +399,14 @@ extern "C" int mmmot_gemm_ares(const mmmot_gemm_ares_args* a, void* stream) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MMMOT_EINVAL;
     n_cu = prop.multiProcessorCount;
   }
+  // K = 64 with the whole weight matrix in LDS (N <= 512): the weight-resident kernel; MMMOT_ARES_WRES=0 keeps the
+  // streaming kernel (A/B timing, tools/bench_pointnet.py)
+  static int use_wres = -1;
+  if (use_wres < 0) {
+    const char* e = getenv("MMMOT_ARES_WRES");
+    use_wres = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (use_wres && a->K == 64 && a->N <= 512) return mmmot_gemm_wres64_launch(a, mode, n_cu, s);
   const int grid = a->T < n_cu ? a->T : n_cu;  // persistent: one workgroup per CU
 #define AR_LAUNCH(KSV, MODEV) \
   hipLaunchKernelGGL((gemm_ares_kernel<KSV, MODEV>), dim3(grid), dim3(AR_THREADS), 0, s, *a)

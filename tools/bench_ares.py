@@ -19,6 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--rows', type=int, default=1 << 20)
     ap.add_argument('--k', type=int, default=128)
+    ap.add_argument('--n', type=int, nargs='*', default=[128, 256, 512, 1024])
     a = ap.parse_args()
     ops = HipOps()
     R, K = a.rows, a.k
@@ -27,7 +28,7 @@ def main():
     sc, sh = torch.ones(1, K).cuda(), torch.zeros(1, K).cuda()
     tiles = RowTiles([R], 'cuda')
     half = HalfTiles(tiles, 'cuda')
-    for N in (128, 256, 512, 1024):
+    for N in a.n:
         W = torch.randn(N, K, generator=g) * K ** -0.5
         shift = hl16_weight_shift(W)
         W16 = to_hl16(W.double() * 2.0 ** shift).cuda()
