@@ -161,7 +161,7 @@ __device__ __forceinline__ void pt_row_to_pixel(int g, int i, int& blk, int& y, 
 // the K loop, 3 = no fragment reads in the K loop, 4 = no MFMAs, 5 = no epilogue at all, 6 = epilogue without
 // the global stores
 // FUSE1: the layer's input is not read from memory but COMPUTED: conv1_1 (3 -> 64, folded BN, ReLU) of the
-// raw crops is evaluated for the 18x18 haloed patch of every tile in the prologue (a 352 x 64 x 32 mini-GEMM on
+// raw crops is evaluated for the 18x18 haloed patch of every tile in the prologue (a 336 x 64 x 32 mini-GEMM on
 // the matrix cores: K = 27 taps*colours padded to 32) and written straight into the two LDS patch buffers
 // (Cin = 64 = both 32-channel slabs).  The [L][H][W][64] conv1_1 tensor (537 MB per cfg3 pair: written once,
 // read 1.3x) never exists.  Requires BN = 64, BS = 16, Cin = Cout = 64.
@@ -236,28 +236,26 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   // of a channel tile stay in that XCD's L2) and its workgroups take the chunk's tiles round-robin.  One
   // launch-time workgroup per tile would leave the CU idle for a dispatch latency between tiles: with a
   // single resident workgroup nothing overlaps it (measured: fixed cost of ~2 channel slabs per tile).
-  // FUSE1: conv1_1 weight fragments (B operand: channel lr + 32*nt, k = 16j + 8h ..+7) stay in registers for
-  // the whole (persistent) kernel; the raw-window offsets of the 16 k values a lane gathers are fixed too
-  f16x8 w1h[2][2], w1l[2][2];
-  int roff[2][8];
+  // FUSE1: conv1_1 weight fragments (A operand of v_mfma_f32_16x16x32_f16: channel 16 mb + (lane & 15),
+  // k = 8 (lane >> 4) .. + 7 - the whole K = 32 in one step) stay in registers for the whole (persistent) kernel;
+  // the raw-window offsets of the 8 k values a lane gathers are fixed too (k >= 27: offset 0 - the weight is zero
+  // and the window value finite, so the gather needs no branch)
+  f16x8 w1h[4], w1l[4];
+  int roff[8];
   if constexpr (FUSE1) {
-    const int l31 = threadIdx.x & 31, hh = (threadIdx.x & 63) >> 5;
+    const int l15 = threadIdx.x & 15, kg1 = (threadIdx.x & 63) >> 4;
 #pragma unroll
-    for (int nt1 = 0; nt1 < 2; ++nt1)
+    for (int mb = 0; mb < 4; ++mb) {
+      const u32x4* p = fz.w1 + ((mb * 16 + l15) * 4 + kg1) * 2;
+      w1h[mb] = __builtin_bit_cast(f16x8, p[0]);
+      w1l[mb] = __builtin_bit_cast(f16x8, p[1]);
+    }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const u32x4* p = fz.w1 + ((nt1 * 32 + l31) * 4 + (2 * j + hh)) * 2;
-        w1h[nt1][j] = __builtin_bit_cast(f16x8, p[0]);
-        w1l[nt1][j] = __builtin_bit_cast(f16x8, p[1]);
-      }
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int k = 16 * j + 8 * hh + e;
-        const int tap = k / 3, c = k - 3 * tap;
-        roff[j][e] = (k < 27) ? c * 400 + (tap / 3) * 20 + (tap % 3) : -1;
-      }
+    for (int e = 0; e < 8; ++e) {
+      const int k = 8 * kg1 + e;
+      const int tap = k / 3, c = k - 3 * tap;
+      roff[e] = (k < 27) ? c * 400 + (tap / 3) * 20 + (tap % 3) : 0;
+    }
   }
   const int nitems = ntm * ntn;
   const int xq = nitems >> 3, xr = nitems & 7;
@@ -596,37 +594,33 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     if (tid < 64) R[1200 + tid] = fz.bias1[tid];
     __syncthreads();
     // ---- conv1_1 on the 324 patch pixels as C^T = W1 X^T: MFMA rows = channels, columns = pixels, so a lane
-    // ends up with ONE pixel (lane & 31 of pixel tile g) and, per 8-channel unit, 4 consecutive channels: its
+    // ends up with ONE pixel (lane & 15 of pixel tile g) and, per 16-channel block, 4 consecutive channels: their
     // hi and lo halves leave as two 8-byte LDS stores and all per-pixel work (coordinates, swizzle, image
-    // mask) is done once per lane.  11 pixel tiles of 32: waves take g = wave, wave + 8. ----
+    // mask) is done once per lane.  16-pixel tiles (16x16x32 MFMA, K = 32 in one step): 21 tiles over 8 waves =
+    // at most 3 per wave (32-pixel tiles: 11 tiles, two waves' worth of work for waves 0-2 while 3-7 wait). ----
     const float* B1 = reinterpret_cast<const float*>(smem + RAW_OFF + 4800);  // conv1_1 bias [64] (staged above)
     float c11max = 0.f;  // range guard of the conv1_1 outputs (pt_range[2])
+    const int l15 = lane & 15, kg1 = lane >> 4;
 #pragma nounroll
-    for (int g = wave; g < (EXP == 8 ? 0 : 11); g += 8) {  // EXP 8: timing experiment without the conv1_1 prologue
-      const int n = g * 32 + lr;  // this lane's patch pixel
-      const int ppy = n / 18, ppx = n - ppy * 18;
+    for (int g = wave; g < (EXP == 8 ? 0 : 21); g += 8) {  // EXP 8: timing experiment without the conv1_1 prologue
+      const int n = g * 16 + l15;  // this lane's patch pixel
+      const int nc = n < 324 ? n : 323;
+      const int ppy = nc / 18, ppx = nc - ppy * 18;
       const int rbase = ppy * 20 + ppx;  // window position of tap (0,0)
-      f32x16 c1[2];
+      f16x8 xh, xl;
 #pragma unroll
-      for (int nt1 = 0; nt1 < 2; ++nt1)
+      for (int e = 0; e < 8; ++e) {
+        const float v = R[rbase + roff[e]];
+        xh[e] = (_Float16)v;
+        xl[e] = (_Float16)(v - (float)xh[e]);
+      }
+      f32x4 c1[4];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) c1[nt1][e] = 0.f;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        f16x8 xh, xl;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float v = 0.f;
-          if (n < 324 && roff[j][e] >= 0) v = R[rbase + roff[j][e]];
-          xh[e] = (_Float16)v;
-          xl[e] = (_Float16)(v - (float)xh[e]);
-        }
-#pragma unroll
-        for (int nt1 = 0; nt1 < 2; ++nt1) {
-          c1[nt1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1l[nt1][j], xh, c1[nt1], 0, 0, 0);
-          c1[nt1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h[nt1][j], xl, c1[nt1], 0, 0, 0);
-          c1[nt1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h[nt1][j], xh, c1[nt1], 0, 0, 0);
-        }
+      for (int mb = 0; mb < 4; ++mb) {
+        c1[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        c1[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1l[mb], xh, c1[mb], 0, 0, 0);
+        c1[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[mb], xl, c1[mb], 0, 0, 0);
+        c1[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[mb], xh, c1[mb], 0, 0, 0);
       }
       if (n < 324) {
         // bias + ReLU; zero outside the image (conv1_2's zero padding applies to conv1_1's OUTPUT)
@@ -634,43 +628,41 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
         const bool inimg = (b0 < nblk) && ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
         const int sw = pt_swz_a(ppy, ppx);
         typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        const int hh = kg1 & 1;  // which half (4 channels) of an 8-channel unit
 #pragma unroll
-        for (int nt1 = 0; nt1 < 2; ++nt1) {
-          const int pb = (nt1 == 0 ? pcur : pnext) + n * P_ROWB + h * 8;  // 32-channel slab nt1, this pixel's record
+        for (int mb = 0; mb < 4; ++mb) {  // channels 16 mb + 4 kg1 .. + 3 = slab mb >> 1, unit q, half hh
+          const int q = (mb & 1) * 2 + (kg1 >> 1);
+          const int rb = ((mb >> 1) == 0 ? pcur : pnext) + n * P_ROWB;  // this pixel's record in slab mb >> 1
+          const f32x4 bq = *reinterpret_cast<const f32x4*>(&B1[mb * 16 + 4 * kg1]);
+          f16x4 hi, lo;
+          float vv[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {  // unit q of the slab: channels 8q + 4h .. + 3 are registers 4q .. 4q+3
-            const f32x4 bq = *reinterpret_cast<const f32x4*>(&B1[nt1 * 32 + 8 * q + 4 * h]);
-            f16x4 hi, lo;
-            float vv[4];
+          for (int r = 0; r < 4; ++r) {
+            float v = fmaxf(fmaf(c1[mb][r], fz.oscale1, bq[r]), 0.f);
+            if (!inimg) v = 0.f;
+            c11max = fmaxf(c11max, v);
+            v = fminf(v, 65000.f);
+            vv[r] = v;
+            hi[r] = (_Float16)v;
+            lo[r] = (_Float16)(v - (float)hi[r]);
+          }
+          if constexpr (Q8) {
+            // record = [fp16 hi: pieces 0..3 | e4m3(a/4): pieces 4,5 | e4m3(a_lo*512): pieces 6,7]
+            *reinterpret_cast<f16x4*>(smem + rb + ((q ^ sw) << 4) + 8 * hh) = hi;
+            int pa = 0, pl = 0;
+            pa = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(vv[0] * 0.25f, 448.f), fminf(vv[1] * 0.25f, 448.f), pa, false);
+            pa = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(vv[2] * 0.25f, 448.f), fminf(vv[3] * 0.25f, 448.f), pa, true);
+            float ll[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float v = fmaxf(fmaf(c1[nt1][4 * q + r], fz.oscale1, bq[r]), 0.f);
-              if (!inimg) v = 0.f;
-              c11max = fmaxf(c11max, v);
-              v = fminf(v, 65000.f);
-              vv[r] = v;
-              hi[r] = (_Float16)v;
-              lo[r] = (_Float16)(v - (float)hi[r]);
-            }
-            if constexpr (Q8) {
-              // record = [fp16 hi: pieces 0..3 | e4m3(a/4): pieces 4,5 | e4m3(a_lo*512): pieces 6,7]
-              const int rb = (nt1 == 0 ? pcur : pnext) + n * P_ROWB;
-              *reinterpret_cast<f16x4*>(smem + rb + ((q ^ sw) << 4) + 8 * h) = hi;
-              int pa = 0, pl = 0;
-              pa = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(vv[0] * 0.25f, 448.f), fminf(vv[1] * 0.25f, 448.f), pa, false);
-              pa = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(vv[2] * 0.25f, 448.f), fminf(vv[3] * 0.25f, 448.f), pa, true);
-              float ll[4];
-#pragma unroll
-              for (int r = 0; r < 4; ++r) ll[r] = __builtin_amdgcn_fmed3f((vv[r] - (float)hi[r]) * 512.f, -448.f, 448.f);
-              pl = __builtin_amdgcn_cvt_pk_fp8_f32(ll[0], ll[1], pl, false);
-              pl = __builtin_amdgcn_cvt_pk_fp8_f32(ll[2], ll[3], pl, true);
-              const int bo = 8 * (q & 1) + 4 * h;  // byte of channel 8q + 4h inside its 16-channel piece
-              *reinterpret_cast<int*>(smem + rb + (((4 + (q >> 1)) ^ sw) << 4) + bo) = pa;
-              *reinterpret_cast<int*>(smem + rb + (((6 + (q >> 1)) ^ sw) << 4) + bo) = pl;
-            } else {
-              *reinterpret_cast<f16x4*>(smem + pb + (((2 * q) ^ sw) << 4)) = hi;
-              *reinterpret_cast<f16x4*>(smem + pb + (((2 * q + 1) ^ sw) << 4)) = lo;
-            }
+            for (int r = 0; r < 4; ++r) ll[r] = __builtin_amdgcn_fmed3f((vv[r] - (float)hi[r]) * 512.f, -448.f, 448.f);
+            pl = __builtin_amdgcn_cvt_pk_fp8_f32(ll[0], ll[1], pl, false);
+            pl = __builtin_amdgcn_cvt_pk_fp8_f32(ll[2], ll[3], pl, true);
+            const int bo = 8 * (q & 1) + 4 * hh;  // byte of channel 8q + 4hh inside its 16-channel piece
+            *reinterpret_cast<int*>(smem + rb + (((4 + (q >> 1)) ^ sw) << 4) + bo) = pa;
+            *reinterpret_cast<int*>(smem + rb + (((6 + (q >> 1)) ^ sw) << 4) + bo) = pl;
+          } else {
+            *reinterpret_cast<f16x4*>(smem + rb + hh * 8 + (((2 * q) ^ sw) << 4)) = hi;
+            *reinterpret_cast<f16x4*>(smem + rb + hh * 8 + (((2 * q + 1) ^ sw) << 4)) = lo;
           }
         }
       }

@@ -57,6 +57,11 @@ class Engine:
         self.pn_gram = os.environ.get('MMMOT_PN_GRAM', '1') != '0'
         # conv2..conv4 (K = 64) from the persistent weight-resident kernel (pn_mlp64.hip) instead of the generic row GEMM
         self.pn_mlp64 = os.environ.get('MMMOT_PN_MLP64', '1') != '0'
+        # LiDAR branch on a side stream next to the trunk: opt-in (MMMOT_TWO_STREAMS=1).  Measured (profiles/README.md
+        # r02): cfg3 x 8 pairs 275.3 -> 276.0 pairs/s (noise) while every trunk launch's own duration grows by the time
+        # it waits for CUs; B = 1 hipGraph replay 2.85 -> 2.71 ms, eager latency unchanged.
+        self.two_streams = os.environ.get('MMMOT_TWO_STREAMS', '0') == '1'
+        self._side = {}
         # conv1_1 evaluated inside conv1_2's patch prologue (MMMOT_FUSE_CONV1=0: two launches)
         self.fuse_conv1 = os.environ.get('MMMOT_FUSE_CONV1', '1') != '0'
         # f16q8 applies to crops of at least this side; smaller crops run the f16x3 trunk.  The e4m3 correction
@@ -116,6 +121,13 @@ class Engine:
             self.ops.gemm(d[name + '_h16'], tiles, N, K, w_hl16=True, oscale=d[name + '_os'], **kw)
         else:
             self.ops.gemm(d[name], tiles, N, K, **kw)
+
+    def _side_stream(self, dev):
+        key = str(dev)
+        st = self._side.get(key)
+        if st is None:
+            st = self._side[key] = torch.cuda.Stream(device=dev)
+        return st
 
     def _part(self, tiles, N):
         return self.buf('part', tiles.T, 2, N)
@@ -468,15 +480,31 @@ class Engine:
         self.dev = dev
         Lt = plan.Lt
         cat = self.buf('cat', Lt, 1024)
-        if need_img:
-            if crops is None or tuple(crops.shape) != (Lt, 3, plan.S, plan.S) or not crops.is_contiguous():
-                raise ValueError('crops must be a contiguous [%d,3,%d,%d] tensor' % (Lt, plan.S, plan.S))
-            self._guarded_appearance(plan, crops, cat)
+        if need_img and (crops is None or tuple(crops.shape) != (Lt, 3, plan.S, plan.S) or not crops.is_contiguous()):
+            raise ValueError('crops must be a contiguous [%d,3,%d,%d] tensor' % (Lt, plan.S, plan.S))
         if need_pts:
             kin = int(self.P['pointnet']['w1'].shape[1])  # 3 (xyz) or 4 (xyz + reflectivity)
             if points is None or tuple(points.shape) != (plan.P, kin) or not points.is_contiguous():
                 raise ValueError('points must be a contiguous [%d,%d] tensor' % (plan.P, kin))
-            self.pointnet(plan, points, cat)
+        # The two branches meet only in `cat` (disjoint column halves, disjoint workspace buffers), so the LiDAR branch
+        # can run on a side stream (two_streams, opt-in): the trunk's persistent workgroups fill every CU (one per CU,
+        # all its LDS and registers) - the branches never share a CU, only PointNet's small-grid launches and the
+        # uneven tail of a trunk layer leave CUs to the other stream.  Fork / join are events: capturable in a hipGraph.
+        side = None
+        if need_img and need_pts and self.two_streams and dev.type == 'cuda' and hasattr(self.ops, 'on_stream'):
+            side = self._side_stream(dev)
+        if side is not None:
+            main = torch.cuda.current_stream(dev)
+            side.wait_stream(main)  # inputs (and the previous forward's readers of the workspace) are ordered before
+            with self.ops.on_stream(side):
+                self.pointnet(plan, points, cat)
+            self._guarded_appearance(plan, crops, cat)
+            main.wait_stream(side)
+        else:
+            if need_img:
+                self._guarded_appearance(plan, crops, cat)
+            if need_pts:
+                self.pointnet(plan, points, cat)
         F = self.buf('F', plan.nR, Lt, 512)
         if rows == (0, 1, 2):
             self.fuse(plan, cat, F)

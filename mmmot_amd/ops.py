@@ -84,6 +84,18 @@ class HipOps:
         finally:
             self._pinned_stream = prev
 
+    @contextlib.contextmanager
+    def on_stream(self, stream):
+        """Launch on ``stream`` (a torch.cuda.Stream) inside the block - the LiDAR branch of a two-stream forward -
+        whatever stream the surrounding ``on_current_stream`` block pinned."""
+        prev = self._pinned_stream
+        self._pinned_stream = stream.cuda_stream
+        try:
+            with torch.cuda.stream(stream):
+                yield
+        finally:
+            self._pinned_stream = prev
+
     def conv3x3(self, inp, wp, bias, out, L, H, W, Cin, Cout, first, pool):
         st = self.lib.mmmot_conv3x3_bn_relu(_ptr(inp), _ptr(wp), _ptr(bias), _ptr(out), L, H, W, Cin, Cout,
                                             int(first), int(pool), self._stream())

@@ -24,23 +24,25 @@ def main():
     w2 = torch.randn(9, 64, 64, generator=g) * (2.0 / 576) ** 0.5
     s1, s2 = hl16_weight_shift(w1), hl16_weight_shift(w2)
     w1h, w2q = to_hl16(w1.double() * 2.0 ** s1).cuda(), to_hq8_w(w2.double() * 2.0 ** s2).cuda()
+    w2h = to_hl16(w2.double() * 2.0 ** s2).cuda()  # the f16x3 launch (default arithmetic)
     b = torch.zeros(64).cuda()
     out = torch.empty(L * (H // 2) * (W // 2), 64).cuda()
-    res = {}
-    for r in range(8):
-        for v in (0, 4, 6, 8):
-            lib.mmmot_set_patch_variant(v)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            ops.conv1_fused_hq8(crops, w1h, b, 2.0 ** -s1, w2q, b, 2.0 ** -s2, out, L, H, W)
-            e1.record()
-            torch.cuda.synchronize()
-            if r:
-                res.setdefault(v, []).append(e0.elapsed_time(e1))
-    lib.mmmot_set_patch_variant(0)
-    for v, ts in res.items():
-        ts.sort()
-        print('variant %d: %.3f ms' % (v, ts[len(ts) // 2]))
+    for name, fn, w2 in (('hq8', ops.conv1_fused_hq8, w2q), ('hl16', ops.conv1_fused_hl16, w2h)):
+        res = {}
+        for r in range(8):
+            for v in (0, 4, 6, 8):
+                lib.mmmot_set_patch_variant(v)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn(crops, w1h, b, 2.0 ** -s1, w2, b, 2.0 ** -s2, out, L, H, W)
+                e1.record()
+                torch.cuda.synchronize()
+                if r:
+                    res.setdefault(v, []).append(e0.elapsed_time(e1))
+        lib.mmmot_set_patch_variant(0)
+        for v, ts in res.items():
+            ts.sort()
+            print('%s variant %d: %.3f ms' % (name, v, ts[len(ts) // 2]))
 
 
 if __name__ == '__main__':
