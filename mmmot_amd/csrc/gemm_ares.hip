@@ -61,13 +61,27 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
     TileMeta m;
     m.row0 = a.tile_row0[tt];
     m.nrows = a.tile_nrows[tt];
-    m.grp = a.tile_group ? a.tile_group[tt] : 0;
-    m.dbrow = a.dbias ? a.tile_dbrow[tt] : 0;
+    // unconditional loads (an absent table reads tile_row0 instead, discarded in scalar()): a conditional load makes
+    // the number of loads in flight path-dependent and turns later counted waits into vmcnt(0)
+    m.grp = (a.tile_group ? a.tile_group : a.tile_row0)[tt];
+    m.dbrow = (a.dbias ? a.tile_dbrow : a.tile_row0)[tt];
+    return m;
+  };
+  // the table words are wave-uniform: held as scalars, and those of tile t + 2 * gridDim.x are requested a whole tile
+  // before they are needed (a lookup at the tile switch is two dependent L2 round trips in front of the switch, and
+  // its vmcnt(0) also drains the two weight stages that are meant to stay in flight)
+  auto scalar = [&](const TileMeta& v) {
+    TileMeta m;
+    m.row0 = __builtin_amdgcn_readfirstlane(v.row0);
+    m.nrows = __builtin_amdgcn_readfirstlane(v.nrows);
+    m.grp = a.tile_group ? __builtin_amdgcn_readfirstlane(v.grp) : 0;
+    m.dbrow = a.dbias ? __builtin_amdgcn_readfirstlane(v.dbrow) : 0;
     return m;
   };
   int t = blockIdx.x;
   if (t >= a.T) return;
-  TileMeta cur = meta_of(t);
+  const int gstep = gridDim.x;
+  TileMeta cur = scalar(meta_of(t));
 
   // ---- wave roles.  vmcnt retires in order PER WAVE: activation rows (HBM, a CU completes only ~30 line misses
   // per microsecond) requested by a wave that also stages weights sit in front of every weight-stage wait, and
@@ -157,226 +171,242 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
     load_x(cur);
     stage_a(cur);
   }
-  // weight stages: s -> register slot s & 1; two stages of global loads are always in flight (one LDS
-  // stage of latency is not enough: the L2 round trip under load is longer than a 24-MFMA stage)
-  auto prime_w = [&]() {
-    if (wspec) {
-      load_w(0, S0{});
-      load_w(1 % NS, S1{});
-      store_w(0, S0{});
-      load_w(2 % NS, S0{});
-    }
-    __syncthreads();
-  };
-  prime_w();
-  const bool wrap_ok = (NS % 2) == 0;  // the LDS buffer parity of stage 0 repeats only for even NS
+  // Everything from here on is compiled TWICE, once per wave role (WS: weight-streaming waves 0-3 / row-fetching waves
+  // 4-7), and a wave enters its own copy: with the role a compile-time constant every copy has a FIXED number of global
+  // loads in flight, so the waits in front of the per-channel constants are counted (vmcnt(16) in the weight waves)
+  // instead of vmcnt(0) - which drained both weight stages in flight at the end of every channel tile.  Both copies
+  // execute the same sequence of barriers.
+  auto run = [&](auto WSC) {
+    constexpr bool WS = decltype(WSC)::value;
+    // weight stages: s -> register slot s & 1; two stages of global loads are always in flight (one LDS
+    // stage of latency is not enough: the L2 round trip under load is longer than a 24-MFMA stage)
+    auto prime_w = [&]() {
+      if constexpr (WS) {
+        load_w(0, S0{});
+        load_w(1 % NS, S1{});
+        store_w(0, S0{});
+        load_w(2 % NS, S0{});
+      }
+      __syncthreads();
+    };
+    prime_w();
+    const bool wrap_ok = (NS % 2) == 0;  // the LDS buffer parity of stage 0 repeats only for even NS
 
-  f32x16 acc[2];
-#pragma unroll
-  for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[tm][e] = 0.f;
+    f32x16 acc[2];
+  #pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+  #pragma unroll
+      for (int e = 0; e < 16; ++e) acc[tm][e] = 0.f;
 
-  // per-tile epilogue state (set by begin_tile)
-  int nrows = 0, nsub = 0, grp = 0;
-  int lim = 0;  // accumulator element (tm, e) is a valid row <=> tm * 32 + (e & 3) + 8 * (e >> 2) < lim (immediates
-                // against one register instead of 32 hoisted row indices)
-  float inv_nsub = 0.f;
-  long prow = 0;
-  bool full = false;
-  const float* pbias = a.bias ? a.bias : ar_zeros;
-  // per-channel epilogue constants of a channel tile: combined bias, output scale / shift.  They are
-  // loaded one channel tile ahead (for the last channel tile: those of the NEXT row tile) and BEFORE the
-  // weight loads of that stage: vmcnt retires in order, so a load issued at epilogue time would also wait
-  // for the two weight stages in flight.
-  auto epi_consts = [&](const TileMeta& m, int nt, float& cb, float& os, float& oh) {
-    const int n = nt * AR_BN + wn * 32 + lr;
-    const float* pdb = a.dbias ? a.dbias + (long)m.dbrow * a.lddb : ar_zeros;
-    const float* posc = (MODE & 2) ? a.osc + (long)m.grp * a.ldosc : ar_zeros;
-    const float* posh = (MODE & 2) ? a.osh + (long)m.grp * a.ldosc : ar_zeros;
-    cb = pbias[n] + pdb[n];
-    os = posc[n];
-    oh = posh[n];
-  };
-  float cbc, osc_c, osh_c, cbn = 0.f, osc_n = 0.f, osh_n = 0.f;
-  epi_consts(cur, 0, cbc, osc_c, osh_c);
-  TileMeta nxt = cur;
-  auto begin_tile = [&](const TileMeta& m, int tt) {
-    nrows = m.nrows;
-    grp = m.grp;
-    nsub = min(max(nrows - 64 * wm, 0), 64);  // valid rows of this wave's half tile
-    inv_nsub = nsub > 0 ? 1.f / (float)nsub : 0.f;
-    prow = (long)(2 * tt + wm);
-    full = (nsub == 64);
-    lim = nrows - (wm * 64 + 4 * (lane >> 5));
-  };
-  begin_tile(cur, t);
-
-  auto stage = [&](int s, auto ODD) {
-    constexpr int odd = decltype(ODD)::value;  // s & 1
-    constexpr int ks = (KS == 2) ? odd : 0;  // NS is a multiple of KS and stages alternate
-    const int nt = s / KS;
-    if constexpr (ks == 0) {
-      const bool last_nt = nt + 1 >= ntn;  // then: first channel tile of the next row tile (same loads, other rows)
-      TileMeta m = cur;
-      if (last_nt) m = nxt;
-      // (handing these constants from waves 0-3 to waves 4-7 through LDS, so that they do not queue behind the
-      // activation rows, measured slower than loading them in every wave)
-      epi_consts(m, last_nt ? 0 : nt + 1, cbn, osc_n, osh_n);
-    }
-    // stage s+1 (register slot !odd) -> the other LDS buffer (last read in stage s-1, every wave is past
-    // that barrier); then its slot takes the loads of stage s+3
-    if (wspec) {
-      store_w(1 - odd, std::integral_constant<int, 1 - odd>{});
-      load_w((s + 3) % NS, std::integral_constant<int, 1 - odd>{});  // wraps into the next row tile
-    }
-    // Four 16-channel steps; the fragments of step j+1 are read while the six MFMAs of step j issue, one
-    // read per MFMA (sched_barrier pins the order): the two waves of a SIMD run in lockstep after every
-    // barrier, so an LDS round trip that is not covered by this wave's own MFMAs is idle matrix-pipe time.
-    const _Float16* ah = &As[ks][0][0];
-    const _Float16* al = &As[ks][1][0];
-    const _Float16* bh = &Bs[odd][0][0];
-    const _Float16* bl = &Bs[odd][1][0];
-    const int offa0 = (wm * 64 + lr) * AR_LDT + kh, offa1 = offa0 + 32 * AR_LDT;
-    const int offb = (wn * 32 + lr) * AR_LDT + kh;
-    struct Fr {
-      f16x8 v[6];  // ah0, al0, ah1, al1, bh, bl
-    };
-    auto rd1 = [&](Fr& f, auto JC, auto RC) {
-      constexpr int j = decltype(JC)::value, r = decltype(RC)::value;
-      if constexpr (r == 0) f.v[0] = *reinterpret_cast<const f16x8*>(ah + offa0 + j * 16);
-      if constexpr (r == 1) f.v[1] = *reinterpret_cast<const f16x8*>(al + offa0 + j * 16);
-      if constexpr (r == 2) f.v[2] = *reinterpret_cast<const f16x8*>(ah + offa1 + j * 16);
-      if constexpr (r == 3) f.v[3] = *reinterpret_cast<const f16x8*>(al + offa1 + j * 16);
-      if constexpr (r == 4) f.v[4] = *reinterpret_cast<const f16x8*>(bh + offb + j * 16);
-      if constexpr (r == 5) f.v[5] = *reinterpret_cast<const f16x8*>(bl + offb + j * 16);
-    };
-    auto mm1 = [&](const Fr& f, auto IC) {  // term-major: consecutive MFMAs alternate between the two accumulators
-      constexpr int i = decltype(IC)::value;
-      constexpr int tm = i & 1, term = i >> 1;
-      if constexpr (term == 0) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.v[2 * tm + 1], f.v[4], acc[tm], 0, 0, 0);
-      if constexpr (term == 1) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.v[2 * tm], f.v[5], acc[tm], 0, 0, 0);
-      if constexpr (term == 2) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.v[2 * tm], f.v[4], acc[tm], 0, 0, 0);
-    };
-    auto step = [&](const Fr& cur, Fr& nxt, auto JN) {  // MFMAs of the current step, reads of step JN underneath
-      constexpr int jn = decltype(JN)::value;
-#define AR_PAIR(I)                                                   \
-  mm1(cur, std::integral_constant<int, I>{});                        \
-  __builtin_amdgcn_sched_barrier(0);                                 \
-  if constexpr (jn < 4) {                                            \
-    rd1(nxt, JN, std::integral_constant<int, I>{});                  \
-    __builtin_amdgcn_sched_barrier(0);                               \
-  }
-      AR_PAIR(0) AR_PAIR(1) AR_PAIR(2) AR_PAIR(3) AR_PAIR(4) AR_PAIR(5)
-#undef AR_PAIR
-    };
-    Fr f0, f1;
-    rd1(f0, S0{}, std::integral_constant<int, 0>{});
-    rd1(f0, S0{}, std::integral_constant<int, 1>{});
-    rd1(f0, S0{}, std::integral_constant<int, 2>{});
-    rd1(f0, S0{}, std::integral_constant<int, 3>{});
-    rd1(f0, S0{}, std::integral_constant<int, 4>{});
-    rd1(f0, S0{}, std::integral_constant<int, 5>{});
-    __builtin_amdgcn_sched_barrier(0);
-    step(f0, f1, std::integral_constant<int, 1>{});
-    step(f1, f0, std::integral_constant<int, 2>{});
-    step(f0, f1, std::integral_constant<int, 3>{});
-    step(f1, f0, std::integral_constant<int, 4>{});
-    if constexpr (ks == KS - 1) {
-      // ---- channel tile nt finished: register-only epilogue for this wave's 64 rows x 32 channels ----
-      // v = acc*oscale + cb is never formed for full half tiles: the sums are taken on the raw accumulators
-      // and rescaled (S = oscale*sum(acc) + n*cb, M2 = oscale^2 * M2(acc), relu(v*os+oh) = relu(acc*(oscale*os)
-      // + (cb*os+oh))); 3 VALU ops per value.
+    // per-tile epilogue state (set by begin_tile)
+    int nrows = 0, nsub = 0, grp = 0;
+    int lim = 0;  // accumulator element (tm, e) is a valid row <=> tm * 32 + (e & 3) + 8 * (e >> 2) < lim (immediates
+                  // against one register instead of 32 hoisted row indices)
+    float inv_nsub = 0.f;
+    long prow = 0;
+    bool full = false;
+    const float* pbias = a.bias ? a.bias : ar_zeros;
+    // per-channel epilogue constants of a channel tile: combined bias, output scale / shift.  They are
+    // loaded one channel tile ahead (for the last channel tile: those of the NEXT row tile) and BEFORE the
+    // weight loads of that stage: vmcnt retires in order, so a load issued at epilogue time would also wait
+    // for the two weight stages in flight.
+    auto epi_consts = [&](const TileMeta& m, int nt, float& cb, float& os, float& oh) {
       const int n = nt * AR_BN + wn * 32 + lr;
-      const float cb = cbc, os = osc_c, oh = osh_c;  // fetched one channel tile ahead (see below)
-      if constexpr (MODE & 1) {
-        float s1 = 0.f;
-        if (full) {
-#pragma unroll
-          for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) s1 += acc[tm][e];
-        } else {
-#pragma unroll
-          for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-              if (tm * 32 + (e & 3) + 8 * (e >> 2) < lim) s1 += acc[tm][e];
-        }
-        s1 += __shfl_xor(s1, 32);
-        const float mu = s1 * inv_nsub;  // mean of the raw accumulators over the half tile
-        float s2 = 0.f;
-        if (full) {
-#pragma unroll
-          for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              const float d = acc[tm][e] - mu;
-              s2 = fmaf(d, d, s2);
-            }
-        } else {
-#pragma unroll
-          for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              const float d = acc[tm][e] - mu;
-              if (tm * 32 + (e & 3) + 8 * (e >> 2) < lim) s2 = fmaf(d, d, s2);
-            }
-        }
-        s2 += __shfl_xor(s2, 32);
-        if (lane < 32) {
-          a.part[(prow * 2 + 0) * a.N + n] = fmaf(s1, a.oscale, (float)nsub * cb);
-          a.part[(prow * 2 + 1) * a.N + n] = s2 * a.oscale * a.oscale;
-        }
-      }
-      if constexpr (MODE & 2) {
-        const float m1 = a.oscale * os, m0 = fmaf(cb, os, oh);
-        float s3 = 0.f;
-        if (full) {
-#pragma unroll
-          for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) s3 += fmaxf(fmaf(acc[tm][e], m1, m0), 0.f);
-        } else {
-#pragma unroll
-          for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-              if (tm * 32 + (e & 3) + 8 * (e >> 2) < lim) s3 += fmaxf(fmaf(acc[tm][e], m1, m0), 0.f);
-        }
-        s3 += __shfl_xor(s3, 32);
-        if (lane < 32) a.colsum[prow * a.N + n] = s3;
-      }
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[tm][e] = 0.f;
-      cbc = cbn;
-      osc_c = osc_n;
-      osh_c = osh_n;
-    }
-    __syncthreads();
-  };
-  for (;;) {
-    const int tn = t + gridDim.x;
-    const bool more = tn < a.T;
-    if (more) nxt = meta_of(tn);
-    // the next tile's rows are requested at the first stage of this tile (waves 4-7: nothing else in their queue
-    // but the small per-channel constants)
-    for (int s = 0; s < NS; s += 2) {
-      if (more && !wspec && s == 0) load_x(nxt);
-      stage(s, S0{});
-      if (s + 1 < NS) stage(s + 1, S1{});
-    }
-    if (!more) break;
-    // tile switch: every wave is past the barrier that ended the last stage, As is free
-    if (!wspec) stage_a(nxt);
-    if (wrap_ok) __syncthreads();
-    else prime_w();  // odd stage count: the buffer parity restarts, re-prime the weight pipeline
-    cur = nxt;
-    t = tn;
+      const float* pdb = a.dbias ? a.dbias + (long)m.dbrow * a.lddb : ar_zeros;
+      const float* posc = (MODE & 2) ? a.osc + (long)m.grp * a.ldosc : ar_zeros;
+      const float* posh = (MODE & 2) ? a.osh + (long)m.grp * a.ldosc : ar_zeros;
+      cb = pbias[n] + pdb[n];
+      os = posc[n];
+      oh = posh[n];
+    };
+    float cbc, osc_c, osh_c, cbn = 0.f, osc_n = 0.f, osh_n = 0.f;
+    epi_consts(cur, 0, cbc, osc_c, osh_c);
+    TileMeta nxt = cur, raw2 = cur;
+    if (t + gstep < a.T) nxt = scalar(meta_of(t + gstep));
+    auto begin_tile = [&](const TileMeta& m, int tt) {
+      nrows = m.nrows;
+      grp = m.grp;
+      nsub = min(max(nrows - 64 * wm, 0), 64);  // valid rows of this wave's half tile
+      inv_nsub = nsub > 0 ? 1.f / (float)nsub : 0.f;
+      prow = (long)(2 * tt + wm);
+      full = (nsub == 64);
+      lim = nrows - (wm * 64 + 4 * (lane >> 5));
+    };
     begin_tile(cur, t);
-  }
+
+    auto stage = [&](int s, auto ODD) {
+      constexpr int odd = decltype(ODD)::value;  // s & 1
+      constexpr int ks = (KS == 2) ? odd : 0;  // NS is a multiple of KS and stages alternate
+      const int nt = s / KS;
+      if constexpr (ks == 0) {
+        const bool last_nt = nt + 1 >= ntn;  // then: first channel tile of the next row tile (same loads, other rows)
+        TileMeta m = cur;
+        if (last_nt) m = nxt;
+        // (handing these constants from waves 0-3 to waves 4-7 through LDS, so that they do not queue behind the
+        // activation rows, measured slower than loading them in every wave)
+        epi_consts(m, last_nt ? 0 : nt + 1, cbn, osc_n, osh_n);
+      }
+      // stage s+1 (register slot !odd) -> the other LDS buffer (last read in stage s-1, every wave is past
+      // that barrier); then its slot takes the loads of stage s+3
+      if constexpr (WS) {
+        store_w(1 - odd, std::integral_constant<int, 1 - odd>{});
+        load_w((s + 3) % NS, std::integral_constant<int, 1 - odd>{});  // wraps into the next row tile
+      }
+      // Four 16-channel steps; the fragments of step j+1 are read while the six MFMAs of step j issue, one
+      // read per MFMA (sched_barrier pins the order): the two waves of a SIMD run in lockstep after every
+      // barrier, so an LDS round trip that is not covered by this wave's own MFMAs is idle matrix-pipe time.
+      const _Float16* ah = &As[ks][0][0];
+      const _Float16* al = &As[ks][1][0];
+      const _Float16* bh = &Bs[odd][0][0];
+      const _Float16* bl = &Bs[odd][1][0];
+      const int offa0 = (wm * 64 + lr) * AR_LDT + kh, offa1 = offa0 + 32 * AR_LDT;
+      const int offb = (wn * 32 + lr) * AR_LDT + kh;
+      struct Fr {
+        f16x8 v[6];  // ah0, al0, ah1, al1, bh, bl
+      };
+      auto rd1 = [&](Fr& f, auto JC, auto RC) {
+        constexpr int j = decltype(JC)::value, r = decltype(RC)::value;
+        if constexpr (r == 0) f.v[0] = *reinterpret_cast<const f16x8*>(ah + offa0 + j * 16);
+        if constexpr (r == 1) f.v[1] = *reinterpret_cast<const f16x8*>(al + offa0 + j * 16);
+        if constexpr (r == 2) f.v[2] = *reinterpret_cast<const f16x8*>(ah + offa1 + j * 16);
+        if constexpr (r == 3) f.v[3] = *reinterpret_cast<const f16x8*>(al + offa1 + j * 16);
+        if constexpr (r == 4) f.v[4] = *reinterpret_cast<const f16x8*>(bh + offb + j * 16);
+        if constexpr (r == 5) f.v[5] = *reinterpret_cast<const f16x8*>(bl + offb + j * 16);
+      };
+      auto mm1 = [&](const Fr& f, auto IC) {  // term-major: consecutive MFMAs alternate between the two accumulators
+        constexpr int i = decltype(IC)::value;
+        constexpr int tm = i & 1, term = i >> 1;
+        if constexpr (term == 0) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.v[2 * tm + 1], f.v[4], acc[tm], 0, 0, 0);
+        if constexpr (term == 1) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.v[2 * tm], f.v[5], acc[tm], 0, 0, 0);
+        if constexpr (term == 2) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.v[2 * tm], f.v[4], acc[tm], 0, 0, 0);
+      };
+      auto step = [&](const Fr& cur, Fr& nxt, auto JN) {  // MFMAs of the current step, reads of step JN underneath
+        constexpr int jn = decltype(JN)::value;
+  #define AR_PAIR(I)                                                   \
+    mm1(cur, std::integral_constant<int, I>{});                        \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+    if constexpr (jn < 4) {                                            \
+      rd1(nxt, JN, std::integral_constant<int, I>{});                  \
+      __builtin_amdgcn_sched_barrier(0);                               \
+    }
+        AR_PAIR(0) AR_PAIR(1) AR_PAIR(2) AR_PAIR(3) AR_PAIR(4) AR_PAIR(5)
+  #undef AR_PAIR
+      };
+      Fr f0, f1;
+      rd1(f0, S0{}, std::integral_constant<int, 0>{});
+      rd1(f0, S0{}, std::integral_constant<int, 1>{});
+      rd1(f0, S0{}, std::integral_constant<int, 2>{});
+      rd1(f0, S0{}, std::integral_constant<int, 3>{});
+      rd1(f0, S0{}, std::integral_constant<int, 4>{});
+      rd1(f0, S0{}, std::integral_constant<int, 5>{});
+      __builtin_amdgcn_sched_barrier(0);
+      step(f0, f1, std::integral_constant<int, 1>{});
+      step(f1, f0, std::integral_constant<int, 2>{});
+      step(f0, f1, std::integral_constant<int, 3>{});
+      step(f1, f0, std::integral_constant<int, 4>{});
+      if constexpr (ks == KS - 1) {
+        // ---- channel tile nt finished: register-only epilogue for this wave's 64 rows x 32 channels ----
+        // v = acc*oscale + cb is never formed for full half tiles: the sums are taken on the raw accumulators
+        // and rescaled (S = oscale*sum(acc) + n*cb, M2 = oscale^2 * M2(acc), relu(v*os+oh) = relu(acc*(oscale*os)
+        // + (cb*os+oh))); 3 VALU ops per value.
+        const int n = nt * AR_BN + wn * 32 + lr;
+        const float cb = cbc, os = osc_c, oh = osh_c;  // fetched one channel tile ahead (see below)
+        if constexpr (MODE & 1) {
+          float s1 = 0.f;
+          if (full) {
+  #pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+  #pragma unroll
+              for (int e = 0; e < 16; ++e) s1 += acc[tm][e];
+          } else {
+  #pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+  #pragma unroll
+              for (int e = 0; e < 16; ++e)
+                if (tm * 32 + (e & 3) + 8 * (e >> 2) < lim) s1 += acc[tm][e];
+          }
+          s1 += __shfl_xor(s1, 32);
+          const float mu = s1 * inv_nsub;  // mean of the raw accumulators over the half tile
+          float s2 = 0.f;
+          if (full) {
+  #pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+  #pragma unroll
+              for (int e = 0; e < 16; ++e) {
+                const float d = acc[tm][e] - mu;
+                s2 = fmaf(d, d, s2);
+              }
+          } else {
+  #pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+  #pragma unroll
+              for (int e = 0; e < 16; ++e) {
+                const float d = acc[tm][e] - mu;
+                if (tm * 32 + (e & 3) + 8 * (e >> 2) < lim) s2 = fmaf(d, d, s2);
+              }
+          }
+          s2 += __shfl_xor(s2, 32);
+          if (lane < 32) {
+            a.part[(prow * 2 + 0) * a.N + n] = fmaf(s1, a.oscale, (float)nsub * cb);
+            a.part[(prow * 2 + 1) * a.N + n] = s2 * a.oscale * a.oscale;
+          }
+        }
+        if constexpr (MODE & 2) {
+          const float m1 = a.oscale * os, m0 = fmaf(cb, os, oh);
+          float s3 = 0.f;
+          if (full) {
+  #pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+  #pragma unroll
+              for (int e = 0; e < 16; ++e) s3 += fmaxf(fmaf(acc[tm][e], m1, m0), 0.f);
+          } else {
+  #pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+  #pragma unroll
+              for (int e = 0; e < 16; ++e)
+                if (tm * 32 + (e & 3) + 8 * (e >> 2) < lim) s3 += fmaxf(fmaf(acc[tm][e], m1, m0), 0.f);
+          }
+          s3 += __shfl_xor(s3, 32);
+          if (lane < 32) a.colsum[prow * a.N + n] = s3;
+        }
+  #pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+  #pragma unroll
+          for (int e = 0; e < 16; ++e) acc[tm][e] = 0.f;
+        cbc = cbn;
+        osc_c = osc_n;
+        osh_c = osh_n;
+      }
+      __syncthreads();
+    };
+    for (;;) {
+      const int tn = t + gstep;
+      const bool more = tn < a.T;
+      const bool more2 = tn + gstep < a.T;
+      // the next tile's rows are requested at the first stage of this tile (waves 4-7: nothing else in their queue
+      // but the small per-channel constants)
+      // table words of the tile after the next: unconditional (clamped) so that the number of loads in flight stays fixed;
+      // consumed a whole tile later
+      raw2 = meta_of(more2 ? tn + gstep : tn < a.T ? tn : t);
+      for (int s = 0; s < NS; s += 2) {
+        if constexpr (!WS)
+          if (more && s == 0) load_x(nxt);
+        stage(s, S0{});
+        if (s + 1 < NS) stage(s + 1, S1{});
+      }
+      if (!more) break;
+      // tile switch: every wave is past the barrier that ended the last stage, As is free
+      if constexpr (!WS) stage_a(nxt);
+      if (wrap_ok) __syncthreads();
+      else prime_w();  // odd stage count: the buffer parity restarts, re-prime the weight pipeline
+      cur = nxt;
+      if (more2) nxt = scalar(raw2);
+      t = tn;
+      begin_tile(cur, t);
+    }
+  };
+  if (wspec) run(std::true_type{});
+  else run(std::false_type{});
 }
 
 int mmmot_gemm_wres64_launch(const mmmot_gemm_ares_args* a, int mode, int n_cu, hipStream_t s);  // gemm_wres.hip

@@ -55,16 +55,18 @@ __global__ __launch_bounds__(WR_THREADS) void gemm_wres64_kernel(mmmot_gemm_ares
     TileMeta m;
     m.row0 = a.tile_row0[tt];
     m.nrows = a.tile_nrows[tt];
-    m.grp = a.tile_group ? a.tile_group[tt] : 0;
-    m.dbrow = a.dbias ? a.tile_dbrow[tt] : 0;
+    // unconditional loads (an absent table reads tile_row0 instead, discarded in scalar()): a conditional load makes
+    // the number of loads in flight path-dependent and turns later counted waits into vmcnt(0)
+    m.grp = (a.tile_group ? a.tile_group : a.tile_row0)[tt];
+    m.dbrow = (a.dbias ? a.tile_dbrow : a.tile_row0)[tt];
     return m;
   };
   auto scalar = [&](const TileMeta& v) {
     TileMeta m;
     m.row0 = __builtin_amdgcn_readfirstlane(v.row0);
     m.nrows = __builtin_amdgcn_readfirstlane(v.nrows);
-    m.grp = __builtin_amdgcn_readfirstlane(v.grp);
-    m.dbrow = __builtin_amdgcn_readfirstlane(v.dbrow);
+    m.grp = a.tile_group ? __builtin_amdgcn_readfirstlane(v.grp) : 0;
+    m.dbrow = a.dbias ? __builtin_amdgcn_readfirstlane(v.dbrow) : 0;
     return m;
   };
   int t = blockIdx.x;
