@@ -61,6 +61,55 @@ __device__ __forceinline__ void mm_stage(const float* __restrict__ As, const flo
 // row = (e&3) + 8*(e>>2) + 4*(l>>5), col = l&31.
 __device__ __forceinline__ int mm_acc_row(int e, int lane) { return (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5); }
 
+// ---- register epilogues of a 64-row x 32-channel wave tile (two 32x32 accumulators; a lane holds 32 of its column's
+// 64 rows, lane ^ 32 the other 32).  The half-wave exchange is v_permlane32_swap (gfx950), a VALU instruction, instead of
+// the ds_bpermute behind __shfl_xor(.., 32) (an LDS round trip twice per channel block).  Measured and not adopted for
+// the 32-value sums: packed fp32 (v_pk_add_f32 / v_pk_fma_f32) tree reductions - fewer instructions, no faster
+// (tools/bench_ares.py A/B on one box: 0.44 ms sequential vs 0.47 ms packed, statistics pass of conv1).
+__device__ __forceinline__ float mm_xor32_sum(float x) {  // x + (x of lane ^ 32)
+  // v_permlane32_swap_b32 a, b: the upper 32 lanes of a <-> the lower 32 lanes of b.  Inline assembly: with this
+  // toolchain (ROCm 7.2 clang) the second result of __builtin_amdgcn_permlane32_swap comes back equal to the first
+  // (probed on an MI355X), and the hazard recogniser does not see into inline assembly - the instruction needs wait
+  // states after the VALU write of its operands and before a VALU read of its results (without the s_nops the upper
+  // lanes read stale values).
+  float a = x, b = x;
+  asm volatile("s_nop 3\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 3" : "+v"(a), "+v"(b));
+  return a + b;
+}
+
+__device__ __forceinline__ float mm_sum32(const f32x16& a, const f32x16& b) {  // sum of the lane's 32 values
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) s += a[e];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) s += b[e];
+  return s;
+}
+
+__device__ __forceinline__ float mm_m2_32(const f32x16& a, const f32x16& b, float mu) {  // sum of (v - mu)^2
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const float d = a[e] - mu;
+    s = fmaf(d, d, s);
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const float d = b[e] - mu;
+    s = fmaf(d, d, s);
+  }
+  return s;
+}
+
+__device__ __forceinline__ float mm_relu_sum32(const f32x16& a, const f32x16& b, float m1, float m0) {
+  float s = 0.f;  // sum of relu(v * m1 + m0)
+#pragma unroll
+  for (int e = 0; e < 16; ++e) s += fmaxf(fmaf(a[e], m1, m0), 0.f);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) s += fmaxf(fmaf(b[e], m1, m0), 0.f);
+  return s;
+}
+
 __device__ __forceinline__ float mm_act(float v, int act) {
   if (act == MMMOT_ACT_RELU) return fmaxf(v, 0.f);
   if (act == MMMOT_ACT_SIGMOID) return 1.f / (1.f + expf(-v));

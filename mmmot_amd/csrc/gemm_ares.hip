@@ -314,10 +314,7 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
         if constexpr (MODE & 1) {
           float s1 = 0.f;
           if (full) {
-  #pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
-  #pragma unroll
-              for (int e = 0; e < 16; ++e) s1 += acc[tm][e];
+            s1 = mm_sum32(acc[0], acc[1]);
           } else {
   #pragma unroll
             for (int tm = 0; tm < 2; ++tm)
@@ -325,17 +322,11 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
               for (int e = 0; e < 16; ++e)
                 if (tm * 32 + (e & 3) + 8 * (e >> 2) < lim) s1 += acc[tm][e];
           }
-          s1 += __shfl_xor(s1, 32);
+          s1 = mm_xor32_sum(s1);
           const float mu = s1 * inv_nsub;  // mean of the raw accumulators over the half tile
           float s2 = 0.f;
           if (full) {
-  #pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
-  #pragma unroll
-              for (int e = 0; e < 16; ++e) {
-                const float d = acc[tm][e] - mu;
-                s2 = fmaf(d, d, s2);
-              }
+            s2 = mm_m2_32(acc[0], acc[1], mu);
           } else {
   #pragma unroll
             for (int tm = 0; tm < 2; ++tm)
@@ -345,7 +336,7 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
                 if (tm * 32 + (e & 3) + 8 * (e >> 2) < lim) s2 = fmaf(d, d, s2);
               }
           }
-          s2 += __shfl_xor(s2, 32);
+          s2 = mm_xor32_sum(s2);
           if (lane < 32) {
             a.part[(prow * 2 + 0) * a.N + n] = fmaf(s1, a.oscale, (float)nsub * cb);
             a.part[(prow * 2 + 1) * a.N + n] = s2 * a.oscale * a.oscale;
@@ -355,10 +346,7 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
           const float m1 = a.oscale * os, m0 = fmaf(cb, os, oh);
           float s3 = 0.f;
           if (full) {
-  #pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
-  #pragma unroll
-              for (int e = 0; e < 16; ++e) s3 += fmaxf(fmaf(acc[tm][e], m1, m0), 0.f);
+            s3 = mm_relu_sum32(acc[0], acc[1], m1, m0);
           } else {
   #pragma unroll
             for (int tm = 0; tm < 2; ++tm)
@@ -366,7 +354,7 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
               for (int e = 0; e < 16; ++e)
                 if (tm * 32 + (e & 3) + 8 * (e >> 2) < lim) s3 += fmaxf(fmaf(acc[tm][e], m1, m0), 0.f);
           }
-          s3 += __shfl_xor(s3, 32);
+          s3 = mm_xor32_sum(s3);
           if (lane < 32) a.colsum[prow * a.N + n] = s3;
         }
   #pragma unroll

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(MM_THREADS, 2) void gemm_rows_kernel(mmmot_gemm_arg
       }
     }
     if (a.part) {
-      s1 += __shfl_xor(s1, 32);
+      s1 = mm_xor32_sum(s1);
       if (lane < 32) red[wm * BN + cl] = s1;
     }
   }
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(MM_THREADS, 2) void gemm_rows_kernel(mmmot_gemm_arg
           }
         }
       }
-      s2 += __shfl_xor(s2, 32);
+      s2 = mm_xor32_sum(s2);
       if (lane < 32) red[wm * BN + cl] = s2;  // red[] was consumed before the barrier above
     }
     __syncthreads();
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(MM_THREADS, 2) void gemm_rows_kernel(mmmot_gemm_arg
           if (r < nrows) s3 += fmaxf(fmaf(acc[tm][tn][e], os, oh), 0.f);
         }
       }
-      s3 += __shfl_xor(s3, 32);
+      s3 = mm_xor32_sum(s3);
       if (lane < 32) red[wm * BN + cl] = s3;
     }
     __syncthreads();

@@ -172,11 +172,6 @@ __global__ __launch_bounds__(WR_THREADS) void gemm_wres64_kernel(mmmot_gemm_ares
     }
     const int tn = t + gstep;
     const bool more = tn < a.T;
-    if (more) {
-      load_consts(nxt);
-      load_x(nxt);  // in flight for the whole tile
-      if (tn + gstep < a.T) raw2 = meta_of(tn + gstep);
-    }
     const int nrows = cur.nrows;
     const int nsub = min(max(nrows - 64 * wm, 0), 64);  // valid rows of this wave's half tile
     const float inv_nsub = nsub > 0 ? 1.f / (float)nsub : 0.f;
@@ -215,15 +210,22 @@ __global__ __launch_bounds__(WR_THREADS) void gemm_wres64_kernel(mmmot_gemm_ares
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j][0], bh[sl], acc[0], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j][2], bh[sl], acc[1], 0, 0, 0);
       }
+      if (i == 0 && more) {
+        // the next tile's requests (constants first, then its rows, then the table words of the tile after it) are
+        // issued in the shadow of this block's MFMAs - ~25 VMEM instructions cost ~800 issue cycles (s_memtime) that
+        // were part of the tile switch, with the matrix pipe idle - and stay in flight for the rest of the tile
+        __builtin_amdgcn_sched_barrier(0);
+        load_consts(nxt);
+        load_x(nxt);
+        if (tn + gstep < a.T) raw2 = meta_of(tn + gstep);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       // ---- register-only epilogue of 64 rows x 32 channels (as gemm_ares: sums on the raw accumulators, rescaled) ----
       const float cbi = cb[i];
       if constexpr (MODE & 1) {
         float s1 = 0.f;
         if (full) {
-#pragma unroll
-          for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) s1 += acc[tm][e];
+          s1 = mm_sum32(acc[0], acc[1]);
         } else {
 #pragma unroll
           for (int tm = 0; tm < 2; ++tm)
@@ -231,17 +233,11 @@ __global__ __launch_bounds__(WR_THREADS) void gemm_wres64_kernel(mmmot_gemm_ares
             for (int e = 0; e < 16; ++e)
               if (tm * 32 + (e & 3) + 8 * (e >> 2) < lim) s1 += acc[tm][e];
         }
-        s1 += __shfl_xor(s1, 32);
+        s1 = mm_xor32_sum(s1);
         const float mu = s1 * inv_nsub;  // mean of the raw accumulators over the half tile
         float s2 = 0.f;
         if (full) {
-#pragma unroll
-          for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              const float d = acc[tm][e] - mu;
-              s2 = fmaf(d, d, s2);
-            }
+          s2 = mm_m2_32(acc[0], acc[1], mu);
         } else {
 #pragma unroll
           for (int tm = 0; tm < 2; ++tm)
@@ -251,7 +247,7 @@ __global__ __launch_bounds__(WR_THREADS) void gemm_wres64_kernel(mmmot_gemm_ares
               if (tm * 32 + (e & 3) + 8 * (e >> 2) < lim) s2 = fmaf(d, d, s2);
             }
         }
-        s2 += __shfl_xor(s2, 32);
+        s2 = mm_xor32_sum(s2);
         if (lane < 32) {
           a.part[(prow * 2 + 0) * a.N + n] = fmaf(s1, a.oscale, (float)nsub * cbi);
           a.part[(prow * 2 + 1) * a.N + n] = s2 * a.oscale * a.oscale;
@@ -261,10 +257,7 @@ __global__ __launch_bounds__(WR_THREADS) void gemm_wres64_kernel(mmmot_gemm_ares
         const float m1i = m1[i], m0i = m0[i];
         float s3 = 0.f;
         if (full) {
-#pragma unroll
-          for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) s3 += fmaxf(fmaf(acc[tm][e], m1i, m0i), 0.f);
+          s3 = mm_relu_sum32(acc[0], acc[1], m1i, m0i);
         } else {
 #pragma unroll
           for (int tm = 0; tm < 2; ++tm)
@@ -272,7 +265,7 @@ __global__ __launch_bounds__(WR_THREADS) void gemm_wres64_kernel(mmmot_gemm_ares
             for (int e = 0; e < 16; ++e)
               if (tm * 32 + (e & 3) + 8 * (e >> 2) < lim) s3 += fmaxf(fmaf(acc[tm][e], m1i, m0i), 0.f);
         }
-        s3 += __shfl_xor(s3, 32);
+        s3 = mm_xor32_sum(s3);
         if (lane < 32) a.colsum[prow * a.N + n] = s3;
       }
     }

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void pn_mlp64_kernel(const float* __restrict__
           Y[(long)(row0 + wave * 32 + mm_acc_row(e, lane)) * ldy + nt * 32 + lr] = acc[nt][e];
         }
       }
-      s1 += __shfl_xor(s1, 32);
+      s1 = mm_xor32_sum(s1);
       if (lane < 32) red[0][wave][nt * 32 + lr] = s1;
     }
     __syncthreads();
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void pn_mlp64_kernel(const float* __restrict__
         const float d = acc[nt][e] - mu;
         if (valid[e]) s2 = fmaf(d, d, s2);
       }
-      s2 += __shfl_xor(s2, 32);
+      s2 = mm_xor32_sum(s2);
       if (lane < 32) red[1][wave][n] = s2;
       if (wave == 0 && lane < 32) part[((long)t * 2 + 0) * NOUT + n] = tot;
     }

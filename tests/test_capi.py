@@ -45,6 +45,11 @@ def test_abi_version_and_argument_checks_without_gpu():
     assert lib.mmmot_gemm_rows(None, None) == -1
     assert lib.mmmot_conv3x3_bn_relu(None, None, None, None, 1, 8, 8, 64, 64, 0, 0, None) == -1
     assert lib.mmmot_softmax_pairs(None, None, None, None, None, 1, 4, 3, None) == -1
+    # mmmot_pn_mlp64: null pointers, and (with non-null, 16-byte aligned dummies) an output width other than 64 / 128
+    assert lib.mmmot_pn_mlp64(None, 64, None, None, 64, None, 1.0, None, None, 64, None, None, None, None, 1, 64, None) == -1
+    d = 4096  # never dereferenced: the argument checks come before any launch
+    assert lib.mmmot_pn_mlp64(d, 64, d, d, 64, d, 1.0, d, d, 96, d, d, d, None, 1, 96, None) == -1
+    assert lib.mmmot_pn_mlp64(d, 62, d, d, 64, d, 1.0, d, d, 64, d, d, d, None, 1, 64, None) == -1
 
 
 import pytest
