@@ -16,6 +16,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 static inline int mm_check(hipError_t e) { return e == hipSuccess ? MMMOT_OK : (int)e; }
 static inline bool mm_al16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
+// CU count of the current device (one process drives one GPU); 0 when there is none.  A function-local static:
+// initialised once, thread-safe (C++11).
+static inline int mm_num_cu() {
+  static const int n = [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    return (int)prop.multiProcessorCount;
+  }();
+  return n;
+}
+
 // XCD-aware bijective remap of a linear workgroup id: the dispatcher places
 // workgroup b on XCD b % 8; give every XCD a contiguous chunk of logical ids so
 // that tiles sharing an A panel hit the same 4 MiB L2.

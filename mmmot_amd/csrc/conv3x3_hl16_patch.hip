@@ -1086,16 +1086,7 @@ extern "C" int mmmot_set_patch_variant(int v) {
 }
 #endif
 
-static int pt_num_cu() {
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    n_cu = prop.multiProcessorCount;
-  }
-  return n_cu;
-}
+static int pt_num_cu() { return mm_num_cu(); }
 
 // 128- or 64-channel tiles?  128 halves the LDS traffic per MFMA, but a small problem (one reference-shaped frame pair:
 // 22 crops, 14 x 14 maps at conv5 = 88 tiles of 128 channels on 256 CUs) fills the chip better with twice as many

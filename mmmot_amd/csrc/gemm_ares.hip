@@ -410,20 +410,14 @@ extern "C" int mmmot_gemm_ares(const mmmot_gemm_ares_args* a, void* stream) {
   if (!a->part && !a->colsum) return MMMOT_EINVAL;  // nothing to produce
   if (a->N > 4096) return MMMOT_EINVAL;
   const int mode = (a->part ? 1 : 0) | (a->colsum ? 2 : 0);
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MMMOT_EINVAL;
-    n_cu = prop.multiProcessorCount;
-  }
-  // K = 64 with the whole weight matrix in LDS (N <= 512): the weight-resident kernel; MMMOT_ARES_WRES=0 keeps the
-  // streaming kernel (A/B timing, tools/bench_pointnet.py)
-  static int use_wres = -1;
-  if (use_wres < 0) {
+  const int n_cu = mm_num_cu();
+  if (n_cu <= 0) return MMMOT_EINVAL;
+  // K = 64 with the whole weight matrix in LDS (N <= 512): the weight-resident kernel; MMMOT_ARES_WRES=0 (read once)
+  // keeps the streaming kernel for A/B timing (tools/bench_ares.py)
+  static const bool use_wres = [] {
     const char* e = getenv("MMMOT_ARES_WRES");
-    use_wres = (e && e[0] == '0') ? 0 : 1;
-  }
+    return !(e && e[0] == '0');
+  }();
   if (use_wres && a->K == 64 && a->N <= 512) return mmmot_gemm_wres64_launch(a, mode, n_cu, s);
   const int grid = a->T < n_cu ? a->T : n_cu;  // persistent: one workgroup per CU
 #define AR_LAUNCH(KSV, MODEV) \

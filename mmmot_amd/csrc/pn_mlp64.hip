@@ -160,13 +160,8 @@ extern "C" int mmmot_pn_mlp64(const float* X, int ldx, const float* sc, const fl
   if (!X || !sc || !sh || !W16 || !Y || !part || !tile_row0 || !tile_nrows || T <= 0) return MMMOT_EINVAL;
   if ((N != 64 && N != 128) || ldx % 4 != 0 || ldsc % 4 != 0 || ldy < N) return MMMOT_EINVAL;
   if (!mm_al16(X) || !mm_al16(sc) || !mm_al16(sh) || !mm_al16(W16)) return MMMOT_EINVAL;
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MMMOT_EINVAL;
-    n_cu = prop.multiProcessorCount;
-  }
+  const int n_cu = mm_num_cu();
+  if (n_cu <= 0) return MMMOT_EINVAL;
   const int grid = T < 2 * n_cu ? T : 2 * n_cu;  // persistent: two workgroups per CU (LDS 55 / 74 KB each)
   hipStream_t s = (hipStream_t)stream;
   if (N == 64)
