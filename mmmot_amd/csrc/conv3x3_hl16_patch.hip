@@ -629,6 +629,12 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
         const int sw = pt_swz_a(ppy, ppx);
         typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
         const int hh = kg1 & 1;  // which half (4 channels) of an 8-channel unit
+        // out-of-image patch pixels exist only in tiles on a crop's border: a wave whose pixels are all inside skips
+        // the per-value select (wave-uniform branch).  (With the fmed3 below: 3 instead of 5 VALU operations per value;
+        // tools/bench_fused1.py shows no change of the launch time - the prologue's 0.12 ms per pair is not set by
+        // its VALU instruction count.)
+        const bool allin = __builtin_amdgcn_ballot_w64(!inimg) == 0;
+        auto emit = [&](auto MASKED) {
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {  // channels 16 mb + 4 kg1 .. + 3 = slab mb >> 1, unit q, half hh
           const int q = (mb & 1) * 2 + (kg1 >> 1);
@@ -638,10 +644,12 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
           float vv[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float v = fmaxf(fmaf(c1[mb][r], fz.oscale1, bq[r]), 0.f);
-            if (!inimg) v = 0.f;
-            c11max = fmaxf(c11max, v);
-            v = fminf(v, 65000.f);
+            float v = fmaf(c1[mb][r], fz.oscale1, bq[r]);
+            if constexpr (decltype(MASKED)::value) {
+              if (!inimg) v = 0.f;
+            }
+            c11max = fmaxf(c11max, v);                    // c11max >= 0: same as taking the maximum after the ReLU
+            v = __builtin_amdgcn_fmed3f(v, 0.f, 65000.f);  // ReLU and the fp16 range clamp in one instruction
             vv[r] = v;
             hi[r] = (_Float16)v;
             lo[r] = (_Float16)(v - (float)hi[r]);
@@ -665,6 +673,9 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
             *reinterpret_cast<f16x4*>(smem + rb + hh * 8 + (((2 * q + 1) ^ sw) << 4)) = lo;
           }
         }
+        };
+        if (allin) emit(std::false_type{});
+        else emit(std::true_type{});
       }
     }
     if (c11max > (Q8 ? PT_SAT_E4M3 : PT_SAT_FP16)) atomicAdd(&pt_range[2], 1u);
