@@ -233,6 +233,57 @@ __global__ __launch_bounds__(256) void segment_mean_kernel(
   }
 }
 
+// hl16 rows without a normalise / ReLU prologue (the SkipPool global average pools over the trunk's stage outputs, 2 GB
+// per 8-pair step): a lane takes a whole 8-channel unit - [hi8 | lo8] = two 16-byte loads - instead of the 4 channels
+// (two 8-byte loads) of the general kernel, and all 64 lanes work whatever C is: UPR = C / 8 lanes cover a row, a wave
+// load instruction 64 / UPR rows.  Same result contract (mean over the segment, divisor seg_div or the row count).
+typedef _Float16 sm_f16x8 __attribute__((ext_vector_type(8)));
+template <int UPR>
+__global__ __launch_bounds__(256) void segment_mean_hl16_kernel(const float* __restrict__ X, int ldx,
+                                                                 const int* __restrict__ seg_start,
+                                                                 const int* __restrict__ seg_count,
+                                                                 const int* __restrict__ seg_stride,
+                                                                 const int* __restrict__ seg_div,
+                                                                 float* __restrict__ out, int ldo) {
+  constexpr int RPW = 64 / UPR;  // rows per wave load instruction
+  __shared__ float red[4][UPR * 8];
+  const int s = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int u = lane % UPR, rsub = lane / UPR;
+  const int start = seg_start[s], count = seg_count[s], stride = seg_stride ? seg_stride[s] : 1;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  auto add_row = [&](int t) {
+    const sm_f16x8* p = reinterpret_cast<const sm_f16x8*>(X + ((long)start + (long)t * stride) * ldx) + 2 * u;
+    const sm_f16x8 h = p[0], l = p[1];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += (float)h[e] + (float)l[e];
+  };
+  constexpr int STEP = 4 * RPW;  // rows per workgroup pass
+  int t = wave * RPW + rsub;
+  for (; t + 3 * STEP < count; t += 4 * STEP) {  // four independent row loads in flight per lane
+    add_row(t);
+    add_row(t + STEP);
+    add_row(t + 2 * STEP);
+    add_row(t + 3 * STEP);
+  }
+  for (; t < count; t += STEP) add_row(t);
+  // lanes u, u + UPR, ... of a wave hold partial sums of the same unit
+#pragma unroll
+  for (int o = UPR; o < 64; o <<= 1)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += __shfl_xor(acc[e], o);
+  if (rsub == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[wave][u * 8 + e] = acc[e];
+  }
+  __syncthreads();
+  const float inv = 1.f / (float)(seg_div ? seg_div[s] : count);
+  for (int c = tid; c < UPR * 8; c += 256)
+    out[(long)s * ldo + c] = ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) * inv;
+}
+
 extern "C" int mmmot_segment_mean(const float* X, int ldx, int C, const int* seg_start, const int* seg_count,
                                   const int* seg_stride, const int* seg_group, const int* seg_div, int nseg,
                                   const float* sc, const float* sh, int ldsc, int relu, float* out, int ldo,
@@ -244,6 +295,19 @@ extern "C" int mmmot_segment_mean(const float* X, int ldx, int C, const int* seg
   if (C % 4 != 0 || ldx % 4 != 0 || ldo % 4 != 0 || !mm_al16(X) || !mm_al16(out)) return MMMOT_EINVAL;
   if ((sc == nullptr) != (sh == nullptr)) return MMMOT_EINVAL;
   if (sc && (ldsc % 4 != 0 || !mm_al16(sc) || !mm_al16(sh))) return MMMOT_EINVAL;
+  if (hl16 == 1 && !sc && relu == 0 && (C == 128 || C == 256 || C == 512) && mm_al16(X) && ldx % 8 == 0) {
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 128)
+      hipLaunchKernelGGL(segment_mean_hl16_kernel<16>, dim3(nseg), dim3(256), 0, st, X, ldx, seg_start, seg_count,
+                         seg_stride, seg_div, out, ldo);
+    else if (C == 256)
+      hipLaunchKernelGGL(segment_mean_hl16_kernel<32>, dim3(nseg), dim3(256), 0, st, X, ldx, seg_start, seg_count,
+                         seg_stride, seg_div, out, ldo);
+    else
+      hipLaunchKernelGGL(segment_mean_hl16_kernel<64>, dim3(nseg), dim3(256), 0, st, X, ldx, seg_start, seg_count,
+                         seg_stride, seg_div, out, ldo);
+    return mm_check(hipGetLastError());
+  }
   hipLaunchKernelGGL(segment_mean_kernel, dim3(nseg, (C + 255) / 256), dim3(256), 0, (hipStream_t)stream, X,
                      ldx, C, seg_start, seg_count, seg_stride, seg_group, seg_div, sc, sh, ldsc, relu, out, ldo, hl16);
   return mm_check(hipGetLastError());

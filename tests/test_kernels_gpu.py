@@ -396,19 +396,37 @@ def test_hl16_small_magnitudes_keep_absolute_accuracy(hip):
     assert err < 2e-6, err   # a flushed lo half would cost ~2^-11 relative = 1e-4 here
 
 
-def test_segment_mean_hl16_input(hip):
+@pytest.mark.parametrize('C', [64, 128, 256, 512])
+def test_segment_mean_hl16_input(hip, C):
+    """hl16 rows: C = 128 / 256 / 512 without a prologue take the unit-per-lane kernel (16 / 32 / 64 lanes per row), other
+    shapes the general one; ragged counts around the kernel's pass sizes (4 x 64 / UPR rows per workgroup pass, 4 passes
+    unrolled), a strided segment and the explicit divisor of the two-level crop pool."""
     from mmmot_amd.pack import from_hl16, to_hl16
     emu = TorchOps()
-    C, hw, Lt = 256, 16, 5
-    x = torch.relu(rnd(Lt * hw, C, seed=160)) * 4
+    counts = [1, 3, 16, 17, 63, 64, 65, 255, 256, 300, 2]
+    starts = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    R = int(sum(counts)) + 600
+    x = torch.relu(rnd(R, C, seed=160)) * 4
     x16 = to_hl16(x)
-    sg_c = Segments(np.arange(Lt) * hw, np.full(Lt, hw), np.ones(Lt), np.zeros(Lt), 'cpu')
-    sg_g = Segments(np.arange(Lt) * hw, np.full(Lt, hw), np.ones(Lt), np.zeros(Lt), 'cuda')
-    out = torch.zeros(Lt, C)
+    # one strided segment on the spare rows: every second row
+    starts = np.concatenate([starts, [sum(counts)]])
+    cnts = np.array(counts + [250])
+    strides = np.array([1] * len(counts) + [2])
+    n = len(cnts)
+    sg_c = Segments(starts, cnts, strides, np.zeros(n), 'cpu')
+    sg_g = Segments(starts, cnts, strides, np.zeros(n), 'cuda')
+    out = torch.zeros(n, C)
     emu.segment_mean(from_hl16(x16), C, sg_c, out, use_group=False)
-    outg = torch.zeros(Lt, C).cuda()
+    outg = torch.full((n, C), float('nan')).cuda()
     hip.segment_mean(x16.cuda(), C, sg_g, outg, use_group=False, hl16=True)
     close(outg, out, 2e-6, 'segment_mean on hl16 rows')
+    # explicit divisor (first level of the two-level pool: partial sums = mean * count / div)
+    sg_c = Segments(starts, cnts, strides, np.zeros(n), 'cpu', div=np.full(n, 7))
+    sg_g = Segments(starts, cnts, strides, np.zeros(n), 'cuda', div=np.full(n, 7))
+    emu.segment_mean(from_hl16(x16), C, sg_c, out, use_group=False)
+    outg.fill_(float('nan'))
+    hip.segment_mean(x16.cuda(), C, sg_g, outg, use_group=False, hl16=True)
+    close(outg, out, 2e-6, 'segment_mean on hl16 rows with a divisor')
 
 
 # ---- fused "next GroupNorm + ReLU + per-detection mean" path (C-ABI v2) -----------------------------------
