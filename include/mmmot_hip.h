@@ -73,7 +73,8 @@ extern "C" {
  * mmmot_trunk_range_read, the tile / LDS-DMA trunk kernels and their knobs removed, timing experiments only in
  * -DMMMOT_DEBUG builds; 5 = training backward of the pairwise block (mmmot_gn_bwd_*, mmmot_gemm_tn,
  * mmmot_pair_bwd, mmmot_pair_expand_bwd, mmmot_rowdot_bwd, mmmot_softmax_pairs_bwd, mmmot_fusion_c_bwd, mmmot_add_rows),
- * mmmot_pointnet_layer1 takes K = 3 | 4; mmmot_pn_mlp64 added (additive, still 5). */
+ * mmmot_pointnet_layer1 takes K = 3 | 4; mmmot_pn_mlp64 added (additive, still 5);
+ * 6 = mmmot_trunk_range_bind (per-caller range-guard counter blocks). */
 int mmmot_abi_version(void);
 /* returns 0 and fills cu_count / gcn arch string (<=32 bytes) of device 0..; */
 int mmmot_device_info(int device, int* cu_count, char* arch, int arch_len);
@@ -148,6 +149,12 @@ int mmmot_hq8_unpack(const void* x, float* y, long n, void* stream);
  * first); reset != 0 clears them.  mmmot_amd.Engine reads them on the first forward and periodically, and moves the
  * trunk to f16x3 / f32 when they are hit. */
 int mmmot_trunk_range_read(unsigned int* out4, int reset);
+/* ABI 6.  Counter block of the CALLER (device memory, 4 x uint32, same layout as above) that the trunk launches issued
+ * by this host thread report to from now on; NULL returns to the library's per-device block.  The block travels as a
+ * kernel argument: a launch - or a launch captured into a hipGraph - keeps the block it was issued with, so every
+ * engine (and every captured forward) has its own window, zeroed and read by its owner with ordinary stream-ordered
+ * copies (mmmot_amd.Engine: one asynchronous 16-byte read-back per forward, inspected one step later). */
+int mmmot_trunk_range_bind(unsigned int* counters4);
 /* tests: cap the persistent grid of the patch kernels (multiple of 8, 0 = one workgroup per CU) so that small
  * problems run several chained tiles per workgroup like production sizes do.  Results do not depend on it. */
 int mmmot_set_patch_grid_limit(int n);

@@ -440,6 +440,7 @@ class _HeadFn(torch.autograd.Function):
     def forward(ctx, cat, eng, model, plan, keys, *params):
         c = cat.detach().contiguous()
         det, link, new, end, tape = head_forward_train(eng, model, plan, c)
+        eng._last_head_tape = tape  # head_autograd reads the batch statistics from here (grad mode or not)
         ctx.eng, ctx.model, ctx.plan, ctx.tape, ctx.keys = eng, model, plan, tape, keys
         ctx.save_for_backward(cat)
         ctx.shapes = [tuple(p.shape) for p in params]
@@ -465,12 +466,15 @@ def head_autograd(model, plan, cat, update_running_stats=True):
     (det [nR, Lt] raw scores, link flat, new [nR, Lt], end [nR, Lt]); ``backward()`` fills ``cat.grad`` and the ``.grad``
     of every fusion_module / w_det / w_link parameter.  With ``update_running_stats`` the BatchNorm buffers of w_det take
     the momentum update PyTorch's training mode does."""
-    eng = model.engine()
+    eng = _current_engine(model)
     named = [(k, p) for k, p in model.named_parameters() if k.split('.')[0] in ('fusion_module', 'w_det', 'w_link')]
     keys = tuple(k for k, _ in named)
+    eng._last_head_tape = None
     out = _HeadFn.apply(cat, eng, model, plan, keys, *[p for _, p in named])
     if update_running_stats:
-        tape = out[0].grad_fn.tape if hasattr(out[0].grad_fn, 'tape') else None
+        # like nn.BatchNorm1d in training mode, the buffers take the momentum update whether or not autograd records
+        # (the tape is handed over through the engine, not through grad_fn, which is None under no_grad)
+        tape, eng._last_head_tape = eng._last_head_tape, None
         if tape is not None:
             n = plan.nR * plan.Lt
             with torch.no_grad():
@@ -482,6 +486,17 @@ def head_autograd(model, plan, cat, update_running_stats=True):
                     bn.running_var.mul_(1 - m).add_(m * var)
                     bn.num_batches_tracked += 1
     return out
+
+
+def _current_engine(model):
+    """The model's engine with the head packed from the parameters as they are NOW: fusion and w_link run from the
+    packed copies, w_det's training forward from the live parameters - after an ``optimizer.step()`` (or any in-place
+    edit: the parameters' version counters moved) the head is re-packed first, so forward and gradients never mix two
+    generations of weights."""
+    eng = model.engine()
+    if hasattr(model, 'head_is_current') and not model.head_is_current():
+        eng = model.refresh_head()
+    return eng
 
 
 class _AffinityFn(torch.autograd.Function):
@@ -511,8 +526,8 @@ def affinity_autograd(model, plan, F):
     """Differentiable pairwise block of ``model`` (a TrackingNet on the device): F [nR, Lt, 512] ->
     (link flat [sum nR*N*M], new [nR, Lt], end [nR, Lt]) attached to the autograd graph; ``backward()`` fills
     ``F.grad`` and the ``.grad`` of every ``model.w_link`` parameter.  The packed weights are those of
-    ``model.engine()``: call ``model.refresh_head()`` after an optimizer step."""
-    eng = model.engine()
+    ``model.engine()``, re-packed here when a head parameter changed since (``model.head_is_current()``)."""
+    eng = _current_engine(model)
     named = [(k, p) for k, p in model.named_parameters() if k.startswith('w_link.')]
     keys = tuple(k for k, _ in named)
     return _AffinityFn.apply(F, eng, plan, keys, *[p for _, p in named])

@@ -79,12 +79,15 @@ __device__ __forceinline__ void pt_encode_q8(const float (&v)[16], u32x4& hi0, u
 // element), [1] elements clamped at the fp16 range limit 65000 (either mode: wrong value), [2] the same two events for
 // conv1_1 outputs inside the fused first launch (counted once per patch pixel, halo pixels included).
 // The common path costs a running maximum (v_max3) and one compare per 16 values; the atomics run only on a hit.
+// Every launch gets the counter block as a kernel argument: the caller's own (mmmot_trunk_range_bind - one block per
+// engine, so two models on one device, or a captured graph next to an eager forward, never mix their windows) or,
+// unbound, this per-device block of the library.
 __device__ unsigned int pt_range[4];
 #define PT_SAT_E4M3 1792.f
 #define PT_SAT_FP16 65000.f
 
 template <int N>
-__device__ __forceinline__ void pt_range_guard(const float* v, bool q8) {
+__device__ __forceinline__ void pt_range_guard(const float* v, bool q8, unsigned int* pt_range) {
   float mx = v[0];
 #pragma unroll
   for (int e = 1; e < N; ++e) mx = fmaxf(mx, v[e]);  // post-ReLU values: >= 0
@@ -187,7 +190,7 @@ template <int BN, int BS, bool POOL, int EXP, bool FUSE1 = false, bool Q8 = fals
 __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     const u32x4* __restrict__ in, const u32x4* __restrict__ wp, const float* __restrict__ bias,
     u32x4* __restrict__ out, int L, int H, int W, int Cin, int Cout, int nby, int nbx, int nblk, int ntm, int ntn,
-    const float* __restrict__ oscv, Fuse1Args fz) {
+    const float* __restrict__ oscv, Fuse1Args fz, unsigned int* __restrict__ rng) {
   static_assert(!FUSE1 || (BN == 64 && BS == 16), "the fused first layer exists for 64-channel 16x16 tiles");
   using G = PatchGeom<BS>;
   constexpr int WN = (BN == 128) ? 2 : 1;  // waves along channels
@@ -678,7 +681,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
         else emit(std::true_type{});
       }
     }
-    if (c11max > (Q8 ? PT_SAT_E4M3 : PT_SAT_FP16)) atomicAdd(&pt_range[2], 1u);
+    if (c11max > (Q8 ? PT_SAT_E4M3 : PT_SAT_FP16)) atomicAdd(&rng[2], 1u);
     pt_wait_vm<2 * NBL>();  // weight stage 0 landed (this wave's part)
     __syncthreads();        // both patch slabs are complete
   } else {
@@ -917,7 +920,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[e + k] = fmaxf(fmaf(w4[k], sq[e + k], bq[e + k]), 0.f);
           }
-          pt_range_guard<16>(v, true);
+          pt_range_guard<16>(v, true, rng);
           u32x4 hi0, hi1, a8, l8;
           pt_encode_q8(v, hi0, hi1, a8, l8);
           const long pix = POOL ? ((long)crop * Hq + (gy >> 1)) * Wq + (gx >> 1) : ((long)crop * H + gy) * W + gx;
@@ -975,7 +978,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
           float vg[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) vg[e] = v[e];
-          pt_range_guard<8>(vg, false);
+          pt_range_guard<8>(vg, false, rng);
         }
         u32x4 hi, lo;
         pt_split8(v, hi, lo);
@@ -1012,7 +1015,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
           float vg[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) vg[e] = v[e];
-          pt_range_guard<8>(vg, false);
+          pt_range_guard<8>(vg, false, rng);
         }
         u32x4 hi, lo;
         pt_split8(v, hi, lo);
@@ -1065,8 +1068,32 @@ extern "C" int mmmot_debug_read_patch_timers(unsigned long long* out8, int reset
 }
 #endif
 
-// Range-guard counters (see pt_range): synchronous read of the CURRENT device's counters into a HOST array of 4;
-// the caller synchronises the launch stream first.  reset != 0 clears them.
+// Counter block the trunk launches of THIS host thread report to (device memory, 4 x uint32, zeroed and read by the
+// caller like any other buffer: stream-ordered, capturable); NULL returns to the library's per-device block that
+// mmmot_trunk_range_read serves.  The pointer is passed to every launch as a kernel argument, so a launch keeps the
+// block it was issued (or captured) with.
+static thread_local unsigned int* g_range_bound = nullptr;
+extern "C" int mmmot_trunk_range_bind(unsigned int* counters4) {
+  if (counters4 && (((uintptr_t)counters4) & 3u)) return MMMOT_EINVAL;
+  g_range_bound = counters4;
+  return MMMOT_OK;
+}
+static unsigned int* pt_range_block() {
+  if (g_range_bound) return g_range_bound;
+  static std::atomic<unsigned int*> cache[16];  // symbol address per device, looked up once
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return nullptr;
+  unsigned int* p = dev < 16 ? cache[dev].load(std::memory_order_relaxed) : nullptr;
+  if (!p) {
+    if (hipGetSymbolAddress((void**)&p, HIP_SYMBOL(pt_range)) != hipSuccess) return nullptr;
+    if (dev < 16) cache[dev].store(p, std::memory_order_relaxed);
+  }
+  return p;
+}
+
+// Range-guard counters (see pt_range): synchronous read of the CURRENT device's library-owned counters into a HOST
+// array of 4 (launches issued while a caller's block was bound do not show here); the caller synchronises the launch
+// stream first.  reset != 0 clears them.
 extern "C" int mmmot_trunk_range_read(unsigned int* out4, int reset) {
   if (!out4) return MMMOT_EINVAL;
   hipError_t e = hipMemcpyFromSymbol(out4, HIP_SYMBOL(pt_range), 4 * sizeof(unsigned int));
@@ -1129,9 +1156,11 @@ static int launch_patch_e(const void* in, const void* wp, const float* bias, voi
   const int glimit = g_patch_grid_limit.load();
   if (glimit > 0 && grid > glimit) grid = glimit;
   if (grid > ((nitems + 7) / 8) * 8) grid = ((nitems + 7) / 8) * 8;
+  unsigned int* rng = pt_range_block();
+  if (!rng) return MMMOT_EINVAL;
   hipLaunchKernelGGL((conv3x3_hl16_patch_kernel<BN, BS, POOL, EXP, FUSE1, Q8>), dim3(grid), dim3(512), 0, s,
                      (const u32x4*)in, (const u32x4*)wp, bias, (u32x4*)out, L, H, W, Cin, Cout, nby, nbx, nblk, ntm, ntn,
-                     oscale, fz);
+                     oscale, fz, rng);
   return mm_check(hipGetLastError());
 }
 

@@ -12,6 +12,7 @@ chain of  GEMM(+stats epilogue) -> finalize -> next GEMM(normalise prologue).
 engine itself only allocates memory and orders launches.
 """
 import os
+import threading
 import warnings
 
 import torch
@@ -34,14 +35,18 @@ class Engine:
         # Range guard (include/mmmot_hip.h: mmmot_trunk_range_read).  The hq8 / hl16 activation formats have a finite
         # range: e4m3 copies saturate above 1792 (products of that element become fp16-class), the fp16 `hi` half
         # clamps at 65000 (wrong value).  The trunk epilogues count both on the device; the engine reads the counters
-        # on its first forward and then every `range_check_every` forwards (one stream synchronisation each; never
-        # during hipGraph capture) and, when they are hit, moves the trunk f16q8 -> f16x3 -> f32 for good, repeats the
-        # trunk of that forward and records the event.  MMMOT_RANGE_GUARD=0 disables it.
+        # synchronously on its first forward (and repeats that forward's trunk when they are hit), asynchronously after
+        # every later one (a 16-byte read-back inspected at the next forward: no synchronisation, one step of lag),
+        # and moves the trunk f16q8 -> f16x3 -> f32 for good.  MMMOT_RANGE_CHECK_EVERY=n adds a synchronous
+        # check-and-recompute every n forwards; MMMOT_RANGE_GUARD=0 disables the guard.  See _guarded_appearance.
         self.range_guard = os.environ.get('MMMOT_RANGE_GUARD', '1') != '0'
-        self.range_check_every = int(os.environ.get('MMMOT_RANGE_CHECK_EVERY', '64'))
+        self.range_check_every = int(os.environ.get('MMMOT_RANGE_CHECK_EVERY', '0'))
         self.q8_sat_limit = float(os.environ.get('MMMOT_Q8_SAT_LIMIT', '1e-4'))  # tolerated fraction of saturated elements
         self.range_events = []
         self._n_forward = 0
+        self._range_buf = self._range_host = self._range_pending = None
+        self._busy = threading.Lock()  # see forward()
+        self._last_stream = None
         # f16q8 only: trunk layers (indices into P['vgg'], 1..12) that run the hq8 arithmetic; None = all of them
         # (MMMOT_Q8_LAYERS=all).  The others run f16x3; at a boundary the activation tensor is re-encoded (hq8 <-> hl16,
         # two small kernels).  Default: conv3_1 .. conv5_3 (layers 4..12).  Measured on trained-like statistics
@@ -224,35 +229,106 @@ class Engine:
             n += plan.Lt * H * H * cv['cout']
         return n
 
+    # ---- range guard ----------------------------------------------------------
+    def _range_block(self, dev):
+        """this engine's own counter block (int32 [4] on `dev`) + its host mirror"""
+        dev = torch.device(dev)
+        if self._range_buf is None or self._range_buf.device != dev:
+            self._range_buf = torch.zeros(4, dtype=torch.int32, device=dev)
+            self._range_host = torch.zeros(4, dtype=torch.int32)
+            if dev.type == 'cuda':
+                self._range_host = self._range_host.pin_memory()
+            self._range_pending = None
+            self._range_seen = [0, 0, 0]  # counter values already accounted for (the block is cumulative)
+        return self._range_buf
+
+    def read_range(self, reset=True):
+        """Synchronous read of this engine's counters: (e4m3-saturated, fp16-clamped, conv1_1 hits) since the last
+        reset.  One stream synchronisation; GraphedForward.check_range() is the caller for captured forwards."""
+        if self._range_buf is None:
+            return 0, 0, 0
+        v = [int(x) & 0xFFFFFFFF for x in self._range_buf.cpu().tolist()[:3]]
+        d = [(a - b) & 0xFFFFFFFF for a, b in zip(v, self._range_seen)]
+        if reset:
+            self._range_seen = v
+        return d[0], d[1], d[2]
+
+    def _range_verdict(self, plan, sat, clamp, c11, window):
+        """arithmetic the counters call for (None: the current one holds)"""
+        q8 = self.trunk == 'f16q8' and plan.S >= self.q8_min_crop
+        if clamp > 0 or (c11 > 0 and not q8):
+            return 'f32'
+        if q8 and (sat > self.q8_sat_limit * self.trunk_elements(plan) * window or c11 > 0):
+            return 'f16x3'
+        return None
+
+    def _range_event(self, plan, lower, sat, clamp, c11, recomputed):
+        ev = dict(forward=self._n_forward, was=self.trunk, now=lower, e4m3_saturated=sat, fp16_clamped=clamp,
+                  conv1_1_hits=c11, trunk_elements=self.trunk_elements(plan), recomputed=recomputed)
+        self.range_events.append(ev)
+        warnings.warn('mmmot_amd range guard: trunk arithmetic %(was)s -> %(now)s (%(e4m3_saturated)d activation '
+                      'elements beyond the e4m3 range, %(fp16_clamped)d beyond the fp16 range, of %(trunk_elements)d '
+                      'per forward); ' % ev + ('the trunk of this forward is recomputed' if recomputed else
+                                               'detected one step late: the PREVIOUS forward ran out of range'),
+                      RuntimeWarning, stacklevel=4)
+        self.trunk = lower
+
     def _guarded_appearance(self, plan, crops, cat):
-        """appearance() under the range guard: see __init__."""
+        """appearance() under the range guard (see __init__).  Every engine owns its counter block (bound around its
+        trunk launches: mmmot_trunk_range_bind), so engines sharing a device and captured graphs never mix windows.
+        First forward: synchronous check, the trunk is recomputed in the lowered arithmetic when it trips.  Every
+        later forward: the 16-byte block is copied to pinned host memory behind the trunk (asynchronous) and inspected
+        at the start of the NEXT forward - no synchronisation, detection lags by one step (the event says so);
+        `range_check_every` > 0 adds a synchronous check-and-recompute every that many forwards.  Never inside a
+        hipGraph capture: GraphedForward.check_range() reads the block of a captured forward."""
+        ops = self.ops
+        dev = crops.device
         capturing = torch.cuda.is_current_stream_capturing() if crops.is_cuda else False
-        first = self._n_forward == 0
-        due = first or (self.range_check_every > 0 and self._n_forward % self.range_check_every == 0)
-        check = (self.range_guard and self.trunk != 'f32' and due and not capturing and
-                 hasattr(self.ops, 'trunk_range_read'))
-        if check and first:
-            self.ops.trunk_range_read(crops.device, reset=True)  # counters are per device: start from zero
-        self.appearance(plan, crops, cat)
-        while check and self.trunk != 'f32':
-            sat, clamp, c11, _ = self.ops.trunk_range_read(crops.device, reset=True)
-            q8 = self.trunk == 'f16q8' and plan.S >= self.q8_min_crop
-            window = 1 if first else self.range_check_every
-            lower = None
-            if clamp > 0 or (c11 > 0 and not q8):
-                lower = 'f32'
-            elif q8 and (sat > self.q8_sat_limit * self.trunk_elements(plan) * window or c11 > 0):
-                lower = 'f16x3'
-            if lower is None:
-                break
-            ev = dict(forward=self._n_forward, was=self.trunk, now=lower, e4m3_saturated=sat, fp16_clamped=clamp,
-                      conv1_1_hits=c11, trunk_elements=self.trunk_elements(plan))
-            self.range_events.append(ev)
-            warnings.warn('mmmot_amd range guard: trunk arithmetic %(was)s -> %(now)s (%(e4m3_saturated)d activation '
-                          'elements beyond the e4m3 range, %(fp16_clamped)d beyond the fp16 range, of %(trunk_elements)d '
-                          'per forward); the trunk of this forward is recomputed' % ev, RuntimeWarning, stacklevel=3)
-            self.trunk = lower
+        active = self.range_guard and hasattr(ops, 'trunk_range_bind')
+        if not active:
             self.appearance(plan, crops, cat)
+            self._n_forward += 1
+            return
+        blk = self._range_block(dev)
+        first = self._n_forward == 0
+        guard = self.trunk != 'f32' and not capturing
+        # ---- verdict of the previous forward's asynchronous read-back -------------------------------------------
+        if guard and self._range_pending is not None:
+            ev = self._range_pending
+            if ev is True or ev.query():
+                self._range_pending = None
+                v = [int(x) & 0xFFFFFFFF for x in self._range_host.tolist()[:3]]
+                sat, clamp, c11 = [(a - b) & 0xFFFFFFFF for a, b in zip(v, self._range_seen)]
+                self._range_seen = v
+                lower = self._range_verdict(plan, sat, clamp, c11, 1)
+                if lower is not None:
+                    self._range_event(plan, lower, sat, clamp, c11, recomputed=False)
+                    guard = self.trunk != 'f32'
+        sync = guard and (first or (self.range_check_every > 0 and self._n_forward % self.range_check_every == 0))
+        if sync:
+            self.read_range(reset=True)  # open the window of this forward (drops whatever a skipped read-back left)
+            self._range_pending = None
+        ops.trunk_range_bind(blk)
+        try:
+            self.appearance(plan, crops, cat)
+            while sync and self.trunk != 'f32':
+                sat, clamp, c11 = self.read_range(reset=True)
+                lower = self._range_verdict(plan, sat, clamp, c11, 1)
+                if lower is None:
+                    break
+                self._range_event(plan, lower, sat, clamp, c11, recomputed=True)
+                self.appearance(plan, crops, cat)
+        finally:
+            ops.trunk_range_bind(None)
+        if guard and not sync and self.trunk != 'f32' and self._range_pending is None:
+            # stream-ordered: copy the (cumulative) block out and mark the point - inspected by the next forward
+            self._range_host.copy_(blk, non_blocking=True)
+            if dev.type == 'cuda':
+                e = torch.cuda.Event()
+                e.record()
+                self._range_pending = e
+            else:
+                self._range_pending = True
         self._n_forward += 1
 
     def _skippool(self, plan, s, x, hw, C, cat, hl16=False):
@@ -466,11 +542,32 @@ class Engine:
     # ---- whole forward -------------------------------------------------------
     def forward(self, plan, crops=None, points=None):
         """Returns dict(det [nR,Lt], link flat, new [nR,Lt], end [nR,Lt], feats F, cat)."""
-        pin = getattr(self.ops, 'on_current_stream', None)
-        if pin is None:
-            return self._forward(plan, crops, points)
-        with pin():
-            return self._forward(plan, crops, points)
+        # One forward at a time per engine: the workspace arena (self.ws), the packed weights and the range-guard
+        # block are mutable state behind the integer handle of the registered operators (mmmot_amd/torch_ops.py), which
+        # an operator schema cannot express.  A second thread entering while a forward is being issued is refused; a
+        # forward issued on ANOTHER stream than the previous one first waits for that stream (the previous forward's
+        # kernels still read and write the same workspace), so consecutive forwards are ordered whatever stream they
+        # are launched on.  Outputs: det / link / new / end are freshly allocated per call; 'F' and 'cat' are views
+        # of the workspace, valid until the next forward of this engine.
+        if not self._busy.acquire(blocking=False):
+            raise RuntimeError('mmmot_amd: concurrent forwards on one engine (its workspace arena is shared mutable state); '
+                               'use one TrackingNet per thread, or serialise the calls')
+        try:
+            pin = getattr(self.ops, 'on_current_stream', None)
+            if pin is None:
+                return self._forward(plan, crops, points)
+            ref = crops if crops is not None else points
+            cur = None
+            if ref is not None and ref.is_cuda:
+                cur = torch.cuda.current_stream(ref.device)
+                last = self._last_stream
+                if last is not None and last != cur and not torch.cuda.is_current_stream_capturing():
+                    cur.wait_stream(last)
+                self._last_stream = cur
+            with pin(cur):
+                return self._forward(plan, crops, points)
+        finally:
+            self._busy.release()
 
     def _forward(self, plan, crops=None, points=None):
         rows = plan.rows

@@ -263,6 +263,45 @@ def _standalone_engine(module, prefix, **cfg):
     return cache[1]
 
 
+def _collect_tensors(obj, out=None):
+    """every tensor reachable through dicts / lists / tuples of a packed-weight tree"""
+    out = [] if out is None else out
+    if torch.is_tensor(obj):
+        out.append(obj)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _collect_tensors(v, out)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _collect_tensors(v, out)
+    return out
+
+
+def _copy_packed_(dst, src):
+    """Copy the packed tree ``src`` into ``dst`` in place (same keys / shapes / dtypes); False when they differ."""
+    if torch.is_tensor(dst):
+        if not torch.is_tensor(src) or dst.shape != src.shape or dst.dtype != src.dtype or dst.device != src.device:
+            return False
+        dst.copy_(src)
+        return True
+    if isinstance(dst, dict):
+        if not isinstance(src, dict) or dst.keys() != src.keys():
+            return False
+        ok = True
+        for k in dst:
+            if torch.is_tensor(dst[k]) or isinstance(dst[k], (dict, list, tuple)):
+                ok = _copy_packed_(dst[k], src[k]) and ok
+            elif dst[k] != src[k]:
+                dst[k] = src[k]  # python scalars (scales): the kernels take them by value at launch time ...
+                ok = False       # ... so a captured launch keeps the old one
+        return ok
+    if isinstance(dst, (list, tuple)):
+        if not isinstance(src, (list, tuple)) or len(dst) != len(src):
+            return False
+        return all([_copy_packed_(d, s_) for d, s_ in zip(dst, src)])
+    return dst == src
+
+
 class GraphedForward:
     """See ``TrackingNet.capture``."""
 
@@ -274,19 +313,42 @@ class GraphedForward:
         with torch.no_grad():
             model.forward_batch(plan, self.crops, self.points)   # warm-up: workspace allocation, range-guard check
             torch.cuda.synchronize()
-            eng.range_guard, guard = False, eng.range_guard      # the guard's counter read would synchronise
+            # (the range guard sees the capture and only binds the engine's counter block: check_range() reads it)
             self.graph = torch.cuda.CUDAGraph()
-            try:
-                with torch.cuda.graph(self.graph):
-                    self.result = model.forward_batch(plan, self.crops, self.points)
-            finally:
-                eng.range_guard = guard
-        # the graph holds raw pointers into the engine's packed weights and workspace arena: keep them alive even if
-        # the model is re-packed or a later, larger forward re-allocates workspace buffers
+            with torch.cuda.graph(self.graph):
+                self.result = model.forward_batch(plan, self.crops, self.points)
+        # the graph holds raw pointers into the engine's packed weights and workspace arena: keep BOTH alive (every
+        # tensor of eng.P and eng.ws at capture time) even if the model is re-packed or a later, larger forward
+        # re-allocates workspace buffers - a replay then reads valid memory.  It would still compute with the weights
+        # of capture time, so a re-pack that could not be done in place (invalidate / load_state_dict / set_trunk / a
+        # head refresh that changed shapes) marks the graph stale: __call__ raises instead of silently replaying it.
+        # refresh_head() itself copies into the packed tensors IN PLACE, so a graph follows an optimizer step.
         self._engine = eng
-        self._keep = list(eng.ws.values())
+        self._model = model
+        self._pack_version = model._pack_version
+        self._keep = list(eng.ws.values()) + _collect_tensors(eng.P) + [eng._range_buf]
+
+    def stale(self):
+        m = self._model
+        return m._engine is not self._engine or m._pack_version != self._pack_version
+
+    def check_range(self):
+        """The trunk's range guard never runs inside a replay (its counter read synchronises): call this now and then
+        when serving from a graph.  Returns the counters (e4m3-saturated, fp16-clamped, conv1_1 hits) accumulated by
+        this engine since the last check and raises if the captured arithmetic left its range (re-capture after
+        ``model.set_trunk('f32')`` or with rescaled inputs)."""
+        eng = self._engine
+        sat, clamp, c11 = eng.read_range(reset=True)
+        if clamp > 0 or (c11 > 0 and eng.trunk != 'f16q8'):
+            raise RuntimeError('mmmot_amd: %d activation elements left the fp16 range inside a captured forward (trunk %s): '
+                               'the replayed results are wrong; lower the trunk (set_trunk) and capture again'
+                               % (clamp + c11, eng.trunk))
+        return sat, clamp, c11
 
     def __call__(self, crops=None, points=None):
+        if self.stale():
+            raise RuntimeError('mmmot_amd: this captured forward is stale - the model was re-packed (load_state_dict / '
+                               'invalidate / set_trunk / .to()) after capture(); capture again')
         if crops is not None and crops.data_ptr() != self.crops.data_ptr():
             self.crops.copy_(crops, non_blocking=True)
         if points is not None and points.data_ptr() != self.points.data_ptr():
@@ -334,6 +396,8 @@ class TrackingNet(nn.Module):
         self._engine = None
         self._engine_key = None
         self._plans = {}
+        self._pack_version = 0     # bumped whenever packed weights are REPLACED (captured graphs go stale)
+        self._head_versions = None  # parameter versions the live engine's head was packed from
 
     # ---- backend / packing ---------------------------------------------------
     def set_ops(self, ops):
@@ -355,7 +419,19 @@ class TrackingNet(nn.Module):
                                   softmax_mode=self.softmax_mode, neg_threshold=self.neg_threshold,
                                   score_arch=self.score_arch, end_mode=self.end_mode, trunk=self.trunk)
             self._plans = {}
+            self._pack_version += 1
+            self._head_versions = self._current_head_versions()
         return self._engine
+
+    _HEADS = ('fusion_module', 'w_det', 'w_link')
+
+    def _current_head_versions(self):
+        return tuple(v._version for k, v in self.state_dict().items() if k.split('.')[0] in self._HEADS)
+
+    def head_is_current(self):
+        """False once a head parameter / buffer was modified in place (``optimizer.step()``, the BatchNorm momentum
+        update) after the engine packed it."""
+        return self._engine is not None and self._head_versions == self._current_head_versions()
 
     def set_trunk(self, trunk):
         """Arithmetic of the VGG trunk (the other GEMMs follow: f16x3, or exact fp32 with 'f32'):
@@ -373,17 +449,26 @@ class TrackingNet(nn.Module):
     def invalidate(self):
         self._engine = None
         self._plans = {}
+        self._pack_version += 1
 
     def refresh_head(self):
         """Re-pack only the head's weights (fusion_module, w_det, w_link: 3 M of the 21 M parameters) into the live
         engine - what a training step on the head needs after ``optimizer.step()`` (mmmot_amd/backward.py); the
         encoders' packed weights (VGG hl16 / hq8 copies, PointNet) stay as they are."""
         eng = self.engine()
-        heads = ('fusion_module', 'w_det', 'w_link')
-        sd = {k: v for k, v in self.state_dict().items() if k.split('.')[0] in heads}
+        sd = {k: v for k, v in self.state_dict().items() if k.split('.')[0] in self._HEADS}
         P = pack_weights(sd, self.score_fusion_arch, next(self.parameters()).device)
+        # in place where the packed layout is unchanged (always, for a pure weight update): the packed tensors keep
+        # their addresses, so a captured hipGraph (GraphedForward) computes with the new weights on its next replay;
+        # anything that cannot be copied in place replaces the entry and marks captured graphs stale
+        inplace = True
         for k in ('fusion', 'w_det', 'w_link'):
-            eng.P[k] = P[k]
+            if not _copy_packed_(eng.P[k], P[k]):
+                eng.P[k] = P[k]
+                inplace = False
+        if not inplace:
+            self._pack_version += 1
+        self._head_versions = self._current_head_versions()
         return eng
 
     def _apply(self, fn, *a, **k):
@@ -392,6 +477,7 @@ class TrackingNet(nn.Module):
 
     def load_state_dict(self, state_dict, strict=True, **k):
         self._engine = None
+        self._pack_version += 1
         return super().load_state_dict(state_dict, strict=strict, **k)
 
     def make_plan(self, samples, crop_hw, rows=(0, 1, 2)):

@@ -8,6 +8,7 @@ there is no fallback.
 """
 import contextlib
 import ctypes
+import threading
 
 import torch
 
@@ -53,7 +54,17 @@ class HipOps:
     def __init__(self):
         self.lib = _lib.load()
         self._osvecs = {}
-        self._pinned_stream = None
+        # the stream a launch sequence was pinned to is per THREAD: two threads sharing one model, each under its own
+        # torch.cuda.stream(), must not see each other's pin
+        self._tls = threading.local()
+
+    @property
+    def _pinned_stream(self):
+        return getattr(self._tls, 'stream', None)
+
+    @_pinned_stream.setter
+    def _pinned_stream(self, v):
+        self._tls.stream = v
 
     def _osv(self, oscale, Cout, like):
         """The [Cout] per-output-channel scale vector of the trunk entry points; a python float (the kernel tests'
@@ -74,11 +85,12 @@ class HipOps:
         return torch.cuda.current_stream().cuda_stream
 
     @contextlib.contextmanager
-    def on_current_stream(self):
+    def on_current_stream(self, stream=None):
         """Resolve torch's current HIP stream once for a whole launch sequence (``torch.cuda.current_stream()`` costs
-        ~8 us per call - 0.6 ms over the ~80 launches of a forward); the stream must not change inside the block."""
+        ~8 us per call - 0.6 ms over the ~80 launches of a forward); the stream must not change inside the block.
+        ``stream``: the already resolved current stream (a torch.cuda.Stream), if the caller has it."""
         prev = self._pinned_stream
-        self._pinned_stream = torch.cuda.current_stream().cuda_stream
+        self._pinned_stream = (stream if stream is not None else torch.cuda.current_stream()).cuda_stream
         try:
             yield
         finally:
@@ -136,6 +148,12 @@ class HipOps:
             torch.cuda.current_stream().synchronize()
             _lib.check(self.lib.mmmot_trunk_range_read(buf, int(reset)), 'mmmot_trunk_range_read')
         return tuple(int(v) for v in buf)
+
+    def trunk_range_bind(self, counters):
+        """Counter block (int32 [4] device tensor, or None = the library's per-device block) the trunk launches issued
+        by this thread report to from now on (mmmot_trunk_range_bind)."""
+        _lib.check(self.lib.mmmot_trunk_range_bind(None if counters is None else _ptr(counters, torch.int32)),
+                   'mmmot_trunk_range_bind')
 
     def hq8_pack(self, x, y):
         _lib.check(self.lib.mmmot_hq8_pack(_ptr(x), _ptr(y), x.numel(), self._stream()), 'mmmot_hq8_pack')

@@ -16,6 +16,15 @@ device memory; they are not tensors and do not belong in an operator signature. 
 raise ``NotImplementedError`` from the dispatcher (no fallback).  Every operator has a Meta kernel (output shapes
 from the plan), so the path can be traced with FakeTensors / ``torch.compile`` graphs can carry it as an opaque node.
 The launches go to torch's current HIP stream; nothing synchronises.
+
+Contract the schema cannot express (the handles hide mutable state):
+  * every returned tensor is freshly allocated and no two outputs share storage (the engine's new / end scores live in
+    one buffer: ``end`` is copied out) - what the functional custom-op contract and the Meta kernels promise;
+  * the engine's workspace arena is scratch shared by all calls on that engine.  ``Engine.forward`` refuses a second
+    thread while a forward is being issued and orders a forward behind the previous one when the stream changed, so
+    eager use from any stream is safe; what is NOT supported is two calls on the SAME engine issued concurrently or
+    re-ordered as if independent (a compiler that treats the op as pure may do the latter only for calls whose
+    results are unused) - use one TrackingNet per concurrent stream.
 """
 import itertools
 import weakref
@@ -56,7 +65,7 @@ def _lookup(engine, plan):
 def _forward_batch(crops, points, engine, plan):
     eng, pl = _lookup(engine, plan)
     out = eng.forward(pl, crops, points)
-    return [out['det'], out['link'], out['new'], out['end']]
+    return [out['det'], out['link'], out['new'], out['end'].clone()]  # new / end share one buffer in the engine
 
 
 def _forward_batch_meta(crops, points, engine, plan):

@@ -38,6 +38,7 @@ class TorchOps:
     def __init__(self, dtype=torch.float32):
         self.dtype = dtype
         self.range = [0, 0, 0, 0]  # emulation of the trunk range-guard counters (mmmot_trunk_range_read)
+        self.range_bound = None    # the caller's counter block (mmmot_trunk_range_bind): int32 [4] tensor
 
     @staticmethod
     def _osv(oscale, Cout):
@@ -46,11 +47,20 @@ class TorchOps:
             return oscale.reshape(1, Cout, 1, 1).double()
         return torch.full((1, Cout, 1, 1), float(oscale), dtype=torch.float64)
 
+    def _count(self, i, n):
+        if self.range_bound is not None:
+            self.range_bound[i] += int(n)
+        else:
+            self.range[i] += int(n)
+
     def _guard(self, rows, q8):
         """rows: post-ReLU activations about to be stored; counts what the epilogue's range guard counts"""
         if q8:
-            self.range[0] += int((rows > 1792.0).sum())
-        self.range[1] += int((rows > 65000.0).sum())
+            self._count(0, (rows > 1792.0).sum())
+        self._count(1, (rows > 65000.0).sum())
+
+    def trunk_range_bind(self, counters):
+        self.range_bound = counters
 
     def trunk_range_read(self, device=None, reset=True):
         r = tuple(self.range)
@@ -88,7 +98,7 @@ class TorchOps:
         w1f = from_hl16(w1.reshape(64, 32)) * oscale1
         tmp = torch.zeros(L * H * W, 64)
         self.conv3x3(crops, w1f, bias1, tmp, L, H, W, 3, 64, True, False)
-        self.range[2] += int((tmp > 65000.0).any())
+        self._count(2, (tmp > 65000.0).any())
         self.conv3x3_hl16_patch(to_hl16(tmp.clamp(max=65000.0)), w2, bias2, out, L, H, W, 64, 64, True, oscale2)
 
     def _conv_hq8(self, x, wp, bias, L, H, W, Cin, Cout, pool, oscale):
@@ -115,7 +125,7 @@ class TorchOps:
         w1f = from_hl16(w1.reshape(64, 32)) * oscale1
         tmp = torch.zeros(L * H * W, 64)
         self.conv3x3(crops, w1f, bias1, tmp, L, H, W, 3, 64, True, False)
-        self.range[2] += int((tmp > 1792.0).any())
+        self._count(2, (tmp > 1792.0).any())
         rows = self._conv_hq8(hq8_parts(to_hq8_act(tmp)), w2, bias2, L, H, W, 64, 64, True, oscale2)
         self._guard(rows, True)
         out.reshape(-1)[:rows.numel()].view(-1, 64).copy_(to_hq8_act(rows))

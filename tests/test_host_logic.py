@@ -149,3 +149,38 @@ def test_custom_operators_are_registered_for_the_device_only():
     # stale handles are refused
     with pytest.raises(RuntimeError):
         torch.ops.mmmot.forward_batch(torch.empty(1, device='meta'), None, 10 ** 9, ph)
+
+
+def test_refresh_head_copies_in_place_and_parameter_edits_are_noticed():
+    """a captured graph holds raw pointers into the packed head; refresh_head() must keep the addresses
+    (in-place copy) and the engine must notice in-place parameter edits (optimizer.step) through the version counters"""
+    c, base = get_case('s2_C_multiply_none')
+    m = build_model(c, base, ops=TorchOps())
+    eng = m.engine()
+    ptrs = {k: v.data_ptr() for k, v in eng.P['w_link'].items() if torch.is_tensor(v)}
+    assert m.head_is_current()
+    before = m(*case_inputs(c))[1][0].clone()
+    with torch.no_grad():
+        m.w_link.conv1[3].weight.mul_(1.001)
+    assert not m.head_is_current()
+    assert m.refresh_head() is eng and m.head_is_current()
+    assert {k: v.data_ptr() for k, v in eng.P['w_link'].items() if torch.is_tensor(v)} == ptrs
+    after = m(*case_inputs(c))[1][0]
+    assert (after - before).abs().max() > 0      # the new weights are the ones that ran
+    v = m._pack_version
+    m.invalidate()
+    assert m._pack_version == v + 1              # replaced packs mark captured graphs stale
+
+
+def test_engine_refuses_concurrent_forwards():
+    """the workspace arena is shared mutable state behind an integer handle"""
+    c, base = get_case('s2_C_multiply_none')
+    m = build_model(c, base, ops=TorchOps())
+    eng = m.engine()
+    assert eng._busy.acquire(blocking=False)
+    try:
+        with pytest.raises(RuntimeError, match='concurrent forwards'):
+            m(*case_inputs(c))
+    finally:
+        eng._busy.release()
+    m(*case_inputs(c))

@@ -102,17 +102,47 @@ def test_calibrated_statistics_do_not_trip_the_guard():
     assert linf(out, ref) < 1e-3
 
 
-def test_guard_checks_on_the_first_forward_and_then_periodically():
+def test_guard_checks_synchronously_on_the_first_forward_and_on_request():
     m, sd, ins = build('calibrated', 0, 1.0)
     eng = m.engine()
     eng.range_check_every = 3
     reads = []
-    orig = eng.ops.trunk_range_read
-    eng.ops.trunk_range_read = lambda device=None, reset=True: (reads.append(eng._n_forward), orig(device, reset))[1]
+    orig = eng.read_range
+    eng.read_range = lambda reset=True: (reads.append(eng._n_forward), orig(reset))[1]
     with torch.no_grad():
         for _ in range(7):
             m(*ins)
-    assert reads == [0, 0, 3, 6]  # reset + check on the first forward, then every third
+    # per synchronous check: one read that opens the window, one after the trunk
+    assert reads == [0, 0, 3, 3, 6, 6]
+
+
+def test_guard_detects_one_step_late_without_synchronising():
+    """after the first forward the counters are read back asynchronously and inspected by the NEXT forward: a model that
+    leaves the range later (here: the weights are swapped under a live engine) is lowered one step late, with an event
+    that says the previous forward was affected; each engine counts in its own block"""
+    m, sd, (dets, info, ds) = build('calibrated', 0, 1.0)
+    eng = m.engine()
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter('error')
+        m(dets, info, ds)
+        m(dets, info, ds)
+    assert not eng.range_events and eng.trunk == 'f16q8'
+    other, _, _ = build('calibrated', 1, 1.0)  # a second engine on the same "device": its own counter block
+    with torch.no_grad():
+        other(dets, info, ds)
+    # blow conv3_1's gain up in the PACKED weights of the live engine (no re-pack: _n_forward keeps counting)
+    cv = eng.P['vgg'][4]
+    cv['bias'] = cv['bias'] + 3000.0
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter('error')
+        m(dets, info, ds)            # out of range, not yet noticed: no synchronous read on this forward
+    assert not eng.range_events
+    with torch.no_grad(), pytest.warns(RuntimeWarning, match='PREVIOUS forward'):
+        m(dets, info, ds)            # the read-back of the previous forward is inspected first
+    ev = eng.range_events[0]
+    assert ev['recomputed'] is False and ev['was'] == 'f16q8' and ev['e4m3_saturated'] > 0
+    assert eng.trunk in ('f16x3', 'f32')
+    assert not other.engine().range_events and other.engine().trunk == 'f16q8'
 
 
 def test_per_channel_shifts_follow_the_folded_gains():
