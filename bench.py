@@ -52,12 +52,23 @@ from mmmot_amd.synth import make_pair  # noqa: E402
 
 METRIC = 'frame-pairs/sec (fusion+affinity fwd) at N_det=64; affinity L∞ vs CPU ref'
 WORKLOADS = {
-    # name: (fusion, affinity_op, softmax_mode, N, M, S, pts/det, reference golden of the pair with seed 1000)
+    # name: (fusion, affinity_op, softmax_mode, N, M, S, pts/det, reference golden of the FIRST pair of the batch)
     'cfg3': ('C', 'multiply', 'none', 64, 64, 128, 2048, 'f_cfg3_C'),
-    'cfg2': ('A', 'multiply', 'none', 32, 32, 64, 512, None),
+    'cfg2': ('A', 'multiply', 'none', 32, 32, 64, 512, 's4_cfg2_A'),
     'cfg4': ('C', 'minus_abs', 'dual_add', 128, 128, 64, 512, 'f_cfg4_C'),
     'tiny': ('C', 'multiply', 'none', 6, 5, 32, 40, None),
 }
+# seed of the first pair of a workload's batch = the seed its reference golden was generated with (oracle/gen_golden.py)
+SEED0 = {'cfg2': 1004}
+# BASELINE.json `configs` beside the headline one, timed in the same default run and reported under extra.workloads:
+# (key, workload, pairs per step per GPU, modality rows).  cfg2 = configs[1] (batch = 32 frame pairs), cfg4 = configs[3]
+# (256 pairs over 8 GPUs = 32 per GPU), cfg5 = configs[4] (image-only / LiDAR-only rows at N_det = 64, cfg3 shapes).
+EXTRA_WORKLOADS = [
+    ('cfg2_b32', 'cfg2', 32, (0, 1, 2)),
+    ('cfg4_b32_per_gpu', 'cfg4', 32, (0, 1, 2)),
+    ('cfg5_image_only', 'cfg3', 8, (0,)),
+    ('cfg5_lidar_only', 'cfg3', 8, (1,)),
+]
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide: BF16/F16 MFMA dense peak (AMD's 5 PF figure is 2:1 sparse)
 HEADLINE_TRUNK = 'f16x3'       # fp32-class arithmetic: what `value` is measured in unless --trunk says otherwise
@@ -72,6 +83,27 @@ def reference_flops_per_pair(N, M, S, P, fusion):
     f_fus = 524288 if fusion in ('A', 'B') else 1048576
     return 2 * (L * (305856 * S * S + 204800) + P * 991625 + L * 262144 + 2.36e6 + L * f_fus + 3 * L * 393472 +
                 3 * N * M * 852096 + 3 * L * 327808)
+
+
+def executed_flops_per_pair(N, M, S, P, fusion, rows=(0, 1, 2)):
+    """F_exec: FLOPs (2 x MAC) of the math this build actually executes per frame pair.  Against
+    F_ref: STN trunks removed (-282 816 MAC/pt), 1088->512 split (-524 288 MAC/pt, +524 288 MAC/det); added: the second
+    (normalise + segment-sum) pass of PointNet_v1.conv1 64->512 (+32 768 MAC/pt) and the 128x128 Gram matrix behind
+    conv5's statistics (+16 384 MAC/pt).  The conv trunk term is F_ref's.  Single-modality rows drop the other branch
+    and the fusion module, and run the head on one row."""
+    L = N + M
+    nR = len(rows)
+    img = (0 in rows) or (2 in rows)
+    pts = (1 in rows) or (2 in rows)
+    f = 0.0
+    if img:
+        f += L * (305856 * S * S + 204800)
+    if pts:
+        f += P * (184521 + 32768 + 16384) + L * (524288 + 262144)
+    if nR == 3:
+        f += L * (524288 if fusion in ('A', 'B') else 1048576)
+    f += nR * L * 393472 + nR * N * M * 852096 + nR * L * 327808
+    return 2.0 * f
 
 
 def parse_args(argv=None):
@@ -91,7 +123,14 @@ def parse_args(argv=None):
                     help="comma list of further trunk modes timed in the same run and reported under 'extra' "
                          "(default: the other one of f16x3 / f16q8; 'none' disables)")
     ap.add_argument('--no-latency', action='store_true', help='skip the B=1 reference-call latency extra')
+    ap.add_argument('--no-workloads', action='store_true',
+                    help='skip extra.workloads (the other BASELINE.json configs: cfg2 B=32, cfg4 32 pairs/GPU, cfg5 rows)')
+    ap.add_argument('--rows', default='0,1,2', help='modality rows of the headline workload (cfg5: 0 = image-only, 1 = LiDAR-only)')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='initialise torch.distributed (RCCL) and run the collective path of the N-GPU run even with one GPU')
     ap.add_argument('--latency-only', action='store_true', help='run only the B=1 latency leg (profiling)')
+    ap.add_argument('--rccl-world1-child', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--device', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--dry', action='store_true',
                     help='CPU / gloo dry run of the launcher, sharding, gather, timing and JSON with a stub step')
     return ap.parse_args(argv)
@@ -142,9 +181,25 @@ def max_over_ranks(dt, world, dev):
     return dt
 
 
-def roofline_of(trunk, events, eng, B, workload, dt):
+def roofline_of(trunk, events, eng, B, workload, dt, rows=(0, 1, 2)):
     """Roofline entry of the dominant kernel from the HIP events recorded around every trunk launch."""
     per_layer = {}
+    tagged = [ev for ev in events if isinstance(ev[0], str)]   # non-trunk launches the engine brackets ('pn5')
+    events = [ev for ev in events if not isinstance(ev[0], str)]
+    if not events:
+        # LiDAR-only rows: no trunk.  Dominant kernel = PointNet conv5 128 -> 1024 (normalise + segment-sum pass).
+        ms = sum(e0.elapsed_time(e1) for _, _, _, _, e0, e1 in tagged)
+        fl = sum(2.0 * r * k * n for _, r, k, n, _, _ in tagged)
+        f16 = trunk != 'f32'
+        peak = PEAK_F16_MFMA_TFLOPS / 3.0 if f16 else PEAK_F32_MFMA_TFLOPS
+        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        roof = {'bound': 'mfma', 'kernel': 'gemm_ares_kernel<K=128> (PointNet conv5 128->1024 + GroupNorm + ReLU + '
+                'per-detection mean, second pass; 1 launch/step)', 'achieved': round(ach, 2), 'peak': round(peak, 1),
+                'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': None,
+                'algorithmic_bytes_per_launch': round(sum(r * k * 4.0 for _, r, k, _, _, _ in tagged) / max(len(tagged), 1)),
+                'avg_launch_ms': round(ms / max(len(tagged), 1), 4), 'share_of_step': round(ms / (dt * 1e3), 4),
+                'flops_basis': 'algorithmic 2*K*N per point', 'peak_basis': '2500/3 (f16x3 row GEMMs)' if f16 else 'fp32 MFMA'}
+        return roof, {}
     for li, rows, cin, cout, e0, e1 in events:
         ms = e0.elapsed_time(e1)
         a = per_layer.setdefault(li, [0.0, 0.0, 0, rows, cin, cout])
@@ -200,15 +255,88 @@ def roofline_of(trunk, events, eng, B, workload, dt):
     return roof, layers
 
 
-def golden_linf(res0, name):
-    """L-inf of one sample's (det, links, new, end) against the committed output of the imported reference."""
+def golden_linf(res0, name, rows=(0, 1, 2)):
+    """L-inf of one sample's (det, links, new, end) against the committed output of the imported reference
+    (``rows``: the modality rows the sample holds - the single-modality paths are rows 0 / 1 of the same golden)."""
     path = os.path.join(ROOT, 'tests', 'golden', name + '.npz')
     if not os.path.exists(path):
         return None
     g = np.load(path)
+    r = list(rows)
     det, links, new, end = res0
-    return float(max(np.abs(det.cpu().numpy() - g['det']).max(), np.abs(links[0].cpu().numpy() - g['link0']).max(),
-                     np.abs(new.cpu().numpy() - g['new']).max(), np.abs(end.cpu().numpy() - g['end']).max()))
+    return float(max(np.abs(det.cpu().numpy() - g['det'][r]).max(), np.abs(links[0].cpu().numpy() - g['link0'][r]).max(),
+                     np.abs(new.cpu().numpy() - g['new'][r]).max(), np.abs(end.cpu().numpy() - g['end'][r]).max()))
+
+
+def init_single_rank_env():
+    """rendezvous environment of a one-rank process group on this node (127.0.0.1, a free port)"""
+    sk = socket.socket()
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', str(port))
+    os.environ.setdefault('RANK', '0')
+    os.environ.setdefault('WORLD_SIZE', '1')
+    os.environ.setdefault('LOCAL_RANK', '0')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+
+def rccl_world1_leg(dev):
+    """rccl_world1_child() in a child process (its own process group and RCCL banner lines stay out of this process's
+    stdout, which carries exactly one JSON line; a crash inside RCCL cannot take the benchmark line with it)."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    for k in ('MASTER_ADDR', 'MASTER_PORT', 'RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), '--rccl-world1-child', '--device', str(dev.index or 0)],
+                           capture_output=True, text=True, timeout=180, env=env)
+        for line in reversed(p.stdout.splitlines()):
+            if line.startswith('RCCL_WORLD1 '):
+                return json.loads(line[len('RCCL_WORLD1 '):])
+        return {'ok': False, 'error': 'child rc=%d: %s' % (p.returncode, (p.stderr or p.stdout)[-300:])}
+    except Exception as e:  # noqa: BLE001
+        return {'ok': False, 'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
+
+
+def rccl_world1_child(dev):
+    """The exact collective call sequence of the N-GPU step on ONE GPU: init_process_group('nccl') with world size 1,
+    barrier, the flat all_gather_into_tensor of the scores (equal and ragged form), the max-over-ranks all_reduce.
+    Proves the RCCL branch executes on this box; says nothing about scaling.  Never raises: a failure is reported."""
+    import torch.distributed as dist
+    from mmmot_amd.dist import gather_flat
+    info = {'backend': 'nccl (RCCL)', 'world_size': 1}
+    try:
+        init_single_rank_env()
+        dist.init_process_group('nccl', device_id=dev)
+        res = [(torch.rand(3, 128, device=dev), [torch.rand(3, 64, 64, device=dev)], torch.rand(3, 128, device=dev),
+                torch.rand(3, 128, device=dev)) for _ in range(8)]  # 8 cfg3-shaped score sets
+        got = gather_results(res, same_layout=True, force=True)
+        ok = len(got) == 8 and all(torch.equal(a[1][0], b[1][0]) and torch.equal(a[0], b[0]) for a, b in zip(got, res))
+        flat = torch.arange(1000, dtype=torch.float32, device=dev)
+        rag = gather_flat(flat, equal=False, force=True)
+        ok = ok and len(rag) == 1 and torch.equal(rag[0], flat)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            gather_results(res, same_layout=True, force=True)
+        torch.cuda.synchronize()
+        info['gather_us_per_step'] = round((time.perf_counter() - t0) / 20 * 1e6, 1)
+        info['max_over_ranks_ok'] = abs(max_over_ranks(1.25, 2, dev) - 1.25) < 1e-12  # the all_reduce(MAX) of the timing
+        info['ok'] = bool(ok)
+        dist.destroy_process_group()
+    except Exception as e:  # noqa: BLE001 - reported, the benchmark line must still be printed
+        info['ok'] = False
+        info['error'] = '%s: %s' % (type(e).__name__, str(e)[:300])
+        try:
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
+    return info
 
 
 def cpu_baseline(model, ins, res, fusion, aff, sm, N, M, n_timed):
@@ -323,6 +451,10 @@ def latency_b1(dev, trunk):
 
 def main():
     args = parse_args()
+    if args.rccl_world1_child:
+        torch.cuda.set_device(args.device)
+        print('RCCL_WORLD1 ' + json.dumps(rccl_world1_child(torch.device('cuda', args.device))), flush=True)
+        return
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         relaunch_under_torchrun(args)  # does not return
     rank = int(os.environ.get('RANK', 0))
@@ -376,79 +508,107 @@ def main():
     if args.latency_only:
         print(json.dumps(latency_b1(dev, args.trunk)), flush=True)
         return
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         import torch.distributed as dist
+        if world == 1 and 'MASTER_ADDR' not in os.environ:
+            init_single_rank_env()
         dist.init_process_group('nccl', device_id=dev)
 
-    model = TrackingNet(**dict(BASE_KW, score_fusion_arch=fusion, affinity_op=aff, softmax_mode=sm))
-    init_module(model, seed=0)
-    model.eval().to(dev)
-
-    # synthetic batch: distinct seeds per global pair index; inputs resident in HBM before timing
-    ins = [make_pair(N, M, S, pts, seed=1000 + i) for i in range(lo, hi)]
-    samples = [([N, M], x[1]['points_split'].reshape(-1).long().numpy()) for x in ins]
-    plan = model.make_plan(samples, S)
-    crops = torch.cat([x[0] for x in ins]).to(dev)
-    points = torch.cat([x[1]['points'].reshape(-1, 3) for x in ins]).to(dev)
-    torch.cuda.synchronize()
-
     def barrier():
-        if world > 1:
+        if dist_on:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_leg(trunk, graph=args.graph):
+    def build_workload(name, Bw, rows, first):
+        """model + plan + device-resident inputs of `Bw` frame pairs (global pair indices first .. first + Bw - 1)"""
+        fusion_, aff_, sm_, N_, M_, S_, pts_, gold_ = WORKLOADS[name]
+        mdl = TrackingNet(**dict(BASE_KW, score_fusion_arch=fusion_, affinity_op=aff_, softmax_mode=sm_))
+        init_module(mdl, seed=0)
+        mdl.eval().to(dev)
+        seed0 = SEED0.get(name, 1000)
+        # synthetic batch: distinct seeds per global pair index; inputs resident in HBM before timing
+        ins_ = [make_pair(N_, M_, S_, pts_, seed=seed0 + i) for i in range(first, first + Bw)]
+        need_img, need_pts = (0 in rows) or (2 in rows), (1 in rows) or (2 in rows)
+        samples = [([N_, M_], x[1]['points_split'].reshape(-1).long().numpy() if need_pts else None) for x in ins_]
+        plan_ = mdl.make_plan(samples, S_, rows=rows)
+        crops_ = torch.cat([x[0] for x in ins_]).to(dev) if need_img else None
+        points_ = torch.cat([x[1]['points'].reshape(-1, 3) for x in ins_]).to(dev) if need_pts else None
+        torch.cuda.synchronize()
+        return dict(name=name, model=mdl, plan=plan_, crops=crops_, points=points_, ins=ins_, rows=rows, B=Bw,
+                    gold=gold_, shape=(N_, M_, S_, pts_, fusion_))
+
+    def run_leg(wl, trunk, steps, warmup, graph=False):
         """W warm-up steps, then exactly K timed steps between barrier + synchronize brackets, max over ranks."""
-        model.set_trunk(trunk)
-        eng = model.engine()
+        mdl, plan_, crops_, points_ = wl['model'], wl['plan'], wl['crops'], wl['points']
+        mdl.set_trunk(trunk)
+        eng = mdl.engine()
 
         def step():
-            res = model.forward_batch(plan, crops, points)
+            res = mdl.forward_batch(plan_, crops_, points_)
             if not args.no_gather:
-                res = gather_results(res, same_layout=True)  # trivial for world == 1
+                res = gather_results(res, same_layout=True, force=args.force_dist)  # trivial for one process
             return res
 
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             step()
         if graph:
             # the C-ABI entry points only launch (no allocation, no synchronisation): the whole step is capturable
-            graphed = model.capture(plan, crops, points)
+            graphed = mdl.capture(plan_, crops_, points_)
 
             def step():  # noqa: F811
-                res = graphed(crops, points)
+                res = graphed(crops_, points_)
                 if not args.no_gather:
-                    res = gather_results(res, same_layout=True)
+                    res = gather_results(res, same_layout=True, force=args.force_dist)
                 return res
             step()
         eng.conv_events = []
-        dt, res = time_steps(step, args.steps, barrier)
+        dt, res = time_steps(step, steps, barrier)
         events, eng.conv_events = eng.conv_events, None
         dt = max_over_ranks(dt, world, dev)
-        roof, layers = roofline_of(trunk, events, eng, B, args.workload, dt)
-        leg = {'value': round(args.steps * B * world / dt, 4), 'ms_per_step': round(dt / args.steps * 1e3, 3),
-               'dtype': trunk, 'roofline': roof}
-        if rank == 0 and gold_name is not None:
-            leg['linf_vs_reference_golden'] = golden_linf(res[0], gold_name)
+        roof, layers = roofline_of(trunk, events, eng, wl['B'], wl['name'], dt, wl['rows'])
+        N_, M_, S_, pts_, fusion_ = wl['shape']
+        value = steps * wl['B'] * world / dt
+        fexec = executed_flops_per_pair(N_, M_, S_, (N_ + M_) * pts_, fusion_, wl['rows'])
+        leg = {'value': round(value, 4), 'ms_per_step': round(dt / steps * 1e3, 3), 'dtype': trunk, 'roofline': roof,
+               'exec_gflop_per_pair': round(fexec / 1e9, 1),
+               'exec_tflops_equiv_per_gpu': round(fexec * value / 1e12 / world, 2)}
+        if trunk == 'f16x3':
+            leg['whole_step_frac_of_f16x3_peak'] = round(fexec * value / 1e12 / world / (PEAK_F16_MFMA_TFLOPS / 3.0), 4)
+        if rank == 0 and wl['gold'] is not None:
+            leg['linf_vs_reference_golden'] = golden_linf(res[0], wl['gold'], wl['rows'])
         return leg, res, layers
 
-    head, res, layers = run_leg(args.trunk)
+    rows = tuple(int(r) for r in args.rows.split(',') if r != '')
+    head_wl = build_workload(args.workload, B, rows, lo)
+    model, ins = head_wl['model'], head_wl['ins']
+    head, res, layers = run_leg(head_wl, args.trunk, args.steps, args.warmup, graph=args.graph)
     value = head['value']
     fref = reference_flops_per_pair(N, M, S, (N + M) * pts, fusion)
     out = {
         'metric': METRIC, 'value': value, 'unit': 'frame-pairs/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': head['ms_per_step'], 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': args.trunk, 'data': 'synthetic',
-        'config': {'workload': '%s: Fusion %s, %s/%s, N=M=%d (%d crops of %dx%d), %d pts/det; %d pairs/step/GPU' % (
-            args.workload, fusion, aff, sm, N, N + M, S, S, pts, B), 'pairs_per_step_per_gpu': B, 'trunk': args.trunk,
-            'parallelism': 'sample-sharded x%d, flat all_gather of scores' % world, 'hipgraph': bool(args.graph)},
+        'config': {'workload': '%s: Fusion %s, %s/%s, N=M=%d (%d crops of %dx%d), %d pts/det; %d pairs/step/GPU%s' % (
+            args.workload, fusion, aff, sm, N, N + M, S, S, pts, B,
+            '' if rows == (0, 1, 2) else '; modality rows %s' % (rows,)), 'pairs_per_step_per_gpu': B, 'trunk': args.trunk,
+            'parallelism': 'sample-sharded x%d, flat all_gather of scores' % world, 'hipgraph': bool(args.graph),
+            'rccl': bool(dist_on)},
         'roofline': head['roofline'],
-        'end_to_end': {'ref_gflop_per_pair': round(fref / 1e9, 1), 'ref_tflops_equiv': round(fref * value / 1e12 / world, 2)},
+        'end_to_end': {
+            'ref_gflop_per_pair': round(fref / 1e9, 1), 'ref_tflops_equiv': round(fref * value / 1e12 / world, 2),
+            'exec_gflop_per_pair': head['exec_gflop_per_pair'], 'exec_tflops_equiv': head['exec_tflops_equiv_per_gpu'],
+            'whole_step_frac_of_f16x3_peak': head.get('whole_step_frac_of_f16x3_peak'),
+            'basis': 'F_ref = reference-as-written FLOPs (SURVEY 8d); F_exec = FLOPs of the math executed (STN trunks and '
+                     'the 1088->512 broadcast eliminated, second PointNet_v1.conv1 pass and the Gram matrix added); '
+                     'whole-step fraction = F_exec x pairs/s / GPU / (2500/3) - north_star target >= 0.50'},
         'parity': {'tolerance': 1e-3},
     }
     if head.get('linf_vs_reference_golden') is not None:
         out['parity']['linf_vs_reference_golden'] = head['linf_vs_reference_golden']
-        out['parity']['golden'] = 'tests/golden/%s.npz (output of the imported reference on the pair with seed 1000)' % gold_name
+        out['parity']['golden'] = ('tests/golden/%s.npz (output of the imported reference on the first pair of the batch)'
+                                   % head_wl['gold'])
     if rank == 0:
         try:
             os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
@@ -458,7 +618,7 @@ def main():
             pass
 
     # ---- CPU baseline + parity on the same inputs (rank 0, single-GPU runs only) ----
-    if rank == 0 and world == 1 and args.cpu_pairs > 0:
+    if rank == 0 and world == 1 and args.cpu_pairs > 0 and rows == (0, 1, 2):
         base, linf = cpu_baseline(model, ins, res, fusion, aff, sm, N, M, max(args.cpu_pairs, 1))
         out['cpu_baseline'] = base
         out['parity']['linf_vs_cpu_oracle'] = linf
@@ -469,21 +629,42 @@ def main():
         extra = {'f16x3': 'f16q8', 'f16q8': 'f16x3'}.get(args.trunk, 'none')
     out['extra'] = {}
     for t in [t for t in extra.split(',') if t and t != 'none' and t != args.trunk]:
-        leg, _, _ = run_leg(t)
+        leg, _, _ = run_leg(head_wl, t, args.steps, args.warmup)
         out['extra'][t] = leg
     if not args.graph and extra != 'none':
         # the headline arithmetic again, the step captured once in a hipGraph and replayed (same K / W; no per-launch
         # HIP events inside a graph, so no roofline entry for this leg)
-        leg, _, _ = run_leg(args.trunk, graph=True)
+        leg, _, _ = run_leg(head_wl, args.trunk, args.steps, args.warmup, graph=True)
         out['extra'][args.trunk + '_hipgraph'] = {k: leg[k] for k in ('value', 'ms_per_step', 'dtype', 'linf_vs_reference_golden')
                                                   if k in leg}
+    del head_wl, model, ins, res
+    torch.cuda.empty_cache()
+
+    # ---- the other BASELINE.json configs at their batch sizes (same arithmetic, same K / W) ----
+    if not args.no_workloads and args.workload == 'cfg3' and rows == (0, 1, 2):
+        wls = {}
+        for key, name, Bw, wrows in EXTRA_WORKLOADS:
+            wl = build_workload(name, Bw, wrows, rank * Bw)
+            leg, _, _ = run_leg(wl, args.trunk, args.steps, args.warmup)
+            N_, M_, S_, pts_, fusion_ = wl['shape']
+            leg['config'] = '%s: Fusion %s, N=M=%d, %dx%d crops, %d pts/det, %d pairs/step/GPU, modality rows %s' % (
+                name, fusion_, N_, S_, S_, pts_, Bw, wrows)
+            leg['unit'] = 'frame-pairs/s'
+            wls[key] = leg
+            del wl
+            torch.cuda.empty_cache()
+        out['extra']['workloads'] = wls
+
+    # ---- the collective path of the N-GPU run, executed on this one GPU (RCCL, world size 1) ----
+    if rank == 0 and world == 1 and not dist_on and not args.no_workloads:
+        out['extra']['rccl_world1'] = rccl_world1_leg(dev)
+
     if rank == 0 and world == 1 and not args.no_latency:
-        del crops, points
         out['extra']['latency'] = latency_b1(dev, args.trunk)
 
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         dist.destroy_process_group()
 

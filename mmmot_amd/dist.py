@@ -51,12 +51,15 @@ def unflatten_results(flat, layout):
     return out
 
 
-def gather_flat(flat, group=None, equal=False):
+def gather_flat(flat, group=None, equal=False, force=False):
     """All-gather variable-length fp32 vectors: returns the list of every rank's vector.
     One length exchange + one padded all_gather_into_tensor (no per-tensor collectives);
     ``equal=True`` (every rank holds the same number of elements) skips the length exchange and
-    its device-to-host read-back."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    its device-to-host read-back.  A one-rank group returns its input without any collective unless
+    ``force`` (tests / ``bench.py --force-dist``: the N-rank call sequence on one GPU)."""
+    if not dist.is_available() or not dist.is_initialized():
+        return [flat]
+    if dist.get_world_size(group) == 1 and not force:
         return [flat]
     world = dist.get_world_size(group)
     if equal:
@@ -75,11 +78,14 @@ def gather_flat(flat, group=None, equal=False):
     return [out[r * mx:r * mx + sizes[r]] for r in range(world)]
 
 
-def gather_results(results, group=None, same_layout=False):
+def gather_results(results, group=None, same_layout=False, force=False):
     """Per-rank list of per-sample results -> list over ALL samples in global (rank-major) order.
     ``same_layout=True`` (every rank holds identically shaped samples, e.g. the synthetic
-    benchmark) skips the python-object exchange of shapes: one length + one data collective."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    benchmark) skips the python-object exchange of shapes: one length + one data collective.
+    ``force``: run the pack / collective / unpack sequence even in a one-rank group."""
+    if not dist.is_available() or not dist.is_initialized():
+        return list(results)
+    if dist.get_world_size(group) == 1 and not force:
         return list(results)  # single process: the results already are the global list (no packing, no copy)
     flat, layout = flatten_results(results)
     world = dist.get_world_size(group)
@@ -88,7 +94,7 @@ def gather_results(results, group=None, same_layout=False):
     else:
         layouts = [None] * world
         dist.all_gather_object(layouts, layout, group=group)
-    flats = gather_flat(flat, group, equal=same_layout)
+    flats = gather_flat(flat, group, equal=same_layout, force=force)
     out = []
     for f, l in zip(flats, layouts):
         out += unflatten_results(f, l)

@@ -395,8 +395,14 @@ class Engine:
                 ops.gemm_ares(pn['w5_h16'], pn['w5_os'], TD, 1024, 128, x, sc, sh, bias=pn['b5'], part=part)
                 sc5, sh5 = self._finalize('pn5', part, TH, 1024, 1024, pn['g5'], pn['be5'])
             cs = self.buf('pn_colsum', TH.T, 1024)
+            if self.conv_events is not None:  # bench.py: HIP events around PointNet's dominant launch
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             ops.gemm_ares(pn['w5_h16'], pn['w5_os'], TD, 1024, 128, x, sc, sh, bias=pn['b5'], osc=sc5, osh=sh5,
                           colsum=cs)
+            if self.conv_events is not None:
+                e1.record()
+                self.conv_events.append(('pn5', Pn, 128, 1024, e0, e1))
             ops.segment_mean(cs, 1024, plan.det_half_segs, seg1024)
         elif fused:
             part = self._part(TD, 1024)

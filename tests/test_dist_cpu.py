@@ -81,3 +81,30 @@ def test_bench_single_command_launcher_dry_run():
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['steps'] == 3 and out['warmup'] == 1 and out['gather_ok'] is True
     assert out['scaling'] == 'weak' and out['config']['pairs_per_step_per_gpu'] == 3
+
+
+def test_forced_one_rank_gather_runs_the_collectives():
+    """``force=True`` (bench.py --force-dist, tests/test_rccl_gpu.py): a one-rank group still packs, all-gathers and
+    unpacks - the call sequence of the N-rank step"""
+    import socket
+    sk = socket.socket()
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1')
+    dist.init_process_group('gloo', rank=0, world_size=1)
+    try:
+        calls = []
+        orig = dist.all_gather_into_tensor
+        dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            res = [fake_result(5, 3, 4), fake_result(6, 3, 4)]
+            assert gather_results(res, same_layout=True) is not res and not calls   # default: no collective
+            got = gather_results(res, same_layout=True, force=True)
+            assert len(calls) == 1 and all(torch.equal(a[1][0], b[1][0]) for a, b in zip(got, res))
+            rag = gather_flat(torch.arange(7, dtype=torch.float32), equal=False, force=True)
+            assert len(calls) == 3 and torch.equal(rag[0], torch.arange(7, dtype=torch.float32))
+        finally:
+            dist.all_gather_into_tensor = orig
+    finally:
+        dist.destroy_process_group()

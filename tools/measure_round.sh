@@ -8,7 +8,7 @@ O=$R/gpurun_out/$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 400 python $R/bench.py > $O/bench_default.log 2>&1
-Q="--cpu-pairs 0 --extra-trunks none --no-latency"
+Q="--cpu-pairs 0 --extra-trunks none --no-latency --no-workloads"
 rm -rf /tmp/prof_stats
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -- python $R/bench.py --steps 4 --warmup 1 $Q > $O/rocprof_stats_run.log 2>&1
 python $R/tools/rocpd_summary.py stats $(find /tmp/prof_stats -name "*_results.db" | head -1) > $O/rocprofv3_kernel_stats_cfg3_pairs8_f16x3.txt 2>&1
