@@ -112,7 +112,7 @@ def parse_args(argv=None):
     ap.add_argument('--steps', type=int, default=6)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='cfg3', choices=sorted(WORKLOADS))
-    ap.add_argument('--pairs', type=int, default=8, help='frame pairs per step per GPU')
+    ap.add_argument('--pairs', type=int, default=16, help='frame pairs per step per GPU')
     ap.add_argument('--cpu-pairs', type=int, default=3, help='timed pairs of the CPU baseline (0 disables)')
     ap.add_argument('--no-gather', action='store_true')
     ap.add_argument('--graph', action='store_true', help='capture the launch sequence of one step in a hipGraph and replay it')

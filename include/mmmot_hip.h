@@ -55,6 +55,10 @@ extern "C" {
 #define MMMOT_PAIR_MINUS 2     /* batch_minus     gcn.py:31-41 */
 
 /* softmax modes (reference modules/tracking_net.py:106-126) */
+/* elementwise loss terms of mmmot_score_loss (reference cost.py:97-131) */
+#define MMMOT_LOSS_BCE 0        /* F.binary_cross_entropy_with_logits */
+#define MMMOT_LOSS_L2 1         /* F.mse_loss(score.mul(mask), gt) */
+#define MMMOT_LOSS_SMOOTH_L1 2  /* F.smooth_l1_loss(score.mul(mask), gt) */
 #define MMMOT_SM_SINGLE 1
 #define MMMOT_SM_DUAL 2
 #define MMMOT_SM_DUAL_ADD 3
@@ -474,6 +478,29 @@ int mmmot_fusion_c_bwd(const float* dFu, const float* Y0, int ld0, const float* 
                        float* DN0, float* DN1, int C, void* stream);
 /* Y[r][c] = A[r][c] + B[r][c] (two gradient paths into one feature); C % 4 == 0 */
 int mmmot_add_rows(const float* A, int lda, const float* B, int ldb, float* Y, int ldy, long R, int C, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Training step, second slice (ABI 6, additive): LiDAR-encoder backward helpers and the loss (csrc/train.hip).
+ *
+ * mmmot_rows_gather_scale: backward of the per-detection average pools of PointNet (reference
+ * modules/point_net.py:32-39 and 139-148: `avg_pool(x[:, :, start:end])`, for conv5 followed by `.repeat` back to the
+ * points): X[r][c] = S[rowidx[r]][c] * scale[rowidx[r]]  (scale = 1 / points of the detection; NULL = 1).  C % 4 == 0. */
+int mmmot_rows_gather_scale(const float* S, int lds, const int* rowidx, const float* scale, float* X, int ldx, long R,
+                            int C, void* stream);
+/* weight / bias gradient of PointNetfeatGN.conv1 with the first transform folded in (forward: mmmot_pointnet_layer1;
+ * reference modules/point_net.py:119-125): per-tile partials PW[t][c * (K + 1) + k] = sum_r dY[r][c] X[r][k] (k < K),
+ * [..][K] = sum_r dY[r][c]; dY [P][64], X [P][K], K = 3 | 4.  The caller adds the T partial rows. */
+int mmmot_pointnet_layer1_bwd(const float* dY, const float* X, int K, const int* tile_row0, const int* tile_nrows, int T,
+                              float* PW, void* stream);
+/* One term of TrackingLoss (reference cost.py:134-185: DetLoss :97-131 on det / new / end scores, LinkLoss :66-94 on a
+ * link block) with its gradient: x [R][C] scores (R modality rows), y [C] target shared by the rows, mask
+ * m(c) = mr(mrow[c / M]) * mc(mcol[c % M]) (NULL vectors: 1) with mask_mode 1: v == 1 (LinkLoss' `gt_det == 1`),
+ * 2: v != ignore (DetLoss' ignore_index), 0: no mask.  g[r][c] = scale * dl/dx, PL[b] = scale * sum of l over block b's
+ * elements (b < nblocks), added to the value PL[b] holds when accumulate != 0 (one block: the terms of a loss add up in
+ * PL[0], launch after launch on one stream); scale = ratio / (R * C) reproduces the reference's reduction='mean'. */
+int mmmot_score_loss(const float* x, int ldx, const float* y, const float* mrow, const float* mcol, int M, int mask_mode,
+                     float ignore, int kind, float scale, int R, int C, float* g, int ldg, float* PL, int nblocks,
+                     int accumulate, void* stream);
 
 /* MFMA fragment-layout self test: C[32][32] = A[32][K] * B[32][K]^T through
  * the same fragment mapping the GEMM kernels use (K % 8 == 0). */

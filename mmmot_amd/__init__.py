@@ -7,7 +7,9 @@ Public surface mirrors the reference's ``modules`` package + ``build_model``:
 from .modules import (AppearanceNet, NewEndIndicator_v2, PointNet_v1, SkipPool, TrackingNet,  # noqa: F401
                       affinity_module, fusion_module_A, fusion_module_B, fusion_module_C)
 
-__all__ = ['TrackingNet', 'AppearanceNet', 'PointNet_v1', 'SkipPool', 'NewEndIndicator_v2', 'affinity_module',
+from .train import TrackingLoss  # noqa: E402,F401  (reference cost.py:134-185; mmmot_amd/train.py)
+
+__all__ = ['TrackingLoss', 'build_criterion', 'TrackingNet', 'AppearanceNet', 'PointNet_v1', 'SkipPool', 'NewEndIndicator_v2', 'affinity_module',
            'fusion_module_A', 'fusion_module_B', 'fusion_module_C', 'build_model', 'model_kwargs_from_config']
 
 
@@ -29,3 +31,11 @@ def build_model(config):
     """Drop-in for reference ``utils.build_util.build_model`` (accepts an EasyDict or a plain dict)."""
     common = config if 'model' in config else config['common']
     return TrackingNet(**model_kwargs_from_config(common))
+
+
+def build_criterion(loss_cfg):
+    """Drop-in for reference ``utils.build_util.build_criterion`` (utils/build_util.py:147-155): ``config['common']['loss']``."""
+    g = lambda k, d=None: (loss_cfg.get(k, d) if hasattr(loss_cfg, 'get') else getattr(loss_cfg, k, d))
+    return TrackingLoss(smooth_ratio=g('smooth_ratio', 0), detloss_type=g('det_loss', 'bce'), det_ratio=g('det_ratio', 0.4),
+                        trans_ratio=g('trans_ratio', 0.4), trans_last=g('trans_last', False),
+                        linkloss_type=g('link_loss', 'l2_softmax'))

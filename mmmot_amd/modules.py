@@ -396,6 +396,7 @@ class TrackingNet(nn.Module):
         self._engine = None
         self._engine_key = None
         self._plans = {}
+        self.freeze_appearance = False  # training mode: opt-in to frozen eval-mode image features (mmmot_amd/train.py)
         self._pack_version = 0     # bumped whenever packed weights are REPLACED (captured graphs go stale)
         self._head_versions = None  # parameter versions the live engine's head was packed from
 
@@ -490,8 +491,9 @@ class TrackingNet(nn.Module):
         """crops [Lt,3,S,S], points [P,3] (device, concatenated over the plan's samples).
         Returns per-sample reference-shaped tuples."""
         if self.training:
-            raise NotImplementedError('mmmot_amd.TrackingNet computes the eval-mode forward only (call .eval(); the '
-                                      'training-mode forward / backward of tracking_model.py:50-66 is not built)')
+            raise NotImplementedError('forward_batch / forward_rows compute the eval-mode forward (call .eval()); the '
+                                      'training-mode forward of tracking_model.py:50-66 is model(dets, det_info, dets_split) '
+                                      'after .train() - mmmot_amd/train.py')
         eng = self.engine()
         if eng.ops.name == 'hip':
             # the registered PyTorch-ROCm operator (mmmot_amd/torch_ops.py): CUDA dispatch key only, no CPU kernel
@@ -529,8 +531,13 @@ class TrackingNet(nn.Module):
 
     # ---- reference entry ------------------------------------------------------
     def forward(self, dets, det_info, dets_split):
-        """Same contract as reference modules/tracking_net.py:165-193 (eval mode):
-        returns (det_scores 3xL, [link_scores 3xNxM ...], new_scores 3xL, end_scores 3xL, trans)."""
+        """Same contract as reference modules/tracking_net.py:165-193: in eval mode
+        (det_scores 3xL, [link_scores 3xNxM ...], new_scores 3xL, end_scores 3xL, trans); in training mode
+        (``.train()``) the differentiable forward of mmmot_amd/train.py - raw det scores, new / end scores without the
+        eval padding - which needs ``self.freeze_appearance = True`` (the VGG trunk's training mode is not built)."""
+        if self.training:
+            from .train import forward_train
+            return forward_train(self, dets, det_info, dets_split)
         return self.forward_rows(dets, det_info, dets_split, rows=(0, 1, 2))
 
     def forward_rows(self, dets, det_info, dets_split, rows=(0, 1, 2)):

@@ -19,6 +19,7 @@ A_PLAIN, A_NORM_RELU, A_PAIR = 0, 1, 2
 PAIR_OPS = {'multiply': 0, 'minus_abs': 1, 'minus': 2}
 SOFTMAX_MODES = {'single': 1, 'dual': 2, 'dual_add': 3, 'dual_max': 4}
 FUSION_MODES = {'A': 0, 'B': 1, 'C': 2}
+LOSS_KINDS = {'bce': 0, 'l2': 1, 'l1': 2}
 
 
 def _ptr(t, dtype=torch.float32):
@@ -360,6 +361,28 @@ class HipOps:
     def add_rows(self, A, B, Y, C):
         st = self.lib.mmmot_add_rows(_ptr(A), _ld(A), _ptr(B), _ld(B), _ptr(Y), _ld(Y), A.shape[0], C, self._stream())
         _lib.check(st, 'mmmot_add_rows')
+
+    # ---- training step, second slice (csrc/train.hip) ----------------------------------------------------------
+    def rows_gather_scale(self, S, rowidx, scale, X, C):
+        """X[r][:C] = S[rowidx[r]][:C] * scale[rowidx[r]] (scale None: 1): backward of the per-detection average pools"""
+        st = self.lib.mmmot_rows_gather_scale(_ptr(S), _ld(S), _iptr(rowidx), _ptr(scale), _ptr(X), _ld(X), X.shape[0], C,
+                                              self._stream())
+        _lib.check(st, 'mmmot_rows_gather_scale')
+
+    def pointnet_layer1_bwd(self, dY, X, tiles, PW):
+        """PW [T][64 * (K + 1)] per-tile partials of (dW1 [64][K] | db1 [64]) interleaved per channel; K = X.shape[1]"""
+        st = self.lib.mmmot_pointnet_layer1_bwd(_ptr(dY), _ptr(X), int(X.shape[1]), _iptr(tiles.row0), _iptr(tiles.nrows),
+                                                tiles.T, _ptr(PW), self._stream())
+        _lib.check(st, 'mmmot_pointnet_layer1_bwd')
+
+    def score_loss(self, x, y, kind, scale, g, PL, mrow=None, mcol=None, M=0, mask_mode=0, ignore=-1.0, accumulate=False):
+        """one TrackingLoss term over x [R][C] (see mmmot_score_loss); PL [nblocks] partial sums of the scaled loss
+        (accumulate: added to PL's contents)"""
+        R, C = x.shape
+        st = self.lib.mmmot_score_loss(_ptr(x), _ld(x), _ptr(y), _ptr(mrow), _ptr(mcol), int(M), int(mask_mode),
+                                       float(ignore), int(kind), float(scale), R, C, _ptr(g), _ld(g), _ptr(PL),
+                                       PL.numel(), int(bool(accumulate)), self._stream())
+        _lib.check(st, 'mmmot_score_loss')
 
     def selftest_mfma(self, A, B, C, K):
         _lib.check(self.lib.mmmot_selftest_mfma(_ptr(A), _ptr(B), _ptr(C), K, self._stream()),

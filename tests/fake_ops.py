@@ -387,9 +387,10 @@ class TorchOps:
     def softmax_pairs_bwd(self, logits, dout, dlogits, row0, gN, gM, G, max_nm, mode):
         for g in range(G):
             N, M, r0 = int(gN[g]), int(gM[g]), int(row0[g])
-            x = logits[r0:r0 + N * M].double().view(N, M).clone().requires_grad_(True)
-            p, q = torch.softmax(x, 1), torch.softmax(x, 0)
-            out = p if mode == 1 else (p * q if mode == 2 else ((p + q) / 2 if mode == 3 else torch.max(p, q)))
+            with torch.enable_grad():  # called from inside an autograd.Function's backward (grad mode off there)
+                x = logits[r0:r0 + N * M].double().view(N, M).clone().requires_grad_(True)
+                p, q = torch.softmax(x, 1), torch.softmax(x, 0)
+                out = p if mode == 1 else (p * q if mode == 2 else ((p + q) / 2 if mode == 3 else torch.max(p, q)))
             (gx,) = torch.autograd.grad(out, x, dout[r0:r0 + N * M].double().view(N, M))
             dlogits[r0:r0 + N * M] = gx.reshape(-1).float()
 
@@ -409,6 +410,49 @@ class TorchOps:
 
     def add_rows(self, A, B, Y, C):
         Y[:, :C] = A[:, :C] + B[:, :C]
+
+    # ---- training step, second slice (csrc/train.hip) ----
+    def rows_gather_scale(self, S, rowidx, scale, X, C):
+        idx = rowidx.long()
+        v = S[idx, :C].to(self.dtype)
+        if scale is not None:
+            v = v * scale[idx].to(self.dtype).unsqueeze(1)
+        X[:, :C] = v.to(X.dtype)
+
+    def pointnet_layer1_bwd(self, dY, X, tiles, PW):
+        K = X.shape[1]
+        for t in range(tiles.T):
+            r0, n = int(tiles.h_row0[t]), int(tiles.h_nrows[t])
+            d, x = dY[r0:r0 + n, :64].to(self.dtype), X[r0:r0 + n].to(self.dtype)
+            PW[t] = torch.cat([d.t() @ x, d.sum(0, keepdim=True).t()], dim=1).reshape(-1).to(PW.dtype)
+
+    def score_loss(self, x, y, kind, scale, g, PL, mrow=None, mcol=None, M=0, mask_mode=0, ignore=-1.0, accumulate=False):
+        R, C = x.shape
+        xv, yv = x.to(self.dtype), y.to(self.dtype).reshape(1, C)
+        m = torch.ones(C, dtype=self.dtype)
+        if mask_mode:
+            ind = (lambda v: (v == 1.0)) if mask_mode == 1 else (lambda v: (v != ignore))
+            c = torch.arange(C)
+            if mrow is not None:
+                m = m * ind(mrow[c // M]).to(self.dtype)
+            if mcol is not None:
+                m = m * ind(mcol[c % M]).to(self.dtype)
+        m = m.reshape(1, C)
+        if kind == 0:
+            l = torch.clamp(xv, min=0) - xv * yv + torch.log1p(torch.exp(-xv.abs()))
+            d = torch.sigmoid(xv) - yv
+        else:
+            e = xv * m - yv
+            if kind == 1:
+                l, d = e * e, 2 * e * m
+            else:
+                a = e.abs()
+                l = torch.where(a < 1, 0.5 * e * e, a - 0.5)
+                d = torch.where(a < 1, e, torch.sign(e)) * m
+        g[:, :C] = (scale * d).to(g.dtype)
+        if not accumulate:
+            PL.zero_()
+        PL[0] += float(scale * l.sum())
 
     def rowdot(self, X, K, w, b, tiles, out, sc=None, sh=None, act=ACT_NONE, use_thr=False, thr=0.0, omap=None):
         R = tiles.R
