@@ -93,8 +93,9 @@ int mmmot_device_info(int device, int* cu_count, char* arch, int arch_len);
  *            (modules/tracking_net.py:132) and wp is [Cout][32]
  *            (k = (ky*3+kx)*3 + c, zero padded 27->32);
  *   first=0: `in` is NHWC [L][H][W][Cin], wp is [9][Cout][Cin].
- *   out: NHWC [L][H][W][Cout], or [L][H/2][W/2][Cout] when pool=1.
- * Implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32).  H, W even;
+ *   out: NHWC [L][H][W][Cout], or [L][H>>1][W>>1][Cout] when pool=1 (odd maps are floored like
+ *        nn.MaxPool2d(2, 2), modules/vgg.py:72: the last row / column has no window).
+ * Implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32).  Any H, W >= 1;
  * Cin % 32 == 0 (first=0); Cout % 64 == 0.
  * ------------------------------------------------------------------------- */
 int mmmot_conv3x3_bn_relu(const float* in, const float* wp, const float* bias,
@@ -110,7 +111,7 @@ int mmmot_conv3x3_bn_relu(const float* in, const float* wp, const float* bias,
  * accumulation (3 MFMAs per algorithmic product: ceiling 2.5 PF / 3).
  *   in  : hl16 NHWC [L][H][W][Cin]       wp: hl16 [9][Cout][Cin], output channel n host-scaled by 2^wshift[n]
  *   out : hl16 NHWC (pooled when pool=1)  oscale[Cout] = 2^-wshift[n], applied before the bias
- * Cin % 32 == 0, Cout % 64 == 0, H and W even.  Same reference lines as above
+ * Cin % 32 == 0, Cout % 64 == 0, any H, W >= 1 (pool=1 floors odd maps: out is [L][H>>1][W>>1][Cout]).  Same reference lines as above
  * (conv2d + batch_norm + relu_ (+ max_pool2d), modules/vgg.py:67-80).
  * Kernel: LDS-resident haloed activation patch + streamed weight ring, persistent workgroups of 256 pixels
  * (16x16 or 4 x 8x8 blocks) x 64/128 channels (conv3x3_hl16_patch.hip).
@@ -135,7 +136,7 @@ int mmmot_conv1_fused_hl16(const float* crops, const void* w1, const float* bias
  *   of a low-gain channel of a trained, BatchNorm-folded layer keep their precision).
  * e4m3 = OCP FP8 E4M3 (max 448).  Relative error of a product ~2^-15 instead of 2^-21 (hl16); end-to-end score
  * error stays below the 1e-3 budget (tools/study_fp8_correction.py, tests/test_hq8_gpu.py, tests/test_robust_gpu.py).
- * Cin % 32 == 0, Cout % 64 == 0, H and W even.  mmmot_hq8_pack/unpack convert n fp32 values (n % 32 == 0). */
+ * Cin % 32 == 0, Cout % 64 == 0, any H, W >= 1 (pool=1 floors odd maps).  mmmot_hq8_pack/unpack convert n fp32 values (n % 32 == 0). */
 int mmmot_conv3x3_bn_relu_hq8(const void* in, const void* wp, const float* bias, void* out,
                               int L, int H, int W, int Cin, int Cout, int pool, const float* oscale, void* stream);
 /* mmmot_conv1_fused_hl16 with conv1_2 in hq8 arithmetic: w1 stays hl16, w2 is hq8 [9][64][64], out is hq8 */

@@ -41,7 +41,10 @@ __global__ __launch_bounds__(MM_THREADS, 2) void conv3x3_kernel(
   const int mt = lid / ntn, nt = lid % ntn;
   const int n0 = nt * BN;
 
-  const int Hq = H >> 1, Wq = W >> 1;
+  // quads are enumerated over the map padded to even sides (odd maps: the last row / column of quads is half outside
+  // and masked); a pooled layer keeps only the windows that lie inside - the floor of nn.MaxPool2d(2, 2), vgg.py:72
+  const int Hq = (H + 1) >> 1, Wq = (W + 1) >> 1;
+  const int Hf = H >> 1, Wf = W >> 1;
   const int lrow = tid >> 3;   // 0..31: staging row (plus 32*i)
   const int kq = tid & 7;      // which float4 of the 32-wide k slab
 
@@ -59,6 +62,7 @@ __global__ __launch_bounds__(MM_THREADS, 2) void conv3x3_kernel(
     const int yq = rem / Wq, xq = rem - yq * Wq;
     py[i] = 2 * yq + (sub >> 1);
     px[i] = 2 * xq + (sub & 1);
+    pval[i] = pval[i] && py[i] < H && px[i] < W;
     pbase[i] = FIRST ? (long)crop * 3 * H * W : ((long)crop * H + py[i]) * W + px[i];
   }
 
@@ -158,6 +162,7 @@ __global__ __launch_bounds__(MM_THREADS, 2) void conv3x3_kernel(
         const int rem = q - crop * (Hq * Wq);
         const int yq = rem / Wq, xq = rem - yq * Wq;
         const long pix = ((long)crop * H + 2 * yq + (sub >> 1)) * W + 2 * xq + (sub & 1);
+        if (2 * yq + (sub >> 1) >= H || 2 * xq + (sub & 1) >= W) continue;
         f16x8 hh, ll;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -187,7 +192,13 @@ __global__ __launch_bounds__(MM_THREADS, 2) void conv3x3_kernel(
           const int m = mt * MM_BM + r;
           const float v = fmaxf(fmaxf(acc[tm][tn][4 * g], acc[tm][tn][4 * g + 1]),
                                 fmaxf(acc[tm][tn][4 * g + 2], acc[tm][tn][4 * g + 3]));
-          if (m < Mtot) out[(long)(m >> 2) * Cout + n] = fmaxf(v + bv, 0.f);
+          if (m < Mtot) {
+            const int q = m >> 2;
+            const int crop = q / (Hq * Wq);
+            const int rem = q - crop * (Hq * Wq);
+            const int yq = rem / Wq, xq = rem - yq * Wq;
+            if (yq < Hf && xq < Wf) out[(((long)crop * Hf + yq) * Wf + xq) * Cout + n] = fmaxf(v + bv, 0.f);
+          }
         }
       } else {
 #pragma unroll
@@ -199,6 +210,7 @@ __global__ __launch_bounds__(MM_THREADS, 2) void conv3x3_kernel(
             const int rem = q - crop * (Hq * Wq);
             const int yq = rem / Wq, xq = rem - yq * Wq;
             const long pix = ((long)crop * H + 2 * yq + (sub >> 1)) * W + 2 * xq + (sub & 1);
+            if (2 * yq + (sub >> 1) >= H || 2 * xq + (sub & 1) >= W) continue;
             const float val = fmaxf(acc[tm][tn][e] + bv, 0.f);
             if constexpr (OUT16) {
               _Float16* o16 = reinterpret_cast<_Float16*>(out) + pix * Cout * 2 + (n >> 3) * 16 + (n & 7);
@@ -218,7 +230,7 @@ __global__ __launch_bounds__(MM_THREADS, 2) void conv3x3_kernel(
 template <int BN, bool FIRST, bool POOL, bool OUT16 = false>
 static int launch_conv(const float* in, const float* wp, const float* bias, float* out, int L, int H,
                        int W, int Cin, int Cout, hipStream_t s) {
-  const int Mtot = L * H * W;
+  const int Mtot = L * 4 * ((H + 1) >> 1) * ((W + 1) >> 1);  // pixels of the maps padded to even sides (quad order)
   const int ntm = (Mtot + MM_BM - 1) / MM_BM;
   const int ntn = Cout / BN;
   hipLaunchKernelGGL((conv3x3_kernel<BN, FIRST, POOL, OUT16>), dim3(ntm * ntn), dim3(MM_THREADS), 0, s, in, wp,
@@ -231,9 +243,9 @@ extern "C" int mmmot_conv3x3_bn_relu(const float* in, const float* wp, const flo
                                      void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!in || !wp || !bias || !out || L <= 0 || H <= 0 || W <= 0) return MMMOT_EINVAL;
-  if ((H & 1) || (W & 1) || (Cout % 64) != 0) return MMMOT_EINVAL;
+  if ((Cout % 64) != 0) return MMMOT_EINVAL;
   if (!mm_al16(in) || !mm_al16(wp) || !mm_al16(out)) return MMMOT_EINVAL;
-  if ((long)L * H * W >= (1L << 31) - MM_BM) return MMMOT_EINVAL;
+  if ((long)L * (H + 1) * (W + 1) >= (1L << 31) - MM_BM) return MMMOT_EINVAL;
   if (first) {
     if (Cin != 3) return MMMOT_EINVAL;
     if (Cout % 128 == 0)

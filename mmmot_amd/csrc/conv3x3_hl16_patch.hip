@@ -911,7 +911,9 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
             gy = bgy0[k] + y;
             gx = bgx0[k] + x;
           }
-        if (crop >= 0 && gy < H && gx < W) {
+        // pooled layers floor odd maps like nn.MaxPool2d(2, 2) (reference modules/vgg.py:72): a window that sticks out
+        // of the image (last row / column of an odd map) produces no output
+        if (crop >= 0 && gy < H && gx < W && (!POOL || ((gy >> 1) < Hq && (gx >> 1) < Wq))) {
           float v[16];
           const float* c = &Cs[itl * CLD + eu16 * 16];
 #pragma unroll
@@ -970,7 +972,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
           gy = bgy0[k] + y;
           gx = bgx0[k] + x;
         }
-      if (crop >= 0 && gy < H && gx < W) {
+      if (crop >= 0 && gy < H && gx < W && (gy >> 1) < Hq && (gx >> 1) < Wq) {  // floor pooling: see the hq8 branch
         f32x8 v = *reinterpret_cast<const f32x8*>(&Cs[qdl * CLD + eu * 8]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], sv[e], bv[e]), 0.f);
@@ -1190,13 +1192,14 @@ static int launch_patch_p(int pool, const void* in, const void* wp, const float*
               : launch_patch<BN, BS, false>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
 }
 
-// Same contract as mmmot_conv3x3_bn_relu_hl16 (Cin % 32 == 0, Cout % 64 == 0, H and W even).
+// Same contract as mmmot_conv3x3_bn_relu_hl16 (Cin % 32 == 0, Cout % 64 == 0); any H, W >= 1: pool = 1 on an odd map
+// floors like nn.MaxPool2d(2, 2) - the output is (H >> 1) x (W >> 1).
 extern "C" int mmmot_conv3x3_bn_relu_hl16_patch(const void* in, const void* wp, const float* bias, void* out, int L,
                                                 int H, int W, int Cin, int Cout, int pool, const float* oscale,
                                                 void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!in || !wp || !bias || !out || !oscale || L <= 0 || H <= 0 || W <= 0) return MMMOT_EINVAL;
-  if ((H & 1) || (W & 1) || Cin % 32 != 0 || Cout % 64 != 0) return MMMOT_EINVAL;
+  if (Cin % 32 != 0 || Cout % 64 != 0) return MMMOT_EINVAL;  // odd maps: floor pooling (partial windows dropped)
   if (!mm_al16(in) || !mm_al16(wp) || !mm_al16(out)) return MMMOT_EINVAL;
   if ((long)L * H * W * (Cin / 4) >= (1L << 31) - 64) return MMMOT_EINVAL;  // 32-bit piece offsets
   const bool big = (H > 8 || W > 8);  // 16x16 blocks unless the whole map fits an 8x8 block
@@ -1241,7 +1244,7 @@ extern "C" int mmmot_conv3x3_bn_relu_hq8(const void* in, const void* wp, const f
                                          int W, int Cin, int Cout, int pool, const float* oscale, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!in || !wp || !bias || !out || !oscale || L <= 0 || H <= 0 || W <= 0) return MMMOT_EINVAL;
-  if ((H & 1) || (W & 1) || Cin % 32 != 0 || Cout % 64 != 0) return MMMOT_EINVAL;
+  if (Cin % 32 != 0 || Cout % 64 != 0) return MMMOT_EINVAL;  // odd maps: floor pooling (partial windows dropped)
   if (!mm_al16(in) || !mm_al16(wp) || !mm_al16(out)) return MMMOT_EINVAL;
   if ((long)L * H * W * (Cin / 4) >= (1L << 31) - 64) return MMMOT_EINVAL;
   const bool big = (H > 8 || W > 8);

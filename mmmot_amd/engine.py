@@ -145,12 +145,13 @@ class Engine:
     def appearance(self, plan, crops, cat):
         """crops [Lt,3,S,S] NCHW (reference contract) -> cat[:, 0:512]."""
         ops, Lt, S = self.ops, plan.Lt, plan.S
-        if S <= 0 or S % 32 != 0:
-            # every trunk kernel works on 2x2-aligned maps (pooling fused into the conv epilogue), and conv5 runs on
-            # the S/16 map: S must be a multiple of 32.  The reference's dataset resizes every crop to 224
-            # (dataset/test_seq_dataset.py:218); its MaxPool2d floors odd maps, which is not built here.
-            raise ValueError('crop side %d is not supported: the HIP VGG trunk needs a multiple of 32 '
-                             '(32, 64, ..., 224, 256); resize the crops (mmmot_amd.crops.crop_resize_normalize)' % S)
+        if S < 32 or S % 2 != 0:
+            # five 2x2 poolings: a 32-pixel crop ends in a 1 x 1 map.  Sides that are not a multiple of 32 give odd maps
+            # on the way down, floored by every pooling like nn.MaxPool2d(2, 2) (reference modules/vgg.py:72) - e.g.
+            # 100 -> 50 -> 25 -> 12 -> 6 -> 3.  The first layer (NCHW crops, fused conv1_1 + conv1_2 + pool) wants an
+            # even side; the reference's dataset resizes every crop to 224 (dataset/test_seq_dataset.py:218).
+            raise ValueError('crop side %d is not supported: the HIP VGG trunk needs an even side >= 32; resize the crops '
+                             '(mmmot_amd.crops.crop_resize_normalize)' % S)
         if Lt * S * S * 16 >= 2 ** 31 - 64:
             # the trunk kernels address activations with 32-bit offsets in 16-byte pieces (largest tensor: L x S x S x 64)
             raise ValueError('%d crops of %dx%d in one launch sequence exceed the 32-bit piece offsets of the trunk kernels '
@@ -163,7 +164,7 @@ class Engine:
         # conv1_1 + conv1_2 + pool as one launch when the trunk has the VGG16 head (3 -> 64 -> 64, pool)
         fuse1 = (f16 and self.fuse_conv1 and len(vgg) > 1 and vgg[0]['cout'] == 64 and
                  vgg[1]['cin'] == 64 and vgg[1]['cout'] == 64 and vgg[1]['pool'] and not vgg[0]['last'] and
-                 not vgg[0]['pool'] and H % 2 == 0 and W % 2 == 0)
+                 not vgg[0]['pool'])
         fmt = 'raw'  # format of x: 'raw' NCHW crops, 'f32' NHWC fp32, 'hl16', 'hq8' (same bytes per value)
         for li, cv in enumerate(vgg):
             if fuse1 and li == 0:

@@ -107,6 +107,11 @@ CASES.append(dict(name='s7_refl_B', fusion='B', aff='multiply', sm='none', N=6, 
                   seed=1010, refl=True))
 CASES.append(dict(name='s7_refl_C', fusion='C', aff='minus_abs', sm='dual_add', N=3, M=8, S=32, pts=50, ragged=True,
                   seed=1011, refl=True))
+# crop sides that are not a multiple of 32: odd feature maps on the way down, floored by nn.MaxPool2d(2, 2)
+# (modules/vgg.py:72): 40 -> 20 -> 10 -> 5 -> 2 -> 1 and 100 -> 50 -> 25 -> 12 -> 6 -> 3
+CASES.append(dict(name='s8_S40_C', fusion='C', aff='multiply', sm='none', N=4, M=3, S=40, pts=25, ragged=True, seed=1012))
+CASES.append(dict(name='s8_S100_A', fusion='A', aff='minus_abs', sm='dual_add', N=2, M=3, S=100, pts=25, ragged=True,
+                  seed=1013))
 # full-size cases: outputs only ('full': True)
 CASES.append(dict(name='f_cfg3_C', fusion='C', aff='multiply', sm='none', N=64, M=64, S=128, pts=2048,
                   ragged=False, seed=1000, full=True))

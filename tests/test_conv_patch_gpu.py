@@ -23,6 +23,12 @@ CASES = [
     (0, 2, 28, 20, 64, 64),      # partial blocks on both axes
     (1, 9, 4, 4, 512, 512),      # 16 slabs
     (1, 1, 64, 64, 64, 64),      # conv1_2-like
+    # odd maps (crop sides that are not a multiple of 32): pooled layers floor like nn.MaxPool2d(2, 2)
+    (0, 3, 25, 25, 64, 64),      # 100-pixel crops at conv3 (16x16 blocks, partial, odd)
+    (1, 3, 25, 25, 128, 128),    # ... pooled: 25 -> 12, the last row / column has no window
+    (1, 4, 5, 5, 64, 128),       # 40-pixel crops at conv4 (8x8 blocks): 5 -> 2
+    (0, 2, 3, 7, 32, 64),        # odd and different sides
+    (1, 2, 9, 17, 64, 64),       # both block shapes' borders: 9 -> 4, 17 -> 8
 ]
 
 

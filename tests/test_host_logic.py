@@ -184,3 +184,14 @@ def test_engine_refuses_concurrent_forwards():
     finally:
         eng._busy.release()
     m(*case_inputs(c))
+
+
+def test_crop_sides_follow_the_reference_pooling():
+    """any even crop side >= 32 runs (odd maps on the way down are floored like nn.MaxPool2d(2, 2), goldens s8_*);
+    an odd side or one that leaves nothing after five poolings is refused with a clear error"""
+    c, base = get_case('s8_S40_C')
+    m = build_model(c, base, ops=TorchOps())
+    dets, info, ds = case_inputs(c)
+    for bad in (30, 41):
+        with pytest.raises(ValueError, match='crop side'):
+            m(torch.zeros(dets.shape[0], 3, bad, bad), info, ds)

@@ -68,6 +68,9 @@ CONV_CASES = [
     (0, 1, 2, 8, 8, 64, 64),
     (0, 0, 2, 8, 12, 64, 128),
     (0, 1, 3, 4, 4, 128, 256),
+    (0, 1, 3, 25, 25, 64, 64),   # odd map, floor pooling (nn.MaxPool2d(2, 2)): 25 -> 12
+    (0, 0, 2, 5, 7, 32, 64),     # odd, unpooled
+    (1, 1, 2, 10, 10, 3, 64),
     (0, 0, 5, 6, 10, 32, 64),
     (0, 1, 7, 2, 2, 256, 512),
     (0, 0, 1, 16, 16, 512, 512),
