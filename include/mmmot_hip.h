@@ -316,6 +316,13 @@ int mmmot_rowdot(const float* X, int ldx, int K, const float* w, float b,
 int mmmot_row_layernorm(const float* X, int ldx, int C, const float* gamma, const float* beta,
                         float eps, int relu, float* Y, int ldy, int R, void* stream);
 
+/* One SkipPool head (reference modules/appear_net.py:19-32) after the global average pool, in one launch (ABI 6):
+ *   out[r][0:128] = relu(LN_128(w4 . relu(LN_C4(w1 . LN_C(P[r]) + c1)) + c4))        LN = GroupNorm(1, .) of a row
+ * P [R][C] pooled stage features (row stride ldp), w1 [C4][C], w4 [128][C4] fp32, C % 64 == 0 <= 512, C4 in {64, 128};
+ * out rows have stride ldo (the stage's 128-column slice of the [L][1024] feature matrix). */
+int mmmot_skippool_head(const float* P, int ldp, int C, int C4, const float* g0, const float* b0, const float* w1,
+                        const float* c1, const float* g2, const float* b2, const float* w4, const float* c4,
+                        const float* g5, const float* b5, float eps, float* out, int ldo, int R, void* stream);
 /* PointNet first shared-MLP layer with the K x K STN transform folded into the
  * weights (point_net.py:119-125): Y[p][0..63] = W[64][K] x[p] + b, plus
  * per-tile statistics like mmmot_gemm_rows.  K = 3 (xyz; every shipped config sets without_reflectivity) or 4

@@ -103,6 +103,8 @@ SIGNATURES = {
     'mmmot_rowdot': [c_f, c_i, c_i, c_f, ctypes.c_float, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i,
                      ctypes.c_float, c_f, c_f, c_f],
     'mmmot_row_layernorm': [c_f, c_i, c_i, c_f, c_f, ctypes.c_float, c_i, c_f, c_i, c_i, c_f],
+    'mmmot_skippool_head': [c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, ctypes.c_float, c_f, c_i, c_i,
+                            c_f],
     'mmmot_pointnet_layer1': [c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f],
     'mmmot_pn_mlp64': [c_f, c_i, c_f, c_f, c_i, c_f, ctypes.c_float, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_i, c_i, c_f],
     'mmmot_affine_act': [c_f, c_i, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_f, c_i, c_f],

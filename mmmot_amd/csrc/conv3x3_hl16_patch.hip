@@ -527,6 +527,13 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     constexpr int i = decltype(IC)::value;
     constexpr int half = decltype(HALFC)::value;
     if constexpr (EXP == 4) return;
+    // EXP 12: only every fourth MFMA - the matrix-core work per streamed weight byte of a Winograd F(2x2, 3x3) stage
+    // (16 positions x [Cout][Cin] transformed weights for 2.25x fewer products, accumulators 4x per output pixel =>
+    // a quarter of the MFMAs per 16 KB weight stage) with every load, fragment read and barrier of the direct kernel
+    // kept: the time per stage of a Winograd kernel WITHOUT its input / output transforms
+    if constexpr (EXP == 12) {
+      if constexpr ((i % 4) != 0) return;
+    }
     constexpr int term = i / NPROD, p = i % NPROD;
     constexpr int tm = p / TN, tn = p % TN;
     if constexpr (Q8) {
@@ -1120,7 +1127,7 @@ extern "C" int mmmot_set_patch_grid_limit(int n) {
 // WRONG results by construction (they remove loads / barriers / MFMAs / stores to time what is left).
 static int g_patch_exp = 0;
 extern "C" int mmmot_set_patch_variant(int v) {
-  if (v < 0 || v > 11) return MMMOT_EINVAL;
+  if (v < 0 || v > 12) return MMMOT_EINVAL;
   g_patch_exp = v;
   return MMMOT_OK;
 }
@@ -1178,6 +1185,7 @@ static int launch_patch(const void* in, const void* wp, const float* bias, void*
       case 4: return launch_patch_e<BN, BS, POOL, 4>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
       case 5: return launch_patch_e<BN, BS, POOL, 5>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
       case 6: return launch_patch_e<BN, BS, POOL, 6>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
+      case 12: return launch_patch_e<BN, BS, POOL, 12>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
       default: break;
     }
   }

@@ -403,6 +403,114 @@ extern "C" int mmmot_row_layernorm(const float* X, int ldx, int C, const float* 
 }
 
 // ---------------------------------------------------------------------------
+// One SkipPool head (reference modules/appear_net.py:19-32) for 4 detections per workgroup, in ONE launch:
+//   LayerNorm(C) -> 1x1 conv C -> C4 -> LayerNorm + ReLU -> 1x1 conv C4 -> 128 -> LayerNorm + ReLU
+// on the pooled [R][C] features of a stage (the global average pool before it stays mmmot_segment_mean).  Seven launches
+// (three row LayerNorms, two small-M GEMMs of 4-8 workgroups, ...) per stage were ~0.4 ms of every step and a third of
+// the launches of a one-pair forward.  Plain fp32: wave w normalises row w; the matrix-vector products walk the
+// output channels (wave w: j = w, w + 4, ...), lanes along k (coalesced 16-byte weight loads, each weight row read
+// once for the workgroup's rows), wave reduction per (row, j).  SP_ROWS = 2 rows per workgroup: a one-pair forward
+// (~22 detections) still spreads over a dozen CUs, a 2048-detection batch reads the 0.8 MB of head weights 1024 times
+// from L2 (0.8 GB: tens of microseconds).
+#define SP_ROWS 2
+__device__ __forceinline__ void sp_layernorm_row(const float* __restrict__ x, int C, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, float eps, bool relu, float* y, int lane) {
+  float v[8];
+  const int per = C >> 6;  // <= 8
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    v[i] = 0.f;
+    if (i < per) { v[i] = x[lane + 64 * i]; s += v[i]; }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (i < per) { const float d = v[i] - mean; q += d * d; }
+  const float rstd = 1.f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (i < per) {
+      const int c = lane + 64 * i;
+      const float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
+      y[c] = relu ? fmaxf(o, 0.f) : o;
+    }
+}
+
+// out[rr][j] = bias[j] + sum_k W[j][k] * x[rr][k] for the workgroup's SP_ROWS rows (x, out in LDS).  Lane l owns
+// k = l, l + 64, ... (coalesced 256-byte weight loads); a wave takes SP_JB output channels at a time so that all
+// their weight loads are in flight together (with few detections the kernel is a chain of L2 round trips, not work)
+#define SP_JB 4
+__device__ __forceinline__ void sp_matvec(const float* __restrict__ W, const float* __restrict__ bias, int N, int K,
+                                          const float (*x)[512], float (*out)[128], int lane, int wave) {
+  const int per = K >> 6;  // <= 8
+  for (int j0 = wave * SP_JB; j0 < N; j0 += 4 * SP_JB) {
+    float w[SP_JB][8];
+#pragma unroll
+    for (int jb = 0; jb < SP_JB; ++jb)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) w[jb][i] = (i < per && j0 + jb < N) ? W[(long)(j0 + jb) * K + lane + 64 * i] : 0.f;
+    float acc[SP_JB][SP_ROWS];
+#pragma unroll
+    for (int jb = 0; jb < SP_JB; ++jb)
+#pragma unroll
+      for (int rr = 0; rr < SP_ROWS; ++rr) acc[jb][rr] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < per) {
+#pragma unroll
+        for (int rr = 0; rr < SP_ROWS; ++rr) {
+          const float xv = x[rr][lane + 64 * i];
+#pragma unroll
+          for (int jb = 0; jb < SP_JB; ++jb) acc[jb][rr] = fmaf(w[jb][i], xv, acc[jb][rr]);
+        }
+      }
+#pragma unroll
+    for (int jb = 0; jb < SP_JB; ++jb)
+#pragma unroll
+      for (int rr = 0; rr < SP_ROWS; ++rr) {
+        const float t = wave_sum(acc[jb][rr]);
+        if (lane == 0 && j0 + jb < N) out[rr][j0 + jb] = t + bias[j0 + jb];
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void skippool_head_kernel(
+    const float* __restrict__ P, int ldp, int C, int C4, const float* __restrict__ g0, const float* __restrict__ b0,
+    const float* __restrict__ w1, const float* __restrict__ c1, const float* __restrict__ g2,
+    const float* __restrict__ b2, const float* __restrict__ w4, const float* __restrict__ c4,
+    const float* __restrict__ g5, const float* __restrict__ b5, float eps, float* __restrict__ out, int ldo, int R) {
+  __shared__ __attribute__((aligned(16))) float xs[SP_ROWS][512];
+  __shared__ __attribute__((aligned(16))) float hs[SP_ROWS][512];  // normalised hidden rows (C4 <= 128 used)
+  __shared__ float h1[SP_ROWS][128];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * SP_ROWS + wave;  // waves 0 .. SP_ROWS-1 normalise a row each; all four do the products
+  const bool mine = wave < SP_ROWS, live = mine && row < R;
+  if (mine) sp_layernorm_row(P + (long)(live ? row : 0) * ldp, C, g0, b0, eps, false, xs[wave], lane);
+  __syncthreads();
+  sp_matvec(w1, c1, C4, C, xs, h1, lane, wave);
+  __syncthreads();
+  if (mine) sp_layernorm_row(h1[wave], C4, g2, b2, eps, true, hs[wave], lane);
+  __syncthreads();
+  sp_matvec(w4, c4, 128, C4, hs, h1, lane, wave);
+  __syncthreads();
+  if (live) sp_layernorm_row(h1[wave], 128, g5, b5, eps, true, out + (long)row * ldo, lane);
+}
+
+extern "C" int mmmot_skippool_head(const float* P, int ldp, int C, int C4, const float* g0, const float* b0,
+                                   const float* w1, const float* c1, const float* g2, const float* b2, const float* w4,
+                                   const float* c4, const float* g5, const float* b5, float eps, float* out, int ldo,
+                                   int R, void* stream) {
+  if (!P || !g0 || !b0 || !w1 || !c1 || !g2 || !b2 || !w4 || !c4 || !g5 || !b5 || !out || R <= 0) return MMMOT_EINVAL;
+  if (C <= 0 || C % 64 != 0 || C > 512 || C4 <= 0 || C4 % 64 != 0 || C4 > 128) return MMMOT_EINVAL;
+  if (!mm_al16(w1) || !mm_al16(w4)) return MMMOT_EINVAL;
+  hipLaunchKernelGGL(skippool_head_kernel, dim3((R + SP_ROWS - 1) / SP_ROWS), dim3(256), 0, (hipStream_t)stream, P, ldp,
+                     C, C4, g0, b0, w1, c1, g2, b2, w4, c4, g5, b5, eps, out, ldo, R);
+  return mm_check(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------
 // PointNet first shared-MLP layer (K = 3 xyz, or 4 with the reflectivity channel): VALU, output-write bound.
 template <int K>
 __global__ __launch_bounds__(256) void pointnet_layer1_kernel(

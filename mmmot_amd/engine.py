@@ -67,6 +67,8 @@ class Engine:
         # it waits for CUs; B = 1 hipGraph replay 2.85 -> 2.71 ms, eager latency unchanged.
         self.two_streams = os.environ.get('MMMOT_TWO_STREAMS', '0') == '1'
         self._side = {}
+        # SkipPool heads: one launch per stage (MMMOT_SP_FUSED=0: LayerNorm / GEMM / LayerNorm / GEMM / LayerNorm launches)
+        self.sp_fused = os.environ.get('MMMOT_SP_FUSED', '1') != '0'
         # conv1_1 evaluated inside conv1_2's patch prologue (MMMOT_FUSE_CONV1=0: two launches)
         self.fuse_conv1 = os.environ.get('MMMOT_FUSE_CONV1', '1') != '0'
         # f16q8 applies to crops of at least this side; smaller crops run the f16x3 trunk.  The e4m3 correction
@@ -343,6 +345,9 @@ class Engine:
             partial = self.buf('sp_partial', npart, C)
             ops.segment_mean(x, C, first, partial, use_group=False, hl16=hl16)
             ops.segment_mean(partial, C, second, pooled, use_group=False)
+        if self.sp_fused and hasattr(ops, 'skippool_head'):
+            ops.skippool_head(pooled, C, hd, EPS, cat[:, 128 * s:128 * (s + 1)], Lt)  # the whole head in one launch
+            return
         ln0 = self.buf('sp_ln0', Lt, C)
         ops.row_layernorm(pooled, C, hd['g0'], hd['b0'], EPS, False, ln0, Lt)
         C4 = hd['w1'].shape[0]

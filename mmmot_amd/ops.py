@@ -268,6 +268,14 @@ class HipOps:
                                           _ptr(Y), _ld(Y), R, self._stream())
         _lib.check(st, 'mmmot_row_layernorm')
 
+    def skippool_head(self, P, C, hd, eps, out, R):
+        """one SkipPool head (appear_net.py:19-32) on the pooled rows P [R][C] -> out [R][128]; hd: packed head dict"""
+        C4 = int(hd['w1'].shape[0])
+        st = self.lib.mmmot_skippool_head(_ptr(P), _ld(P), C, C4, _ptr(hd['g0']), _ptr(hd['b0']), _ptr(hd['w1']),
+                                          _ptr(hd['c1']), _ptr(hd['g2']), _ptr(hd['b2']), _ptr(hd['w4']), _ptr(hd['c4']),
+                                          _ptr(hd['g5']), _ptr(hd['b5']), float(eps), _ptr(out), _ld(out), R, self._stream())
+        _lib.check(st, 'mmmot_skippool_head')
+
     def pointnet_layer1(self, X, W, bias, Y, part, tiles):
         """X [P][K] with K = W.shape[1] in (3, 4)."""
         st = self.lib.mmmot_pointnet_layer1(_ptr(X), int(W.shape[1]), _ptr(W), _ptr(bias), _ptr(Y), _ptr(part),

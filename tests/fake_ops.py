@@ -411,6 +411,13 @@ class TorchOps:
     def add_rows(self, A, B, Y, C):
         Y[:, :C] = A[:, :C] + B[:, :C]
 
+    def skippool_head(self, P, C, hd, eps, out, R):
+        ln = lambda x, g, b: torch.nn.functional.layer_norm(x, (x.shape[1],), g.to(self.dtype), b.to(self.dtype), eps)
+        x = ln(P[:R, :C].to(self.dtype), hd['g0'], hd['b0'])
+        x = torch.relu(ln(x @ hd['w1'].to(self.dtype).t() + hd['c1'].to(self.dtype), hd['g2'], hd['b2']))
+        x = torch.relu(ln(x @ hd['w4'].to(self.dtype).t() + hd['c4'].to(self.dtype), hd['g5'], hd['b5']))
+        out[:R, :128] = x.to(out.dtype)
+
     # ---- training step, second slice (csrc/train.hip) ----
     def rows_gather_scale(self, S, rowidx, scale, X, C):
         idx = rowidx.long()

@@ -604,3 +604,20 @@ def test_pn_mlp64_matches_row_gemm_contract(hip, N, counts):
              amode=1, w_hl16=True, oscale=osv)
     close(Yg, Y2, 1e-6, 'pn_mlp64 vs gemm_rows output')
     close(pg[:, 0], p2[:, 0], 1e-5, 'pn_mlp64 vs gemm_rows sums')
+
+
+@pytest.mark.parametrize('C,C4,R', [(128, 64, 22), (256, 64, 5), (512, 128, 131), (512, 128, 1)])
+def test_skippool_head_one_launch(hip, C, C4, R):
+    """the fused SkipPool head (LayerNorm -> 1x1 -> LayerNorm + ReLU -> 1x1 -> LayerNorm + ReLU) vs its float64
+    specification; partial last workgroup, strided output slice"""
+    emu = TorchOps(torch.float64)
+    hd = dict(g0=rnd(C, seed=1).abs() + 0.5, b0=rnd(C, seed=2), w1=rnd(C4, C, seed=3, scale=C ** -0.5), c1=rnd(C4, seed=4),
+              g2=rnd(C4, seed=5).abs() + 0.5, b2=rnd(C4, seed=6), w4=rnd(128, C4, seed=7, scale=C4 ** -0.5),
+              c4=rnd(128, seed=8), g5=rnd(128, seed=9).abs() + 0.5, b5=rnd(128, seed=10))
+    P = rnd(R, C, seed=11) * 3 + 1
+    ref = torch.zeros(R, 128, dtype=torch.float64)
+    emu.skippool_head(P, C, hd, 1e-5, ref, R)
+    cat = torch.full((R, 1024), 9.0).cuda()
+    hip.skippool_head(P.cuda(), C, {k: v.cuda() for k, v in hd.items()}, 1e-5, cat[:, 256:384], R)
+    close(cat[:, 256:384], ref.float(), 2e-5, 'skippool head')
+    assert (cat[:, :256] == 9.0).all() and (cat[:, 384:] == 9.0).all()
