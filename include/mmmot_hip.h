@@ -229,7 +229,8 @@ int mmmot_gemm_rows(const mmmot_gemm_args* a, void* stream);
  * is never stored.  Outputs, per 64-row HALF tile h of tile t (row index 2t+h; a half may be empty):
  *   part   [2T][2][N]: sum and half-tile-centred M2 of v   -> mmmot_gn_finalize with tile_nrows = rows per half
  *   colsum [2T][N]   : sum of relu(v*osc[g][n]+osh[g][n])  -> mmmot_segment_mean with seg_div
- * W is hl16 ([N][K/8] units, pre-scaled by 1/oscale); K is 64 or 128; N % 128 == 0; tiles must not straddle
+ * W is hl16 ([N][K/8] units, pre-scaled by 1/oscale); K is 64 or 128; N % 256 == 0 (K = 64 with N <= 512,
+ * served by the weight-resident kernel: N % 128 == 0); tiles must not straddle
  * the rows that share a dbias row (detection-aligned tiles).  At least one of part / colsum. */
 typedef struct mmmot_gemm_ares_args {
   const float* X; int ldx;

@@ -15,6 +15,12 @@
 // stage), the per-tile epilogue is register-only (each wave owns 64 rows x 32 channels: column sums by
 // lane-half shuffle, statistics centred on the wave's own 64-row mean), nothing but the partials is stored.
 // Arithmetic: fp16 matrix cores with the 3-term hi/lo split (same as gemm_rows F16 / conv3x3_hl16).
+//
+// Round 3: 2 x 2 register blocking.  With a 64-row x 32-channel wave tile every MFMA needed one 1 KB LDS fragment read
+// (4 activation + 2 weight fragments per 6 MFMAs): 192 KB of fragment reads per 1536-cycle stage and CU - the kernel sat
+// at 34 % of the ceiling, LDS-read bound (a weight-resident variant, a deferred epilogue and counted-vmcnt role copies
+// all left it there).  Now a wave owns 64 rows x 64 channels (channel tile 256, weight stage 256 channels x 32 k = the
+// same 32 KB): 4 + 4 fragment reads feed 12 MFMAs.
 #include <cstdlib>
 #include <type_traits>
 
@@ -24,9 +30,11 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define AR_BM 128
-#define AR_BN 128
-#define AR_BK 64
-#define AR_LDT 72  // halves per LDS row (144 B): conflict-free ds_read_b128
+#define AR_BN 256   // channels per channel tile: a wave owns 64 rows x 64 channels (2 x 2 MFMA blocks)
+#define AR_BK 32    // k per weight stage
+#define AR_LDT 72   // halves per LDS row of the activation planes (64 k + pad: 144 B, conflict-free ds_read_b128)
+#define AR_LDB 40   // halves per LDS row of a weight stage (32 k + pad: 80 B - 16 consecutive rows hit 16 distinct
+                    // 16-byte bank groups)
 #define AR_THREADS 512
 
 static __device__ float ar_zeros[4096];  // stands in for absent bias / dbias / osc / osh rows (branch-free loads)
@@ -38,18 +46,20 @@ static __device__ float ar_zeros[4096];  // stands in for absent bias / dbias / 
 template <int KS, int MODE>
 __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_args a) {
   constexpr int PLANE = AR_BM * AR_LDT;  // halves per [128][72] plane
-  __shared__ __attribute__((aligned(16))) _Float16 As[KS][2][PLANE];  // [k stage][hi, lo]
-  __shared__ __attribute__((aligned(16))) _Float16 Bs[2][2][PLANE];   // [buffer][hi, lo]
+  constexpr int BPLANE = AR_BN * AR_LDB; // halves per [256][40] weight-stage plane
+  constexpr int SPT = 2 * KS;            // 32-k weight stages per channel tile
+  __shared__ __attribute__((aligned(16))) _Float16 As[KS][2][PLANE];  // [64-k block][hi, lo]
+  __shared__ __attribute__((aligned(16))) _Float16 Bs[2][2][BPLANE];  // [buffer][hi, lo]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves: 64 rows x 32 channels each
+  const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves: 64 rows x 64 channels each
   const int lr = lane & 31;
   const int kh = (lane >> 5) * 8;
 
   const int ntn = a.N / AR_BN;
-  const int NS = ntn * KS;  // weight stages per row tile
+  const int NS = ntn * SPT;  // weight stages per row tile (always even)
   // Persistent workgroups (LDS allows one per CU): tiles blockIdx.x, + gridDim.x, ...  The weight stream
   // wraps around (stage NS continues with stage 0 of the next tile), the next tile's activation rows are
   // fetched into registers during the current tile's last stages, so a tile switch costs one conversion
@@ -90,32 +100,27 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
   // own queue.  Both views share one set of staging registers (a wave uses one of them).
   const bool wspec = wave < 4;
   u32x4 stg[16];
-  // weights: thread tw -> (channel rows tw >> 2 and (tw >> 2) + 64, units 2q, 2q+1 of the 8 in a 64-k stage)
+  // weights: thread tw -> unit q = tw & 3 (of the 4 hl16 units [hi8 | lo8] of a 32-k stage) of channel rows
+  // (tw >> 2) + 64 p, p = 0..3: a wave's load instruction covers 16 rows x 64 contiguous bytes
   const int wrow = (tid & 255) >> 2, wq = tid & 3;
   const u32x4* wp = reinterpret_cast<const u32x4*>(a.W);
   const long ku = (long)(a.K >> 3);  // hl16 units per weight row
   auto load_w = [&](int s, auto SLOT) {  // two stages in flight: slot = stage & 1
     constexpr int sl = decltype(SLOT)::value;
-    const int nt = s / KS, ks = s - nt * KS;
+    const int nt = s / SPT, ks = s - nt * SPT;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const u32x4* p = wp + ((long)(nt * AR_BN + wrow + 64 * r) * ku + ks * 8 + wq * 2) * 2;
-      stg[sl * 8 + 4 * r + 0] = p[0];
-      stg[sl * 8 + 4 * r + 1] = p[1];
-      stg[sl * 8 + 4 * r + 2] = p[2];
-      stg[sl * 8 + 4 * r + 3] = p[3];
+    for (int r = 0; r < 4; ++r) {
+      const u32x4* p = wp + ((long)(nt * AR_BN + wrow + 64 * r) * ku + ks * 4 + wq) * 2;
+      stg[sl * 8 + 2 * r + 0] = p[0];
+      stg[sl * 8 + 2 * r + 1] = p[1];
     }
   };
   auto store_w = [&](int buf, auto SLOT) {
     constexpr int sl = decltype(SLOT)::value;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      _Float16* bh = &Bs[buf][0][(wrow + 64 * r) * AR_LDT + wq * 16];
-      _Float16* bl = &Bs[buf][1][(wrow + 64 * r) * AR_LDT + wq * 16];
-      *reinterpret_cast<u32x4*>(bh) = stg[sl * 8 + 4 * r + 0];
-      *reinterpret_cast<u32x4*>(bl) = stg[sl * 8 + 4 * r + 1];
-      *reinterpret_cast<u32x4*>(bh + 8) = stg[sl * 8 + 4 * r + 2];
-      *reinterpret_cast<u32x4*>(bl + 8) = stg[sl * 8 + 4 * r + 3];
+    for (int r = 0; r < 4; ++r) {
+      *reinterpret_cast<u32x4*>(&Bs[buf][0][(wrow + 64 * r) * AR_LDB + wq * 8]) = stg[sl * 8 + 2 * r + 0];
+      *reinterpret_cast<u32x4*>(&Bs[buf][1][(wrow + 64 * r) * AR_LDB + wq * 8]) = stg[sl * 8 + 2 * r + 1];
     }
   };
   using S0 = std::integral_constant<int, 0>;
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
           lo[4 + e] = (_Float16)(y1 - (float)hi[4 + e]);
         }
         const int k = aq * (16 * KS) + 8 * u;  // channel of the unit
-        const int ks = k / AR_BK, kk = k - ks * AR_BK;
+        const int ks = k / 64, kk = k - ks * 64;  // 64-k block of the activation planes
         *reinterpret_cast<f16x8*>(&As[ks][0][row * AR_LDT + kk]) = hi;
         *reinterpret_cast<f16x8*>(&As[ks][1][row * AR_LDT + kk]) = lo;
       }
@@ -190,13 +195,14 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
       __syncthreads();
     };
     prime_w();
-    const bool wrap_ok = (NS % 2) == 0;  // the LDS buffer parity of stage 0 repeats only for even NS
 
-    f32x16 acc[2];
+    f32x16 acc[2][2];  // [row block][channel block]
   #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
   #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[tm][e] = 0.f;
+      for (int tn = 0; tn < 2; ++tn)
+  #pragma unroll
+        for (int e = 0; e < 16; ++e) acc[tm][tn][e] = 0.f;
 
     // per-tile epilogue state (set by begin_tile)
     int nrows = 0, nsub = 0, grp = 0;
@@ -206,21 +212,28 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
     long prow = 0;
     bool full = false;
     const float* pbias = a.bias ? a.bias : ar_zeros;
-    // per-channel epilogue constants of a channel tile: combined bias, output scale / shift.  They are
-    // loaded one channel tile ahead (for the last channel tile: those of the NEXT row tile) and BEFORE the
-    // weight loads of that stage: vmcnt retires in order, so a load issued at epilogue time would also wait
+    // per-channel epilogue constants of a channel tile (two 32-channel blocks per wave): combined bias, output scale /
+    // shift.  They are loaded one channel tile ahead (for the last channel tile: those of the NEXT row tile) and BEFORE
+    // the weight loads of that stage: vmcnt retires in order, so a load issued at epilogue time would also wait
     // for the two weight stages in flight.
-    auto epi_consts = [&](const TileMeta& m, int nt, float& cb, float& os, float& oh) {
-      const int n = nt * AR_BN + wn * 32 + lr;
+    struct EpiC {
+      float cb[2], os[2], oh[2];
+    };
+    auto epi_consts = [&](const TileMeta& m, int nt, EpiC& c) {
       const float* pdb = a.dbias ? a.dbias + (long)m.dbrow * a.lddb : ar_zeros;
       const float* posc = (MODE & 2) ? a.osc + (long)m.grp * a.ldosc : ar_zeros;
       const float* posh = (MODE & 2) ? a.osh + (long)m.grp * a.ldosc : ar_zeros;
-      cb = pbias[n] + pdb[n];
-      os = posc[n];
-      oh = posh[n];
+  #pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const int n = nt * AR_BN + wn * 64 + tn * 32 + lr;
+        c.cb[tn] = pbias[n] + pdb[n];
+        c.os[tn] = posc[n];
+        c.oh[tn] = posh[n];
+      }
     };
-    float cbc, osc_c, osh_c, cbn = 0.f, osc_n = 0.f, osh_n = 0.f;
-    epi_consts(cur, 0, cbc, osc_c, osh_c);
+    EpiC ec, en;
+    epi_consts(cur, 0, ec);
+    en = ec;
     TileMeta nxt = cur, raw2 = cur;
     if (t + gstep < a.T) nxt = scalar(meta_of(t + gstep));
     auto begin_tile = [&](const TileMeta& m, int tt) {
@@ -234,17 +247,21 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
     };
     begin_tile(cur, t);
 
-    auto stage = [&](int s, auto ODD) {
-      constexpr int odd = decltype(ODD)::value;  // s & 1
-      constexpr int ks = (KS == 2) ? odd : 0;  // NS is a multiple of KS and stages alternate
-      const int nt = s / KS;
-      if constexpr (ks == 0) {
+    // One stage = 32 k of one channel tile (KQ: which of the tile's SPT stages; its parity is the LDS buffer / register
+    // slot parity because SPT is even).
+    auto stage = [&](int s, auto KQC) {
+      constexpr int kq = decltype(KQC)::value;
+      constexpr int odd = kq & 1;
+      constexpr int ks = kq >> 1;          // 64-k block of the activation planes
+      constexpr int kk0 = (kq & 1) * 32;   // first k inside it
+      const int nt = s / SPT;
+      if constexpr (kq == 0) {
         const bool last_nt = nt + 1 >= ntn;  // then: first channel tile of the next row tile (same loads, other rows)
         TileMeta m = cur;
         if (last_nt) m = nxt;
         // (handing these constants from waves 0-3 to waves 4-7 through LDS, so that they do not queue behind the
         // activation rows, measured slower than loading them in every wave)
-        epi_consts(m, last_nt ? 0 : nt + 1, cbn, osc_n, osh_n);
+        epi_consts(m, last_nt ? 0 : nt + 1, en);
       }
       // stage s+1 (register slot !odd) -> the other LDS buffer (last read in stage s-1, every wave is past
       // that barrier); then its slot takes the loads of stage s+3
@@ -252,17 +269,18 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
         store_w(1 - odd, std::integral_constant<int, 1 - odd>{});
         load_w((s + 3) % NS, std::integral_constant<int, 1 - odd>{});  // wraps into the next row tile
       }
-      // Four 16-channel steps; the fragments of step j+1 are read while the six MFMAs of step j issue, one
-      // read per MFMA (sched_barrier pins the order): the two waves of a SIMD run in lockstep after every
-      // barrier, so an LDS round trip that is not covered by this wave's own MFMAs is idle matrix-pipe time.
+      // Two 16-channel steps of 12 MFMAs (2 x 2 blocks x 3 terms) fed by 8 fragment reads; the fragments of the second
+      // step are read while the MFMAs of the first issue, one read per MFMA (sched_barrier pins the order): the two waves
+      // of a SIMD run in lockstep after every barrier, so an LDS round trip that is not covered by this wave's own MFMAs
+      // is idle matrix-pipe time.
       const _Float16* ah = &As[ks][0][0];
       const _Float16* al = &As[ks][1][0];
       const _Float16* bh = &Bs[odd][0][0];
       const _Float16* bl = &Bs[odd][1][0];
-      const int offa0 = (wm * 64 + lr) * AR_LDT + kh, offa1 = offa0 + 32 * AR_LDT;
-      const int offb = (wn * 32 + lr) * AR_LDT + kh;
+      const int offa0 = (wm * 64 + lr) * AR_LDT + kk0 + kh, offa1 = offa0 + 32 * AR_LDT;
+      const int offb0 = (wn * 64 + lr) * AR_LDB + kh, offb1 = offb0 + 32 * AR_LDB;
       struct Fr {
-        f16x8 v[6];  // ah0, al0, ah1, al1, bh, bl
+        f16x8 v[8];  // ah0, al0, ah1, al1, bh0, bl0, bh1, bl1
       };
       auto rd1 = [&](Fr& f, auto JC, auto RC) {
         constexpr int j = decltype(JC)::value, r = decltype(RC)::value;
@@ -270,100 +288,98 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
         if constexpr (r == 1) f.v[1] = *reinterpret_cast<const f16x8*>(al + offa0 + j * 16);
         if constexpr (r == 2) f.v[2] = *reinterpret_cast<const f16x8*>(ah + offa1 + j * 16);
         if constexpr (r == 3) f.v[3] = *reinterpret_cast<const f16x8*>(al + offa1 + j * 16);
-        if constexpr (r == 4) f.v[4] = *reinterpret_cast<const f16x8*>(bh + offb + j * 16);
-        if constexpr (r == 5) f.v[5] = *reinterpret_cast<const f16x8*>(bl + offb + j * 16);
+        if constexpr (r == 4) f.v[4] = *reinterpret_cast<const f16x8*>(bh + offb0 + j * 16);
+        if constexpr (r == 5) f.v[5] = *reinterpret_cast<const f16x8*>(bl + offb0 + j * 16);
+        if constexpr (r == 6) f.v[6] = *reinterpret_cast<const f16x8*>(bh + offb1 + j * 16);
+        if constexpr (r == 7) f.v[7] = *reinterpret_cast<const f16x8*>(bl + offb1 + j * 16);
       };
-      auto mm1 = [&](const Fr& f, auto IC) {  // term-major: consecutive MFMAs alternate between the two accumulators
+      auto mm1 = [&](const Fr& f, auto IC) {  // term-major: consecutive MFMAs walk the four accumulators
         constexpr int i = decltype(IC)::value;
-        constexpr int tm = i & 1, term = i >> 1;
-        if constexpr (term == 0) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.v[2 * tm + 1], f.v[4], acc[tm], 0, 0, 0);
-        if constexpr (term == 1) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.v[2 * tm], f.v[5], acc[tm], 0, 0, 0);
-        if constexpr (term == 2) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.v[2 * tm], f.v[4], acc[tm], 0, 0, 0);
-      };
-      auto step = [&](const Fr& cur, Fr& nxt, auto JN) {  // MFMAs of the current step, reads of step JN underneath
-        constexpr int jn = decltype(JN)::value;
-  #define AR_PAIR(I)                                                   \
-    mm1(cur, std::integral_constant<int, I>{});                        \
-    __builtin_amdgcn_sched_barrier(0);                                 \
-    if constexpr (jn < 4) {                                            \
-      rd1(nxt, JN, std::integral_constant<int, I>{});                  \
-      __builtin_amdgcn_sched_barrier(0);                               \
-    }
-        AR_PAIR(0) AR_PAIR(1) AR_PAIR(2) AR_PAIR(3) AR_PAIR(4) AR_PAIR(5)
-  #undef AR_PAIR
+        constexpr int blk = i & 3, term = i >> 2;
+        constexpr int tm = blk >> 1, tn = blk & 1;
+        if constexpr (term == 0) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.v[2 * tm + 1], f.v[4 + 2 * tn], acc[tm][tn], 0, 0, 0);
+        if constexpr (term == 1) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.v[2 * tm], f.v[5 + 2 * tn], acc[tm][tn], 0, 0, 0);
+        if constexpr (term == 2) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.v[2 * tm], f.v[4 + 2 * tn], acc[tm][tn], 0, 0, 0);
       };
       Fr f0, f1;
-      rd1(f0, S0{}, std::integral_constant<int, 0>{});
-      rd1(f0, S0{}, std::integral_constant<int, 1>{});
-      rd1(f0, S0{}, std::integral_constant<int, 2>{});
-      rd1(f0, S0{}, std::integral_constant<int, 3>{});
-      rd1(f0, S0{}, std::integral_constant<int, 4>{});
-      rd1(f0, S0{}, std::integral_constant<int, 5>{});
+  #define AR_RD(F, J, R) rd1(F, std::integral_constant<int, J>{}, std::integral_constant<int, R>{});
+      AR_RD(f0, 0, 0) AR_RD(f0, 0, 1) AR_RD(f0, 0, 2) AR_RD(f0, 0, 3) AR_RD(f0, 0, 4) AR_RD(f0, 0, 5) AR_RD(f0, 0, 6) AR_RD(f0, 0, 7)
       __builtin_amdgcn_sched_barrier(0);
-      step(f0, f1, std::integral_constant<int, 1>{});
-      step(f1, f0, std::integral_constant<int, 2>{});
-      step(f0, f1, std::integral_constant<int, 3>{});
-      step(f1, f0, std::integral_constant<int, 4>{});
-      if constexpr (ks == KS - 1) {
-        // ---- channel tile nt finished: register-only epilogue for this wave's 64 rows x 32 channels ----
+  #define AR_PAIR(I)                                                   \
+    mm1(f0, std::integral_constant<int, I>{});                         \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+    if constexpr (I < 8) {                                             \
+      AR_RD(f1, 1, I)                                                  \
+      __builtin_amdgcn_sched_barrier(0);                               \
+    }
+      AR_PAIR(0) AR_PAIR(1) AR_PAIR(2) AR_PAIR(3) AR_PAIR(4) AR_PAIR(5)
+      AR_PAIR(6) AR_PAIR(7) AR_PAIR(8) AR_PAIR(9) AR_PAIR(10) AR_PAIR(11)
+  #undef AR_PAIR
+  #undef AR_RD
+  #define AR_MM(I) mm1(f1, std::integral_constant<int, I>{});
+      AR_MM(0) AR_MM(1) AR_MM(2) AR_MM(3) AR_MM(4) AR_MM(5) AR_MM(6) AR_MM(7) AR_MM(8) AR_MM(9) AR_MM(10) AR_MM(11)
+  #undef AR_MM
+      if constexpr (kq == SPT - 1) {
+        // ---- channel tile nt finished: register-only epilogue for this wave's 64 rows x 2 x 32 channels ----
         // v = acc*oscale + cb is never formed for full half tiles: the sums are taken on the raw accumulators
         // and rescaled (S = oscale*sum(acc) + n*cb, M2 = oscale^2 * M2(acc), relu(v*os+oh) = relu(acc*(oscale*os)
         // + (cb*os+oh))); 3 VALU ops per value.
-        const int n = nt * AR_BN + wn * 32 + lr;
-        const float cb = cbc, os = osc_c, oh = osh_c;  // fetched one channel tile ahead (see below)
-        if constexpr (MODE & 1) {
-          float s1 = 0.f;
-          if (full) {
-            s1 = mm_sum32(acc[0], acc[1]);
-          } else {
   #pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
+        for (int tn = 0; tn < 2; ++tn) {
+          const int n = nt * AR_BN + wn * 64 + tn * 32 + lr;
+          const float cb = ec.cb[tn], os = ec.os[tn], oh = ec.oh[tn];  // fetched one channel tile ahead
+          if constexpr (MODE & 1) {
+            float s1 = 0.f;
+            if (full) {
+              s1 = mm_sum32(acc[0][tn], acc[1][tn]);
+            } else {
   #pragma unroll
-              for (int e = 0; e < 16; ++e)
-                if (tm * 32 + (e & 3) + 8 * (e >> 2) < lim) s1 += acc[tm][e];
+              for (int tm = 0; tm < 2; ++tm)
+  #pragma unroll
+                for (int e = 0; e < 16; ++e)
+                  if (tm * 32 + (e & 3) + 8 * (e >> 2) < lim) s1 += acc[tm][tn][e];
+            }
+            s1 = mm_xor32_sum(s1);
+            const float mu = s1 * inv_nsub;  // mean of the raw accumulators over the half tile
+            float s2 = 0.f;
+            if (full) {
+              s2 = mm_m2_32(acc[0][tn], acc[1][tn], mu);
+            } else {
+  #pragma unroll
+              for (int tm = 0; tm < 2; ++tm)
+  #pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                  const float d = acc[tm][tn][e] - mu;
+                  if (tm * 32 + (e & 3) + 8 * (e >> 2) < lim) s2 = fmaf(d, d, s2);
+                }
+            }
+            s2 = mm_xor32_sum(s2);
+            if (lane < 32) {
+              a.part[(prow * 2 + 0) * a.N + n] = fmaf(s1, a.oscale, (float)nsub * cb);
+              a.part[(prow * 2 + 1) * a.N + n] = s2 * a.oscale * a.oscale;
+            }
           }
-          s1 = mm_xor32_sum(s1);
-          const float mu = s1 * inv_nsub;  // mean of the raw accumulators over the half tile
-          float s2 = 0.f;
-          if (full) {
-            s2 = mm_m2_32(acc[0], acc[1], mu);
-          } else {
+          if constexpr (MODE & 2) {
+            const float m1 = a.oscale * os, m0 = fmaf(cb, os, oh);
+            float s3 = 0.f;
+            if (full) {
+              s3 = mm_relu_sum32(acc[0][tn], acc[1][tn], m1, m0);
+            } else {
   #pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
+              for (int tm = 0; tm < 2; ++tm)
   #pragma unroll
-              for (int e = 0; e < 16; ++e) {
-                const float d = acc[tm][e] - mu;
-                if (tm * 32 + (e & 3) + 8 * (e >> 2) < lim) s2 = fmaf(d, d, s2);
-              }
+                for (int e = 0; e < 16; ++e)
+                  if (tm * 32 + (e & 3) + 8 * (e >> 2) < lim) s3 += fmaxf(fmaf(acc[tm][tn][e], m1, m0), 0.f);
+            }
+            s3 = mm_xor32_sum(s3);
+            if (lane < 32) a.colsum[prow * a.N + n] = s3;
           }
-          s2 = mm_xor32_sum(s2);
-          if (lane < 32) {
-            a.part[(prow * 2 + 0) * a.N + n] = fmaf(s1, a.oscale, (float)nsub * cb);
-            a.part[(prow * 2 + 1) * a.N + n] = s2 * a.oscale * a.oscale;
-          }
+  #pragma unroll
+          for (int tm = 0; tm < 2; ++tm)
+  #pragma unroll
+            for (int e = 0; e < 16; ++e) acc[tm][tn][e] = 0.f;
         }
-        if constexpr (MODE & 2) {
-          const float m1 = a.oscale * os, m0 = fmaf(cb, os, oh);
-          float s3 = 0.f;
-          if (full) {
-            s3 = mm_relu_sum32(acc[0], acc[1], m1, m0);
-          } else {
-  #pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
-  #pragma unroll
-              for (int e = 0; e < 16; ++e)
-                if (tm * 32 + (e & 3) + 8 * (e >> 2) < lim) s3 += fmaxf(fmaf(acc[tm][e], m1, m0), 0.f);
-          }
-          s3 = mm_xor32_sum(s3);
-          if (lane < 32) a.colsum[prow * a.N + n] = s3;
-        }
-  #pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-  #pragma unroll
-          for (int e = 0; e < 16; ++e) acc[tm][e] = 0.f;
-        cbc = cbn;
-        osc_c = osc_n;
-        osh_c = osh_n;
+        ec = en;
       }
       __syncthreads();
     };
@@ -376,17 +392,20 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
       // table words of the tile after the next: unconditional (clamped) so that the number of loads in flight stays fixed;
       // consumed a whole tile later
       raw2 = meta_of(more2 ? tn + gstep : tn < a.T ? tn : t);
-      for (int s = 0; s < NS; s += 2) {
+      for (int s = 0; s < NS; s += SPT) {
         if constexpr (!WS)
           if (more && s == 0) load_x(nxt);
-        stage(s, S0{});
-        if (s + 1 < NS) stage(s + 1, S1{});
+        stage(s, std::integral_constant<int, 0>{});
+        stage(s + 1, std::integral_constant<int, 1>{});
+        if constexpr (SPT == 4) {
+          stage(s + 2, std::integral_constant<int, 2>{});
+          stage(s + 3, std::integral_constant<int, 3>{});
+        }
       }
       if (!more) break;
       // tile switch: every wave is past the barrier that ended the last stage, As is free
       if constexpr (!WS) stage_a(nxt);
-      if (wrap_ok) __syncthreads();
-      else prime_w();  // odd stage count: the buffer parity restarts, re-prime the weight pipeline
+      __syncthreads();  // NS is even: the LDS buffer parity of stage 0 repeats, the weight stream simply continues
       cur = nxt;
       if (more2) nxt = scalar(raw2);
       t = tn;
@@ -402,7 +421,7 @@ int mmmot_gemm_wres64_launch(const mmmot_gemm_ares_args* a, int mode, int n_cu, 
 extern "C" int mmmot_gemm_ares(const mmmot_gemm_ares_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!a || !a->X || !a->W || !a->sc || !a->sh || !a->tile_row0 || !a->tile_nrows || a->T <= 0) return MMMOT_EINVAL;
-  if ((a->K != 64 && a->K != 128) || a->N <= 0 || a->N % AR_BN != 0) return MMMOT_EINVAL;
+  if ((a->K != 64 && a->K != 128) || a->N <= 0 || a->N % 128 != 0) return MMMOT_EINVAL;
   if (a->ldx % 4 != 0 || a->ldsc % 4 != 0 || !mm_al16(a->X) || !mm_al16(a->W) || !mm_al16(a->sc) || !mm_al16(a->sh))
     return MMMOT_EINVAL;
   if (a->dbias && !a->tile_dbrow) return MMMOT_EINVAL;
@@ -419,6 +438,7 @@ extern "C" int mmmot_gemm_ares(const mmmot_gemm_ares_args* a, void* stream) {
     return !(e && e[0] == '0');
   }();
   if (use_wres && a->K == 64 && a->N <= 512) return mmmot_gemm_wres64_launch(a, mode, n_cu, s);
+  if (a->N % AR_BN != 0) return MMMOT_EINVAL;  // the streaming kernel walks 256-channel tiles
   const int grid = a->T < n_cu ? a->T : n_cu;  // persistent: one workgroup per CU
 #define AR_LAUNCH(KSV, MODEV) \
   hipLaunchKernelGGL((gemm_ares_kernel<KSV, MODEV>), dim3(grid), dim3(AR_THREADS), 0, s, *a)
