@@ -496,6 +496,31 @@ int mmmot_add_rows(const float* A, int lda, const float* B, int ldb, float* Y, i
  * points): X[r][c] = S[rowidx[r]][c] * scale[rowidx[r]]  (scale = 1 / points of the detection; NULL = 1).  C % 4 == 0. */
 int mmmot_rows_gather_scale(const float* S, int lds, const int* rowidx, const float* scale, float* X, int ldx, long R,
                             int C, void* stream);
+/* ---- third slice: the VGG16-BN trunk in TRAINING mode (reference modules/vgg.py:67-80 under .train(): BatchNorm2d on
+ * the statistics of the batch) and its backward; fp32 NHWC, exact fp32 matrix cores (conv3x3.hip, csrc/train_vgg.hip) ----
+ * mmmot_conv3x3_raw: out = conv3x3(in, wp) + bias (no BatchNorm fold, no ReLU); layouts of mmmot_conv3x3_bn_relu.  Also
+ * the input gradient of a layer: in = dZ, wp = the layer's weights with taps flipped and Cin / Cout swapped, bias = 0. */
+int mmmot_conv3x3_raw(const float* in, const float* wp, const float* bias, float* out, int L, int H, int W, int Cin,
+                      int Cout, int first, void* stream);
+/* per-tile statistics of an existing tensor: part[t][0][c] = sum_r Y[r][c], part[t][1][c] = sum_r (Y[r][c] - tile mean)^2
+ * (the `part` contract of mmmot_gemm_rows; input of mmmot_gn_finalize).  C % 4 == 0. */
+int mmmot_rows_stats(const float* Y, int ldy, int C, const int* tile_row0, const int* tile_nrows, int T, float* part,
+                     void* stream);
+/* A = relu(Z * sc + sh) per channel (sc / sh [C]: the batch statistics folded by mmmot_gn_finalize), followed by the
+ * 2x2 / stride-2 max-pool with floor semantics when pool != 0.  Z NHWC [L][H][W][C] -> A [L][H >> pool][W >> pool][C]. */
+int mmmot_bn_relu_pool(const float* Z, int C, const float* sc, const float* sh, int L, int H, int W, int pool, float* A,
+                       void* stream);
+/* backward of that max-pool: dA [L][H][W][C] = dP of the window at the window's first maximum of relu(Z * sc + sh)
+ * (PyTorch's tie rule), zero elsewhere (odd maps: the last row / column belongs to no window). */
+int mmmot_maxpool_bwd(const float* Z, int C, const float* sc, const float* sh, const float* dP, int L, int H, int W,
+                      float* dA, void* stream);
+/* weight gradient of a 3x3 convolution: dW[s][tap][co][ci] = sum over share s of the pixels of dZ[p][co] * A[p + off(tap)][ci]
+ * (zero padding); nsplit shares, the caller adds them.  Cin % 64 == 0, Cout % 64 == 0. */
+int mmmot_conv3x3_wgrad(const float* dZ, const float* A, int L, int H, int W, int Cin, int Cout, int nsplit, float* dW,
+                        void* stream);
+/* first layer (NCHW crops X [L][3][H][W], Cout = 64): PW[b][co][28] partial sums over block b's pixels of
+ * (dW1[co][k = tap * 3 + colour], k < 27 | db1[co]); the caller adds the nblocks partials. */
+int mmmot_conv3x3_first_wgrad(const float* dZ, const float* X, int L, int H, int W, float* PW, int nblocks, void* stream);
 /* weight / bias gradient of PointNetfeatGN.conv1 with the first transform folded in (forward: mmmot_pointnet_layer1;
  * reference modules/point_net.py:119-125): per-tile partials PW[t][c * (K + 1) + k] = sum_r dY[r][c] X[r][k] (k < K),
  * [..][K] = sum_r dY[r][c]; dY [P][64], X [P][K], K = 3 | 4.  The caller adds the T partial rows. */

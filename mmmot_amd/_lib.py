@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.environ.get('MMMOT_LIB_PATH', os.path.join(_HERE, 'libmmmot_hip.so'))  # override: tools' timing-experiment builds
 SOURCES = ['conv3x3.hip', 'hl16_format.hip', 'conv3x3_hl16_patch.hip', 'gemm_rows.hip',
-           'gemm_ares.hip', 'gemm_wres.hip', 'pn_mlp64.hip', 'gram.hip', 'points_gather.hip', 'crop_resize.hip', 'small_kernels.hip', 'backward.hip', 'train.hip']
+           'gemm_ares.hip', 'gemm_wres.hip', 'pn_mlp64.hip', 'gram.hip', 'points_gather.hip', 'crop_resize.hip', 'small_kernels.hip', 'backward.hip', 'train.hip', 'train_vgg.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 HIPFLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
 
@@ -128,6 +128,12 @@ SIGNATURES = {
     'mmmot_softmax_pairs_bwd': [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f],
     'mmmot_fusion_c_bwd': [c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_f, c_f, c_i, c_f, c_f, c_i, c_f],
     'mmmot_add_rows': [c_f, c_i, c_f, c_i, c_f, c_i, ctypes.c_long, c_i, c_f],
+    'mmmot_conv3x3_raw': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f],
+    'mmmot_rows_stats': [c_f, c_i, c_i, c_f, c_f, c_i, c_f, c_f],
+    'mmmot_bn_relu_pool': [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f],
+    'mmmot_maxpool_bwd': [c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f],
+    'mmmot_conv3x3_wgrad': [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f],
+    'mmmot_conv3x3_first_wgrad': [c_f, c_f, c_i, c_i, c_i, c_f, c_i, c_f],
     'mmmot_rows_gather_scale': [c_f, c_i, c_f, c_f, c_f, c_i, ctypes.c_long, c_i, c_f],
     'mmmot_pointnet_layer1_bwd': [c_f, c_f, c_i, c_f, c_f, c_i, c_f, c_f],
     'mmmot_score_loss': [c_f, c_i, c_f, c_f, c_f, c_i, c_i, ctypes.c_float, c_i, ctypes.c_float, c_i, c_i, c_f, c_i, c_f,

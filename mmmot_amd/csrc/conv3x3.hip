@@ -15,7 +15,9 @@
 
 // OUT16: write the output in the hl16 split-half format consumed by conv3x3_hl16.hip
 // (unit u of a pixel = [hi of channels 8u..8u+7 | lo of channels 8u..8u+7], 2-byte stores).
-template <int BN, bool FIRST, bool POOL, bool OUT16 = false>
+// RAW: bias only - no ReLU, no folded BatchNorm - the pre-BatchNorm tensor of the training-mode trunk (train_vgg.hip) and,
+// with flipped / transposed weights, its input gradient.
+template <int BN, bool FIRST, bool POOL, bool OUT16 = false, bool RAW = false>
 __global__ __launch_bounds__(MM_THREADS, 2) void conv3x3_kernel(
     const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
     float* __restrict__ out, int L, int H, int W, int Cin, int Cout, int Mtot, int ntn) {
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(MM_THREADS, 2) void conv3x3_kernel(
             const int yq = rem / Wq, xq = rem - yq * Wq;
             const long pix = ((long)crop * H + 2 * yq + (sub >> 1)) * W + 2 * xq + (sub & 1);
             if (2 * yq + (sub >> 1) >= H || 2 * xq + (sub & 1) >= W) continue;
-            const float val = fmaxf(acc[tm][tn][e] + bv, 0.f);
+            const float val = RAW ? acc[tm][tn][e] + bv : fmaxf(acc[tm][tn][e] + bv, 0.f);
             if constexpr (OUT16) {
               _Float16* o16 = reinterpret_cast<_Float16*>(out) + pix * Cout * 2 + (n >> 3) * 16 + (n & 7);
               const _Float16 h = (_Float16)val;
@@ -227,13 +229,13 @@ __global__ __launch_bounds__(MM_THREADS, 2) void conv3x3_kernel(
   }
 }
 
-template <int BN, bool FIRST, bool POOL, bool OUT16 = false>
+template <int BN, bool FIRST, bool POOL, bool OUT16 = false, bool RAW = false>
 static int launch_conv(const float* in, const float* wp, const float* bias, float* out, int L, int H,
                        int W, int Cin, int Cout, hipStream_t s) {
   const int Mtot = L * 4 * ((H + 1) >> 1) * ((W + 1) >> 1);  // pixels of the maps padded to even sides (quad order)
   const int ntm = (Mtot + MM_BM - 1) / MM_BM;
   const int ntn = Cout / BN;
-  hipLaunchKernelGGL((conv3x3_kernel<BN, FIRST, POOL, OUT16>), dim3(ntm * ntn), dim3(MM_THREADS), 0, s, in, wp,
+  hipLaunchKernelGGL((conv3x3_kernel<BN, FIRST, POOL, OUT16, RAW>), dim3(ntm * ntn), dim3(MM_THREADS), 0, s, in, wp,
                      bias, out, L, H, W, Cin, Cout, Mtot, ntn);
   return mm_check(hipGetLastError());
 }
@@ -260,6 +262,24 @@ extern "C" int mmmot_conv3x3_bn_relu(const float* in, const float* wp, const flo
                 : launch_conv<128, false, false>(in, wp, bias, out, L, H, W, Cin, Cout, s);
   return pool ? launch_conv<64, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, s)
               : launch_conv<64, false, false>(in, wp, bias, out, L, H, W, Cin, Cout, s);
+}
+
+// conv3x3 (pad 1) + bias, nothing else: out NHWC [L][H][W][Cout] = conv(in) + bias.  first / in / wp as in
+// mmmot_conv3x3_bn_relu (wp holds the UNFOLDED convolution weights).
+extern "C" int mmmot_conv3x3_raw(const float* in, const float* wp, const float* bias, float* out, int L, int H, int W,
+                                 int Cin, int Cout, int first, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!in || !wp || !bias || !out || L <= 0 || H <= 0 || W <= 0 || (Cout % 64) != 0) return MMMOT_EINVAL;
+  if (!mm_al16(in) || !mm_al16(wp) || !mm_al16(out)) return MMMOT_EINVAL;
+  if ((long)L * (H + 1) * (W + 1) >= (1L << 31) - MM_BM) return MMMOT_EINVAL;
+  if (first) {
+    if (Cin != 3) return MMMOT_EINVAL;
+    return (Cout % 128 == 0) ? launch_conv<128, true, false, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, s)
+                             : launch_conv<64, true, false, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, s);
+  }
+  if (Cin % MM_BK != 0) return MMMOT_EINVAL;
+  return (Cout % 128 == 0) ? launch_conv<128, false, false, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, s)
+                           : launch_conv<64, false, false, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, s);
 }
 
 // First trunk layer (NCHW fp32 crops in, K = 27) with hl16 output for the fp16-split trunk.

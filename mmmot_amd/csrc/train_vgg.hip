@@ -1,0 +1,246 @@
+// Training step, third slice: the VGG16-BN trunk in TRAINING mode and its backward
+// (reference modules/vgg.py:67-80 under model.train(): conv3x3 -> BatchNorm2d on the statistics of the batch -> ReLU
+// (-> MaxPool 2x2), tracking_model.py:50-66).  The inference trunk folds the running statistics into the weights and runs
+// on the fp16 matrix cores; training cannot fold (the statistics are those of the batch and receive gradients), so this
+// path is separate and plain: fp32 NHWC activations, exact fp32 matrix cores, every pre-BatchNorm tensor kept.
+//   forward  : mmmot_conv3x3_raw (conv3x3.hip, bias only) -> mmmot_rows_stats -> mmmot_gn_finalize (per channel over
+//              all pixels of the batch = GroupNorm(C, C) with one group) -> mmmot_bn_relu_pool
+//   backward : mmmot_maxpool_bwd -> mmmot_gn_bwd_* (backward.hip; BatchNorm backward IS that GroupNorm backward) ->
+//              mmmot_conv3x3_wgrad / mmmot_conv3x3_first_wgrad (dW, db) -> mmmot_conv3x3_raw with the flipped, transposed
+//              weights (dX)
+// Deterministic: per-tile / per-share partial sums, no atomics.
+#include "common.h"
+
+// part[t][0][c] = sum over the tile's rows of Y[r][c], part[t][1][c] = sum of (Y[r][c] - tile mean)^2: the statistics
+// contract of mmmot_gemm_rows (input of mmmot_gn_finalize) for a tensor that already exists.  One workgroup per tile.
+__global__ __launch_bounds__(256) void rows_stats_kernel(const float* __restrict__ Y, int ldy, int C,
+                                                         const int* __restrict__ tile_row0,
+                                                         const int* __restrict__ tile_nrows, float* __restrict__ part) {
+  const int t = blockIdx.x;
+  const int row0 = tile_row0[t], nrows = tile_nrows[t];
+  for (int c = (blockIdx.y * 256 + threadIdx.x) * 4; c < C; c += gridDim.y * 1024) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < nrows; ++r) s += *reinterpret_cast<const f32x4*>(&Y[(long)(row0 + r) * ldy + c]);
+    const float inv = nrows > 0 ? 1.f / (float)nrows : 0.f;
+    const f32x4 mu = s * inv;
+    f32x4 q = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < nrows; ++r) {
+      const f32x4 d = *reinterpret_cast<const f32x4*>(&Y[(long)(row0 + r) * ldy + c]) - mu;
+      q += d * d;
+    }
+    *reinterpret_cast<f32x4*>(&part[((long)t * 2 + 0) * C + c]) = s;
+    *reinterpret_cast<f32x4*>(&part[((long)t * 2 + 1) * C + c]) = q;
+  }
+}
+
+extern "C" int mmmot_rows_stats(const float* Y, int ldy, int C, const int* tile_row0, const int* tile_nrows, int T,
+                                float* part, void* stream) {
+  if (!Y || !tile_row0 || !tile_nrows || !part || T <= 0 || C <= 0 || C % 4 != 0 || ldy % 4 != 0) return MMMOT_EINVAL;
+  if (!mm_al16(Y) || !mm_al16(part)) return MMMOT_EINVAL;
+  const int gy = (C + 1023) / 1024;
+  hipLaunchKernelGGL(rows_stats_kernel, dim3(T, gy), dim3(256), 0, (hipStream_t)stream, Y, ldy, C, tile_row0, tile_nrows,
+                     part);
+  return mm_check(hipGetLastError());
+}
+
+// A[.][c] = relu(Z[.][c] * sc[c] + sh[c]), then (pool != 0) the 2x2 / stride-2 maximum with floor semantics
+// (nn.MaxPool2d(2, 2): odd maps lose their last row / column).  Z NHWC [L][H][W][C] -> A [L][Ho][Wo][C].
+__global__ __launch_bounds__(256) void bn_relu_pool_kernel(const float* __restrict__ Z, int C,
+                                                           const float* __restrict__ sc, const float* __restrict__ sh,
+                                                           int L, int H, int W, int pool, float* __restrict__ A) {
+  const int Ho = pool ? H >> 1 : H, Wo = pool ? W >> 1 : W;
+  const int C4 = C >> 2;
+  const long n = (long)L * Ho * Wo * C4;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+    const int c = (int)(idx % C4) * 4;
+    const long p = idx / C4;
+    const int xo = (int)(p % Wo);
+    const long q = p / Wo;
+    const int yo = (int)(q % Ho);
+    const long crop = q / Ho;
+    const f32x4 s4 = *reinterpret_cast<const f32x4*>(&sc[c]);
+    const f32x4 h4 = *reinterpret_cast<const f32x4*>(&sh[c]);
+    f32x4 o;
+    if (pool) {
+      o = f32x4{0.f, 0.f, 0.f, 0.f};  // relu outputs are >= 0: the maximum of a window starts from 0
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const long pix = (crop * H + 2 * yo + (k >> 1)) * W + 2 * xo + (k & 1);
+        const f32x4 z = *reinterpret_cast<const f32x4*>(&Z[pix * C + c]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], fmaf(z[e], s4[e], h4[e]));
+      }
+    } else {
+      const f32x4 z = *reinterpret_cast<const f32x4*>(&Z[p * C + c]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = fmaxf(fmaf(z[e], s4[e], h4[e]), 0.f);
+    }
+    *reinterpret_cast<f32x4*>(&A[p * C + c]) = o;
+  }
+}
+
+extern "C" int mmmot_bn_relu_pool(const float* Z, int C, const float* sc, const float* sh, int L, int H, int W, int pool,
+                                  float* A, void* stream) {
+  if (!Z || !sc || !sh || !A || L <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0) return MMMOT_EINVAL;
+  if (pool && (H < 2 || W < 2)) return MMMOT_EINVAL;
+  if (!mm_al16(Z) || !mm_al16(A) || !mm_al16(sc) || !mm_al16(sh)) return MMMOT_EINVAL;
+  const long n = (long)L * (pool ? H >> 1 : H) * (pool ? W >> 1 : W) * (C / 4);
+  const int grid = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+  hipLaunchKernelGGL(bn_relu_pool_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, Z, C, sc, sh, L, H, W, pool, A);
+  return mm_check(hipGetLastError());
+}
+
+// Backward of the 2x2 max-pool of relu(Z * sc + sh): dA [L][H][W][C] = dP of the window routed to the window's FIRST
+// maximum in (0,0), (0,1), (1,0), (1,1) order (PyTorch's max_pool2d backward), zero elsewhere - including the last row /
+// column of an odd map, which belongs to no window.  One thread per (window, 4 channels) plus the leftover pixels.
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ Z, int C, const float* __restrict__ sc,
+                                                          const float* __restrict__ sh, const float* __restrict__ dP, int L,
+                                                          int H, int W, float* __restrict__ dA) {
+  const int Hq = (H + 1) >> 1, Wq = (W + 1) >> 1, Ho = H >> 1, Wo = W >> 1;
+  const int C4 = C >> 2;
+  const long n = (long)L * Hq * Wq * C4;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+    const int c = (int)(idx % C4) * 4;
+    const long p = idx / C4;
+    const int xq = (int)(p % Wq);
+    const long q = p / Wq;
+    const int yq = (int)(q % Hq);
+    const long crop = q / Hq;
+    const bool win = yq < Ho && xq < Wo;
+    const f32x4 s4 = *reinterpret_cast<const f32x4*>(&sc[c]);
+    const f32x4 h4 = *reinterpret_cast<const f32x4*>(&sh[c]);
+    f32x4 a[4], g = {0.f, 0.f, 0.f, 0.f};
+    int arg[4] = {0, 0, 0, 0};
+    if (win) {
+      g = *reinterpret_cast<const f32x4*>(&dP[((crop * Ho + yq) * Wo + xq) * C + c]);
+      f32x4 best;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const long pix = (crop * H + 2 * yq + (k >> 1)) * W + 2 * xq + (k & 1);
+        const f32x4 z = *reinterpret_cast<const f32x4*>(&Z[pix * C + c]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a[k][e] = fmaxf(fmaf(z[e], s4[e], h4[e]), 0.f);
+          if (k == 0 || a[k][e] > best[e]) {  // strictly greater: ties keep the first
+            best[e] = a[k][e];
+            arg[e] = k;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int y = 2 * yq + (k >> 1), x = 2 * xq + (k & 1);
+      if (y < H && x < W) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (win && arg[e] == k) ? g[e] : 0.f;
+        *reinterpret_cast<f32x4*>(&dA[((crop * H + y) * W + x) * C + c]) = o;
+      }
+    }
+  }
+}
+
+extern "C" int mmmot_maxpool_bwd(const float* Z, int C, const float* sc, const float* sh, const float* dP, int L, int H,
+                                 int W, float* dA, void* stream) {
+  if (!Z || !sc || !sh || !dP || !dA || L <= 0 || H < 2 || W < 2 || C <= 0 || C % 4 != 0) return MMMOT_EINVAL;
+  if (!mm_al16(Z) || !mm_al16(dP) || !mm_al16(dA) || !mm_al16(sc) || !mm_al16(sh)) return MMMOT_EINVAL;
+  const long n = (long)L * ((H + 1) >> 1) * ((W + 1) >> 1) * (C / 4);
+  const int grid = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, Z, C, sc, sh, dP, L, H, W, dA);
+  return mm_check(hipGetLastError());
+}
+
+// Weight gradient of a 3x3 convolution (pad 1): dW[tap][co][ci] = sum over pixels p of dZ[p][co] * A[p + off(tap)][ci]
+// (zero outside the image); dZ NHWC [L][H][W][Cout], A NHWC [L][H][W][Cin].  Like gemm_tn_kernel (backward.hip): one
+// workgroup = 4 waves = one 64 x 64 tile of one tap's dW, the pixel axis is the K of v_mfma_f32_32x32x2_f32 (two pixels per
+// instruction, both operands coalesced 128-byte row reads), pixels split into gridDim.z contiguous shares whose partial
+// dW the caller adds.  grid = (Cout / 64, Cin / 64, 9 * nsplit).
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restrict__ dZ, const float* __restrict__ A, int L,
+                                                            int H, int W, int Cin, int Cout, int nsplit,
+                                                            float* __restrict__ dW) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * 64 + (wave >> 1) * 32, k0 = blockIdx.y * 64 + (wave & 1) * 32;
+  const int tap = blockIdx.z / nsplit, share = blockIdx.z - tap * nsplit;
+  const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+  const int lr = lane & 31, hf = lane >> 5;
+  const long P = (long)L * H * W;
+  const long p_lo = P * share / nsplit, p_hi = P * (share + 1) / nsplit;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const int n = n0 + lr, k = k0 + lr;
+  const int HW = H * W;
+  for (long p = p_lo; p < p_hi; p += 2) {
+    const long pp = p + hf;
+    const bool ok = pp < p_hi;
+    const long pc = ok ? pp : p_lo;
+    const int rem = (int)(pc % HW);
+    const int y = rem / W, x = rem - y * W;
+    const int yy = y + dy, xx = x + dx;
+    const bool in = ok && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+    float dz = dZ[pc * Cout + n];
+    float av = A[(in ? pc + (long)dy * W + dx : pc) * Cin + k];
+    dz = ok ? dz : 0.f;
+    av = in ? av : 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dz, av, acc, 0, 0, 0);
+  }
+  float* out = dW + ((long)share * 9 + tap) * Cout * Cin;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) out[(long)(n0 + mm_acc_row(e, lane)) * Cin + k0 + lr] = acc[e];
+}
+
+extern "C" int mmmot_conv3x3_wgrad(const float* dZ, const float* A, int L, int H, int W, int Cin, int Cout, int nsplit,
+                                   float* dW, void* stream) {
+  if (!dZ || !A || !dW || L <= 0 || H <= 0 || W <= 0 || Cin % 64 != 0 || Cout % 64 != 0 || Cin <= 0 || Cout <= 0)
+    return MMMOT_EINVAL;
+  if (nsplit < 1 || nsplit > 256) return MMMOT_EINVAL;
+  hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(Cout / 64, Cin / 64, 9 * nsplit), dim3(256), 0, (hipStream_t)stream, dZ, A, L,
+                     H, W, Cin, Cout, nsplit, dW);
+  return mm_check(hipGetLastError());
+}
+
+// First layer (3 input channels, NCHW crops as delivered): PW[b][co][k] partial sums of dW1[co][k = tap * 3 + colour]
+// = sum_p dZ[p][co] * X[crop][colour][p + off(tap)] over block b's pixels (28 columns: 27 + the bias gradient sum_p dZ).
+// VALU, like the forward's K = 27 case is not matrix-core shaped; float64 accumulation (the sums cancel: BatchNorm
+// backward makes sum_p dZ = 0).  grid = nblocks workgroups, each 256 threads = 64 channels x 4 pixel phases.
+__global__ __launch_bounds__(256) void conv3x3_first_wgrad_kernel(const float* __restrict__ dZ, const float* __restrict__ X,
+                                                                  int L, int H, int W, float* __restrict__ PW) {
+  __shared__ double red[4][64][28];
+  const int c = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const long P = (long)L * H * W;
+  const long p_lo = P * blockIdx.x / gridDim.x, p_hi = P * (blockIdx.x + 1) / gridDim.x;
+  double acc[28];
+#pragma unroll
+  for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+  const int HW = H * W;
+  for (long p = p_lo + ph; p < p_hi; p += 4) {
+    const int crop = (int)(p / HW), rem = (int)(p - (long)crop * HW);
+    const int y = rem / W, x = rem - y * W;
+    const double d = (double)dZ[p * 64 + c];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+      if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+#pragma unroll
+        for (int col = 0; col < 3; ++col)
+          acc[tap * 3 + col] = fma(d, (double)X[(((long)crop * 3 + col) * H + yy) * W + xx], acc[tap * 3 + col]);
+      }
+    }
+    acc[27] += d;
+  }
+#pragma unroll
+  for (int k = 0; k < 28; ++k) red[ph][c][k] = acc[k];
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 64 * 28; idx += 256) {
+    const int cc = idx / 28, k = idx - cc * 28;
+    PW[(long)blockIdx.x * 64 * 28 + idx] = (float)(red[0][cc][k] + red[1][cc][k] + red[2][cc][k] + red[3][cc][k]);
+  }
+}
+
+extern "C" int mmmot_conv3x3_first_wgrad(const float* dZ, const float* X, int L, int H, int W, float* PW, int nblocks,
+                                         void* stream) {
+  if (!dZ || !X || !PW || L <= 0 || H <= 0 || W <= 0 || nblocks <= 0 || nblocks > 65535) return MMMOT_EINVAL;
+  hipLaunchKernelGGL(conv3x3_first_wgrad_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, dZ, X, L, H, W, PW);
+  return mm_check(hipGetLastError());
+}

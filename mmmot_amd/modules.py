@@ -396,7 +396,7 @@ class TrackingNet(nn.Module):
         self._engine = None
         self._engine_key = None
         self._plans = {}
-        self.freeze_appearance = False  # training mode: opt-in to frozen eval-mode image features (mmmot_amd/train.py)
+        self.freeze_appearance = False  # training mode: True = frozen eval-mode image features instead of the training trunk
         self._pack_version = 0     # bumped whenever packed weights are REPLACED (captured graphs go stale)
         self._head_versions = None  # parameter versions the live engine's head was packed from
 
@@ -534,7 +534,8 @@ class TrackingNet(nn.Module):
         """Same contract as reference modules/tracking_net.py:165-193: in eval mode
         (det_scores 3xL, [link_scores 3xNxM ...], new_scores 3xL, end_scores 3xL, trans); in training mode
         (``.train()``) the differentiable forward of mmmot_amd/train.py - raw det scores, new / end scores without the
-        eval padding - which needs ``self.freeze_appearance = True`` (the VGG trunk's training mode is not built)."""
+        eval padding, batch-statistics BatchNorm in the trunk and w_det (``self.freeze_appearance = True`` runs the image
+        branch frozen in eval mode instead)."""
         if self.training:
             from .train import forward_train
             return forward_train(self, dets, det_info, dets_split)

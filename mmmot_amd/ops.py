@@ -392,6 +392,33 @@ class HipOps:
                                        PL.numel(), int(bool(accumulate)), self._stream())
         _lib.check(st, 'mmmot_score_loss')
 
+    # ---- training step, third slice: training-mode VGG trunk (csrc/train_vgg.hip, conv3x3.hip RAW) ----
+    def conv3x3_raw(self, inp, wp, bias, out, L, H, W, Cin, Cout, first):
+        st = self.lib.mmmot_conv3x3_raw(_ptr(inp), _ptr(wp), _ptr(bias), _ptr(out), L, H, W, Cin, Cout, int(first),
+                                        self._stream())
+        _lib.check(st, 'mmmot_conv3x3_raw')
+
+    def rows_stats(self, Y, C, tiles, part):
+        st = self.lib.mmmot_rows_stats(_ptr(Y), _ld(Y), C, _iptr(tiles.row0), _iptr(tiles.nrows), tiles.T, _ptr(part),
+                                       self._stream())
+        _lib.check(st, 'mmmot_rows_stats')
+
+    def bn_relu_pool(self, Z, C, sc, sh, L, H, W, pool, A):
+        st = self.lib.mmmot_bn_relu_pool(_ptr(Z), C, _ptr(sc), _ptr(sh), L, H, W, int(bool(pool)), _ptr(A), self._stream())
+        _lib.check(st, 'mmmot_bn_relu_pool')
+
+    def maxpool_bwd(self, Z, C, sc, sh, dP, L, H, W, dA):
+        st = self.lib.mmmot_maxpool_bwd(_ptr(Z), C, _ptr(sc), _ptr(sh), _ptr(dP), L, H, W, _ptr(dA), self._stream())
+        _lib.check(st, 'mmmot_maxpool_bwd')
+
+    def conv3x3_wgrad(self, dZ, A, L, H, W, Cin, Cout, nsplit, dW):
+        st = self.lib.mmmot_conv3x3_wgrad(_ptr(dZ), _ptr(A), L, H, W, Cin, Cout, nsplit, _ptr(dW), self._stream())
+        _lib.check(st, 'mmmot_conv3x3_wgrad')
+
+    def conv3x3_first_wgrad(self, dZ, X, L, H, W, PW):
+        st = self.lib.mmmot_conv3x3_first_wgrad(_ptr(dZ), _ptr(X), L, H, W, _ptr(PW), PW.shape[0], self._stream())
+        _lib.check(st, 'mmmot_conv3x3_first_wgrad')
+
     def selftest_mfma(self, A, B, C, K):
         _lib.check(self.lib.mmmot_selftest_mfma(_ptr(A), _ptr(B), _ptr(C), K, self._stream()),
                    'mmmot_selftest_mfma')

@@ -19,9 +19,9 @@ The reference's training step is ``tracking_model.py:50-66``: training-mode ``Tr
 * ``TrackingLoss``: the reference's criterion with the reference's signature; the score terms and their gradients come
   from ``mmmot_score_loss`` in one pass, the transform regulariser (a 64 x 64 expression) stays in torch.
 * ``forward_train(model, dets, det_info, dets_split)``: the training-mode forward with the reference's return contract
-  (raw det scores, no eval padding of new / end), attached to autograd.  The image branch runs FROZEN in eval mode
-  (folded running statistics, no gradient): the VGG trunk's training mode (batch-statistics BatchNorm2d) and backward
-  are not built, so a caller has to opt in with ``model.freeze_appearance = True``.
+  (raw det scores, no eval padding of new / end), attached to autograd: image encoder in training mode
+  (mmmot_amd/train_vgg.py: batch-statistics BatchNorm2d, differentiable) unless ``model.freeze_appearance`` is set, in
+  which case the image branch runs frozen on the eval-mode inference trunk (folded running statistics, no gradient).
 """
 import numpy as np
 import torch
@@ -295,13 +295,9 @@ class TrackingLoss(nn.Module):
 def forward_train(model, dets, det_info, dets_split):
     """``TrackingNet.forward`` in training mode (reference modules/tracking_net.py:165-193 with ``self.training``):
     returns (det_scores 3 x L raw, [link_scores 3 x N x M ...], new_scores 3 x (L - N_first), end_scores 3 x (L - N_last),
-    trans) on the autograd graph of the PointNet and head parameters.  Needs ``model.freeze_appearance``."""
+    trans) on the autograd graph of every parameter (``model.freeze_appearance = True`` keeps the image encoder out)."""
     from . import torch_ops
     from .plan import BatchPlan
-    if not getattr(model, 'freeze_appearance', False):
-        raise NotImplementedError('the training mode of the VGG trunk (batch-statistics BatchNorm2d) and its backward are not '
-                                  'built: set model.freeze_appearance = True to train PointNet + fusion + w_det + w_link on '
-                                  'frozen eval-mode image features')
     fc = [int(d.item()) if torch.is_tensor(d) else int(d) for d in dets_split]
     ps = det_info['points_split'].reshape(-1).detach().to('cpu').numpy().astype(np.int64)
     points = det_info['points']
@@ -309,14 +305,19 @@ def forward_train(model, dets, det_info, dets_split):
     S = int(dets.shape[-1])
     plan = BatchPlan([(fc, ps)], S, points.device, rows=(0, 1, 2), use_points=True)
     eng = _current_engine(model)
-    with torch.no_grad():
-        if eng.ops.name == 'hip':
-            img = torch.ops.mmmot.appearance(dets.contiguous(), torch_ops.engine_handle(eng), torch_ops.plan_handle(plan))
-        else:  # an injected backend (tests: the torch emulation of the C-ABI)
-            eng.dev = dets.device
-            cat0 = eng.buf('cat', plan.Lt, 1024)
-            eng.appearance(plan, dets.contiguous(), cat0)
-            img = cat0[:, :512].clone()
+    if not getattr(model, 'freeze_appearance', False):
+        from .train_vgg import appearance_autograd
+        img = appearance_autograd(model, plan, dets)   # training-mode trunk: batch-statistics BatchNorm2d, differentiable
+    else:                                              # frozen image branch: the eval-mode (folded) inference trunk
+        with torch.no_grad():
+            if eng.ops.name == 'hip':
+                img = torch.ops.mmmot.appearance(dets.contiguous(), torch_ops.engine_handle(eng),
+                                                 torch_ops.plan_handle(plan))
+            else:  # an injected backend (tests: the torch emulation of the C-ABI)
+                eng.dev = dets.device
+                cat0 = eng.buf('cat', plan.Lt, 1024)
+                eng.appearance(plan, dets.contiguous(), cat0)
+                img = cat0[:, :512].clone()
     pts_feat, trans = pointnet_autograd(model, plan, points)
     cat = torch.cat([img, pts_feat], dim=1)
     det, link, new, end = head_autograd(model, plan, cat)

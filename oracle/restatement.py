@@ -29,9 +29,10 @@ def _gn(x, sd, key, groups):
     return F.group_norm(x, groups, sd[key + '.weight'], sd[key + '.bias'], EPS)
 
 
-def vgg_stage(x, sd, stage):
+def vgg_stage(x, sd, stage, training=False):
     """One regrouped VGG16-BN stage: reference modules/appear_net.py:130-157 (regrouping),
-    modules/vgg.py:67-80 (conv3x3 pad1 -> BatchNorm2d(eval) -> ReLU, 'M' = MaxPool 2x2)."""
+    modules/vgg.py:67-80 (conv3x3 pad1 -> BatchNorm2d -> ReLU, 'M' = MaxPool 2x2).  ``training``: BatchNorm2d on the
+    statistics of the batch (the module under .train(), tracking_model.py:41-48) instead of the running buffers."""
     layout = {0: [64, 64, 'M', 128, 128, 'M'], 1: [256, 256, 256, 'M'], 2: [512, 512, 512, 'M'],
               3: [512, 512, 512, 'M']}[stage]
     p = 'appearance.layers.%d.' % stage
@@ -43,8 +44,11 @@ def vgg_stage(x, sd, stage):
         else:
             x = F.conv2d(x, sd[p + '%d.weight' % idx], sd[p + '%d.bias' % idx], padding=1)
             b = p + '%d.' % (idx + 1)
-            x = F.batch_norm(x, sd[b + 'running_mean'], sd[b + 'running_var'], sd[b + 'weight'], sd[b + 'bias'],
-                             False, 0.0, EPS)
+            if training:
+                x = F.batch_norm(x, None, None, sd[b + 'weight'], sd[b + 'bias'], True, 0.0, EPS)
+            else:
+                x = F.batch_norm(x, sd[b + 'running_mean'], sd[b + 'running_var'], sd[b + 'weight'], sd[b + 'bias'],
+                                 False, 0.0, EPS)
             x = F.relu(x)
             idx += 3
     return x
@@ -62,12 +66,12 @@ def skippool(x, sd, stage):
     return o.flatten(1)
 
 
-def appearance(crops, sd, keep=None):
+def appearance(crops, sd, keep=None, training=False):
     """reference modules/appear_net.py:166-190 (vgg + skippool path): L x 3 x S x S -> L x 512."""
     outs = []
     x = crops
     for s in range(4):
-        x = vgg_stage(x, sd, s)
+        x = vgg_stage(x, sd, s, training)
         if keep is not None:
             keep['vgg_stage%d' % s] = x
         outs.append(skippool(x, sd, s))
@@ -248,11 +252,13 @@ def det_head_train(feats, sd):
     return F.conv1d(x, sd['w_det.6.weight'], sd['w_det.6.bias']).squeeze(1)
 
 
-def tracking_forward_train(sd, cfg, img_feats, points, points_split, dets_split):
-    """Training-mode ``TrackingNet.forward`` (reference modules/tracking_net.py:165-193 with ``self.training``) from
-    GIVEN image features ``img_feats`` L x 512 (the product trains on frozen eval-mode image features - the oracle's
-    ``appearance()`` of the crops): PointNet (GroupNorm only: identical in both modes), fusion, training-mode w_det,
-    the pairwise block; new / end scores are NOT padded in training mode (:190-192)."""
+def tracking_forward_train(sd, cfg, img_feats, points, points_split, dets_split, crops=None):
+    """Training-mode ``TrackingNet.forward`` (reference modules/tracking_net.py:165-193 with ``self.training``): image
+    encoder in training mode on ``crops`` (batch-statistics BatchNorm2d), or - ``crops`` None - GIVEN image features
+    ``img_feats`` L x 512 (the product's frozen-image-branch mode); PointNet (GroupNorm only: identical in both modes),
+    fusion, training-mode w_det, the pairwise block; new / end scores are NOT padded in training mode (:190-192)."""
+    if crops is not None:
+        img_feats = appearance(crops, sd, training=True)
     split = points_split.reshape(-1).long()
     pts, trans = pointnet(points.transpose(-1, -2), split, sd)
     cat = torch.cat([img_feats, pts], dim=-1).t().unsqueeze(0)

@@ -418,6 +418,61 @@ class TorchOps:
         x = torch.relu(ln(x @ hd['w4'].to(self.dtype).t() + hd['c4'].to(self.dtype), hd['g5'], hd['b5']))
         out[:R, :128] = x.to(out.dtype)
 
+    # ---- training step, third slice (csrc/train_vgg.hip, conv3x3.hip RAW) ----
+    def conv3x3_raw(self, inp, wp, bias, out, L, H, W, Cin, Cout, first):
+        F = torch.nn.functional
+        if first:
+            x = inp.reshape(L, 3, H, W)
+            w = wp[:, :27].reshape(Cout, 3, 3, 3).permute(0, 3, 1, 2)
+        else:
+            x = inp.reshape(-1)[:L * H * W * Cin].view(L, H, W, Cin).permute(0, 3, 1, 2)
+            w = wp.view(3, 3, Cout, Cin).permute(2, 3, 0, 1)
+        y = F.conv2d(x.to(self.dtype), w.to(self.dtype), bias.to(self.dtype), padding=1)
+        out.reshape(-1)[:L * H * W * Cout].view(L, H, W, Cout).copy_(y.permute(0, 2, 3, 1).to(out.dtype))
+
+    def rows_stats(self, Y, C, tiles, part):
+        for t in range(tiles.T):
+            r0, n = int(tiles.h_row0[t]), int(tiles.h_nrows[t])
+            y = Y[r0:r0 + n, :C].to(self.dtype)
+            part[t, 0, :C] = y.sum(0).to(part.dtype)
+            part[t, 1, :C] = ((y - y.mean(0, keepdim=True)) ** 2).sum(0).to(part.dtype)
+
+    def bn_relu_pool(self, Z, C, sc, sh, L, H, W, pool, A):
+        a = torch.relu(Z.reshape(-1)[:L * H * W * C].view(L, H, W, C).to(self.dtype) * sc.reshape(-1)[:C].to(self.dtype) +
+                       sh.reshape(-1)[:C].to(self.dtype))
+        if pool:
+            a = torch.nn.functional.max_pool2d(a.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+        A.reshape(-1)[:a.numel()].view(a.shape).copy_(a.to(A.dtype))
+
+    def maxpool_bwd(self, Z, C, sc, sh, dP, L, H, W, dA):
+        with torch.enable_grad():
+            a = torch.relu(Z.reshape(-1)[:L * H * W * C].view(L, H, W, C).to(torch.float64) * sc.reshape(-1)[:C].double() +
+                           sh.reshape(-1)[:C].double()).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+            p = torch.nn.functional.max_pool2d(a, 2, 2)
+            g = dP.reshape(-1)[:p.numel()].view(L, H // 2, W // 2, C).permute(0, 3, 1, 2).double()
+            (ga,) = torch.autograd.grad(p, a, g)
+        dA.reshape(-1)[:L * H * W * C].view(L, H, W, C).copy_(ga.permute(0, 2, 3, 1).to(dA.dtype))
+
+    def conv3x3_wgrad(self, dZ, A, L, H, W, Cin, Cout, nsplit, dW):
+        with torch.enable_grad():
+            w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+            x = A.reshape(-1)[:L * H * W * Cin].view(L, H, W, Cin).permute(0, 3, 1, 2).double()
+            y = torch.nn.functional.conv2d(x, w, None, padding=1)
+            g = dZ.reshape(-1)[:L * H * W * Cout].view(L, H, W, Cout).permute(0, 3, 1, 2).double()
+            (gw,) = torch.autograd.grad(y, w, g)
+        dW.zero_()
+        dW.reshape(nsplit, 9, Cout, Cin)[0] = gw.permute(2, 3, 0, 1).reshape(9, Cout, Cin).to(dW.dtype)
+
+    def conv3x3_first_wgrad(self, dZ, X, L, H, W, PW):
+        with torch.enable_grad():
+            w = torch.zeros(64, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+            y = torch.nn.functional.conv2d(X.reshape(L, 3, H, W).double(), w, None, padding=1)
+            g = dZ.reshape(-1)[:L * H * W * 64].view(L, H, W, 64).permute(0, 3, 1, 2).double()
+            (gw,) = torch.autograd.grad(y, w, g)
+        PW.zero_()
+        PW[0].view(64, 28)[:, :27] = gw.permute(0, 2, 3, 1).reshape(64, 27).to(PW.dtype)  # k = (ky*3+kx)*3 + colour
+        PW[0].view(64, 28)[:, 27] = g.sum(dim=(0, 2, 3)).to(PW.dtype)
+
     # ---- training step, second slice (csrc/train.hip) ----
     def rows_gather_scale(self, S, rowidx, scale, X, C):
         idx = rowidx.long()

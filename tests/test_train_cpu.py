@@ -130,10 +130,8 @@ def test_one_sgd_step_matches_the_oracle(name):
     cfg = dict(fusion=c['fusion'], affinity_op=c['aff'], softmax_mode=c['sm'])
     lr = 0.05
     ref_loss, ref_params, ref_scores = sgd_step_reference(m, cfg, kw, dets, info, ds, gts, lr)
-    with pytest.raises(NotImplementedError):
-        m.train()
-        m(dets, info, ds)                    # opt-in required: the image branch is frozen
-    m.freeze_appearance = True
+    m.train()
+    m.freeze_appearance = True               # this test: PointNet + head on frozen eval-mode image features
     crit = TrackingLoss(**kw)
     crit.ops = TorchOps()
     opt = torch.optim.SGD(m.parameters(), lr=lr)

@@ -1,0 +1,117 @@
+"""Training-mode image encoder (mmmot_amd/train_vgg.py) on the torch emulation of the C-ABI: features and every
+``appearance.*`` gradient against torch.autograd through the oracle's training-mode trunk (float64), the BatchNorm2d
+buffer updates against torch's, and one SGD step on the WHOLE network against the oracle's.  tests/test_train_vgg_gpu.py
+runs the same through the HIP kernels."""
+import pytest
+import torch
+
+from common import build_model, case_inputs, get_case
+from fake_ops import TorchOps
+from mmmot_amd import TrackingLoss
+from mmmot_amd.train_vgg import appearance_autograd
+from oracle import restatement as R
+from test_train_cpu import make_gts
+
+
+def oracle_leaves(model, prefixes, dtype=torch.float64):
+    train = {k for k, p in model.named_parameters() if p.requires_grad and k.startswith(prefixes)}
+    return {k: (v.detach().to(dtype).clone().requires_grad_(k in train) if v.dtype.is_floating_point else v.detach().clone())
+            for k, v in model.state_dict().items()}
+
+
+def check_grads(model, sd, prefix, rtol=3e-4):
+    gmax = max(v.grad.abs().max().item() for k, v in sd.items() if k.startswith(prefix) and v.grad is not None)
+    seen, worst = 0, 0.0
+    for k, p in model.named_parameters():
+        if not k.startswith(prefix):
+            continue
+        ref = sd[k].grad
+        assert ref is not None and p.grad is not None, k
+        seen += 1
+        err = (p.grad.detach().cpu().double() - ref).abs().max().item()
+        assert err < rtol * ref.abs().max().item() + 3e-6 * (1.0 + gmax), (k, err, ref.abs().max().item())
+        worst = max(worst, err / (ref.abs().max().item() + 1e-12))
+    return seen, worst
+
+
+# The emulation runs every operator in float64 here (tensors between operators stay fp32): the schedule, the tape and the
+# gradient algebra must then agree with float64 autograd to ~1e-6.  In fp32 (the device) the same comparison is limited by
+# the non-differentiable points of the network, not by arithmetic: with 2x2 .. 4x4 feature maps and a dozen crops a
+# max-pool argmax or a ReLU sign that differs between fp32 and float64 in ONE window moves a gradient tensor by 1e-2
+# (measured: conv1_1 .. conv4_2 1e-3 .. 1e-2, conv4_3 .. conv5_3 1e-5 in the same run) - test_train_vgg_gpu.py bounds that.
+@pytest.mark.parametrize('name', ['s2_C_multiply_none', 's8_S40_C'])
+def test_appearance_backward_matches_autograd_through_the_oracle(name):
+    c, base = get_case(name)
+    m = build_model(c, base, ops=TorchOps(torch.float64))
+    m.set_trunk('f32')
+    dets, info, ds = case_inputs(c)
+    plan = m.make_plan([([int(d) for d in ds], None)], c['S'], rows=(0,))
+    rm0 = m.appearance.layers[1][1].running_mean.clone()
+    bn0 = m.appearance.layers[0][1]
+    rm, rv = bn0.running_mean.clone(), bn0.running_var.clone()   # the buffers before the training-mode forward
+    nb0 = int(bn0.num_batches_tracked)
+    feats = appearance_autograd(m, plan, dets)
+    w = torch.randn(feats.shape, generator=torch.Generator().manual_seed(3))
+    (feats * w).sum().backward()
+    sd = oracle_leaves(m, ('appearance.',))
+    ref = R.appearance(dets.double(), sd, training=True)
+    (ref * w.double()).sum().backward()
+    assert (feats.detach().double() - ref.detach()).abs().max().item() < 2e-5
+    seen, worst = check_grads(m, sd, 'appearance.', rtol=2e-5)
+    assert seen == 13 * 4 + 4 * 10
+    print('appearance backward %s: worst relative gradient error %.1e over %d tensors' % (name, worst, seen))
+    # running statistics: torch's training-mode BatchNorm2d momentum update on the same pre-BatchNorm tensor
+    import torch.nn.functional as Fn
+    x = Fn.conv2d(dets, m.appearance.layers[0][0].weight.detach(), m.appearance.layers[0][0].bias.detach(), padding=1)
+    Fn.batch_norm(x, rm, rv, None, None, True, 0.1, 1e-5)
+    bn = m.appearance.layers[0][1]
+    assert torch.allclose(bn.running_mean, rm, atol=1e-5) and torch.allclose(bn.running_var, rv, rtol=1e-4, atol=1e-6)
+    assert int(bn.num_batches_tracked) == nb0 + 1 and not torch.equal(m.appearance.layers[1][1].running_mean, rm0)
+
+
+def sgd_step_reference_full(model, cfg, kw, dets, info, ds, gts, lr):
+    """one SGD step on EVERY parameter through the oracle in float64 (training-mode trunk included)"""
+    sd = oracle_leaves(model, ('appearance.', 'point_net.', 'fusion_module.', 'w_det.', 'w_link.'))
+    det, links, new, end, trans = R.tracking_forward_train(sd, cfg, None, info['points'].double(), info['points_split'], ds,
+                                                           crops=dets.double())
+    gt_det, gt_link, gt_new, gt_end = gts
+    loss = R.tracking_loss([int(d) for d in ds], gt_det.double(), [g.double() for g in gt_link], gt_new.double(),
+                           gt_end.double(), det, links, new, end, trans, **kw)
+    loss.backward()
+    return loss.item(), {k: (v.detach() - lr * v.grad) for k, v in sd.items() if v.dtype.is_floating_point and v.grad is not None}
+
+
+def test_one_full_sgd_step_matches_the_oracle():
+    """tracking_model.py:50-66 end to end: training-mode forward of the whole network (batch-statistics BatchNorm in the
+    trunk and w_det) -> TrackingLoss -> backward -> SGD step; every updated parameter against the oracle's"""
+    c, base = get_case('s2_B_minus_abs_dual_add')
+    m = build_model(c, base, ops=TorchOps(torch.float64))
+    m.set_trunk('f32')
+    dets, info, ds = case_inputs(c)
+    counts = [int(d) for d in ds]
+    gts = make_gts(counts, 12)
+    kw = dict(detloss_type='bce', linkloss_type='l2', det_ratio=1.5, trans_ratio=0.001)
+    cfg = dict(fusion=c['fusion'], affinity_op=c['aff'], softmax_mode=c['sm'])
+    lr = 0.02
+    ref_loss, ref_params = sgd_step_reference_full(m, cfg, kw, dets, info, ds, gts, lr)
+    m.train()
+    crit = TrackingLoss(**kw)
+    crit.ops = TorchOps(torch.float64)
+    opt = torch.optim.SGD(m.parameters(), lr=lr)
+    det, links, new, end, trans = m(dets, info, ds)
+    loss = crit(ds, gts[0], gts[1], gts[2], gts[3], det, links, new, end, trans)
+    assert abs(loss.item() - ref_loss) < 2e-5 * max(1.0, abs(ref_loss))
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    worst, bad = 0.0, []
+    for k, p in m.named_parameters():
+        if k in ref_params:
+            ref = ref_params[k]
+            err = (p.detach().double() - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
+            worst = max(worst, err)
+            if err >= 2e-5:
+                bad.append((k, '%.1e' % err))
+    assert not bad, bad
+    assert len([k for k in ref_params if k.startswith('appearance.')]) == 92
+    print('one full SGD step: worst relative parameter difference %.2e over %d tensors' % (worst, len(ref_params)))
