@@ -128,6 +128,13 @@ int mmmot_conv3x3_bn_relu_hl16_patch(const void* in, const void* wp, const float
 int mmmot_conv1_fused_hl16(const float* crops, const void* w1, const float* bias1, float oscale1,
                            const void* w2, const float* bias2, const float* oscale2, void* out, int L, int H, int W,
                            void* stream);
+/* ABI 6: mmmot_conv1_fused_hl16 / _hq8 fed by the 8-bit crops of the resize instead of the fp32 model input (SURVEY 8f
+ * rank 3 "fuse into the first conv's loader"): crops_u8 [L][H][W][3] RGB (mmmot_crop_resize_norm's out_u8), ToTensor and
+ * Normalize - x / 255, (x - mean) / std with IEEE divisions, reference utils/build_util.py:111-112,137-142 - applied while
+ * the raw window of a tile is fetched; bit-identical to feeding the fp32 tensor.  q8 != 0: the hq8 contract (w2, out). */
+int mmmot_conv1_fused_u8(const unsigned char* crops_u8, float mean0, float mean1, float mean2, float std0, float std1,
+                         float std2, const void* w1, const float* bias1, float oscale1, const void* w2,
+                         const float* bias2, const float* oscale2, void* out, int L, int H, int W, int q8, void* stream);
 /* "hq8" arithmetic (trunk mode 'f16q8', same reference lines): the two correction terms of the hi/lo split run on
  * the fp8 matrix cores (one block-scaled K=64 MFMA), 2 instead of 3 fp16-MFMA equivalents per product.
  *   activation record per 32 channels (128 bytes, like hl16): [32 x fp16 hi | 32 x e4m3(a / 4) | 32 x e4m3((a - hi) * 512)]
@@ -411,6 +418,9 @@ int mmmot_points_scatter_batched(const float* pts, int F, int NS, int NPOLY, int
  *   mean_std [6] floats (mean rgb, std rgb)          work  N*2*S*(2+kmax) ints (scratch)
  *   out   [N][3][S][S] fp32                           out_u8 [N][S][S][3] uint8 or NULL (the resized image)
  * S <= 256. */
+/* out (fp32 model input) or out_u8 may be NULL (not both).  mmmot_u8_normalize: ToTensor + Normalize of 8-bit crops
+ * [N][S][S][3] -> fp32 [N][3][S][S] for the paths that cannot take bytes (exact-fp32 trunk, unfused first layer). */
+int mmmot_u8_normalize(const unsigned char* u8, int N, int S, const float* mean_std, float* out, void* stream);
 int mmmot_crop_resize_norm(const unsigned char* img, int H, int W, const int* boxes, int N, int S, int kmax,
                            const float* mean_std, int* work, float* out, unsigned char* out_u8, void* stream);
 

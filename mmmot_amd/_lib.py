@@ -91,6 +91,9 @@ SIGNATURES = {
     'mmmot_conv3x3_bn_relu_hl16_patch': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f],
     'mmmot_conv1_fused_hl16': [c_f, c_f, c_f, ctypes.c_float, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f],
     'mmmot_conv3x3_bn_relu_hq8': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f],
+    'mmmot_conv1_fused_u8': [c_f, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                             ctypes.c_float, c_f, c_f, ctypes.c_float, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
+    'mmmot_u8_normalize': [c_f, c_i, c_i, c_f, c_f, c_f],
     'mmmot_conv1_fused_hq8': [c_f, c_f, c_f, ctypes.c_float, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f],
     'mmmot_conv3x3_first_hl16': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
     'mmmot_set_patch_grid_limit': [c_i],

@@ -169,10 +169,15 @@ __device__ __forceinline__ void pt_row_to_pixel(int g, int i, int& blk, int& y, 
 // (Cin = 64 = both 32-channel slabs).  The [L][H][W][64] conv1_1 tensor (537 MB per cfg3 pair: written once,
 // read 1.3x) never exists.  Requires BN = 64, BS = 16, Cin = Cout = 64.
 struct Fuse1Args {
-  const float* raw;    // crops, NCHW fp32 [L][3][H][W]
+  const float* raw;    // crops, NCHW fp32 [L][3][H][W] (normalised: the reference's `dets`), or
   const u32x4* w1;     // conv1_1 weights, hl16 [64][32] (k = tap*3 + colour, zero for k >= 27), scaled by 2^shift
   const float* bias1;  // [64] folded BN bias
   float oscale1;       // 2^-shift
+  // raw8 != nullptr: the crops arrive as the 8-bit RGB images of the resize, [L][H][W][3] (what PIL hands to
+  // torchvision), and ToTensor / Normalize (x / 255, (x - mean) / std: IEEE divisions, utils/build_util.py:111-112) are
+  // applied while the raw window is fetched - the fp32 crop tensor (77 MB per 128 detections at 224 x 224) never exists
+  const unsigned char* raw8;
+  float mean[3], stdv[3];
 };
 
 // Q8 ("hq8" arithmetic and storage): the two CORRECTION terms of the hi/lo split run on the fp8 matrix cores.
@@ -290,8 +295,14 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
       const int wy = rem / 20, wx = rem - wy * 20;
       const int gy = by * 16 - 2 + wy, gx = bx * 16 - 2 + wx;
       float v = 0.f;
-      if (i < 1200 && mtile < nblk && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
-        v = fz.raw[(((long)crop * 3 + c) * H + gy) * W + gx];
+      if (i < 1200 && mtile < nblk && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+        if (fz.raw8) {
+          const float x = __fdiv_rn((float)fz.raw8[(((long)crop * H + gy) * W + gx) * 3 + c], 255.f);  // ToTensor
+          v = __fdiv_rn(__fsub_rn(x, fz.mean[c]), fz.stdv[c]);                                          // Normalize
+        } else {
+          v = fz.raw[(((long)crop * 3 + c) * H + gy) * W + gx];
+        }
+      }
       rawv[k] = v;
     }
   };
@@ -1152,7 +1163,7 @@ static bool pt_use_bn64(int L, int H, int W, int Cout) {
 
 template <int BN, int BS, bool POOL, int EXP, bool FUSE1 = false, bool Q8 = false>
 static int launch_patch_e(const void* in, const void* wp, const float* bias, void* out, int L, int H, int W, int Cin,
-                        int Cout, const float* oscale, hipStream_t s, Fuse1Args fz = Fuse1Args{nullptr, nullptr, nullptr, 1.f}) {
+                        int Cout, const float* oscale, hipStream_t s, Fuse1Args fz = Fuse1Args{nullptr, nullptr, nullptr, 1.f, nullptr, {0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}}) {
   const int nby = (H + BS - 1) / BS, nbx = (W + BS - 1) / BS;
   const int nblk = L * nby * nbx;
   constexpr int NB = PatchGeom<BS>::NB;
@@ -1225,7 +1236,22 @@ extern "C" int mmmot_conv1_fused_hl16(const float* crops, const void* w1, const 
   hipStream_t s = (hipStream_t)stream;
   if (!crops || !w1 || !bias1 || !w2 || !bias2 || !oscale2 || !out || L <= 0 || H <= 0 || W <= 0) return MMMOT_EINVAL;
   if ((H & 1) || (W & 1) || !mm_al16(w1) || !mm_al16(w2) || !mm_al16(out)) return MMMOT_EINVAL;
-  Fuse1Args fz{crops, (const u32x4*)w1, bias1, oscale1};
+  Fuse1Args fz{crops, (const u32x4*)w1, bias1, oscale1, nullptr, {0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}};
+  return launch_patch_e<64, 16, true, 0, true>(nullptr, w2, bias2, out, L, H, W, 64, 64, oscale2, s, fz);
+}
+
+// The same launch fed by the 8-bit crops [L][H][W][3] (RGB) of the resize: ToTensor + Normalize in the loader (mean / std
+// by value; q8 != 0: conv1_2 in hq8 arithmetic, w2 / out hq8 - mmmot_conv1_fused_hq8's contract).
+extern "C" int mmmot_conv1_fused_u8(const unsigned char* crops_u8, float mean0, float mean1, float mean2, float std0,
+                                    float std1, float std2, const void* w1, const float* bias1, float oscale1,
+                                    const void* w2, const float* bias2, const float* oscale2, void* out, int L, int H,
+                                    int W, int q8, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!crops_u8 || !w1 || !bias1 || !w2 || !bias2 || !oscale2 || !out || L <= 0 || H <= 0 || W <= 0) return MMMOT_EINVAL;
+  if ((H & 1) || (W & 1) || !mm_al16(w1) || !mm_al16(w2) || !mm_al16(out)) return MMMOT_EINVAL;
+  if (!(std0 != 0.f) || !(std1 != 0.f) || !(std2 != 0.f)) return MMMOT_EINVAL;
+  Fuse1Args fz{nullptr, (const u32x4*)w1, bias1, oscale1, crops_u8, {mean0, mean1, mean2}, {std0, std1, std2}};
+  if (q8) return launch_patch_e<64, 16, true, 0, true, true>(nullptr, w2, bias2, out, L, H, W, 64, 64, oscale2, s, fz);
   return launch_patch_e<64, 16, true, 0, true>(nullptr, w2, bias2, out, L, H, W, 64, 64, oscale2, s, fz);
 }
 
@@ -1269,7 +1295,7 @@ extern "C" int mmmot_conv1_fused_hq8(const float* crops, const void* w1, const f
   hipStream_t s = (hipStream_t)stream;
   if (!crops || !w1 || !bias1 || !w2 || !bias2 || !oscale2 || !out || L <= 0 || H <= 0 || W <= 0) return MMMOT_EINVAL;
   if ((H & 1) || (W & 1) || !mm_al16(w1) || !mm_al16(w2) || !mm_al16(out)) return MMMOT_EINVAL;
-  Fuse1Args fz{crops, (const u32x4*)w1, bias1, oscale1};
+  Fuse1Args fz{crops, (const u32x4*)w1, bias1, oscale1, nullptr, {0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}};
 #ifdef MMMOT_DEBUG
   if (g_patch_exp == 4) return launch_patch_e<64, 16, true, 4, true, true>(nullptr, w2, bias2, out, L, H, W, 64, 64, oscale2, s, fz);
   if (g_patch_exp == 6) return launch_patch_e<64, 16, true, 6, true, true>(nullptr, w2, bias2, out, L, H, W, 64, 64, oscale2, s, fz);

@@ -104,8 +104,10 @@ __global__ __launch_bounds__(256) void cr_resize_kernel(const unsigned char* __r
   for (int c = 0; c < 3; ++c) {
     const int v8 = cr_clip8(acc[c]);
     if (out_u8) out_u8[(((long)n * S + oy) * S + ox) * 3 + c] = (unsigned char)v8;
-    const float x = __fdiv_rn((float)v8, 255.f);                       // to_tensor
-    out[(((long)n * 3 + c) * S + oy) * S + ox] = __fdiv_rn(__fsub_rn(x, ms[c]), ms[3 + c]);  // normalize
+    if (out) {
+      const float x = __fdiv_rn((float)v8, 255.f);                       // to_tensor
+      out[(((long)n * 3 + c) * S + oy) * S + ox] = __fdiv_rn(__fsub_rn(x, ms[c]), ms[3 + c]);  // normalize
+    }
   }
 }
 
@@ -113,10 +115,33 @@ extern "C" int mmmot_crop_resize_norm(const unsigned char* img, int H, int W, co
                                       const float* mean_std, int* work, float* out, unsigned char* out_u8,
                                       void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (!img || !boxes || !mean_std || !work || !out || H <= 0 || W <= 0 || N <= 0) return MMMOT_EINVAL;
+  if (!img || !boxes || !mean_std || !work || (!out && !out_u8) || H <= 0 || W <= 0 || N <= 0) return MMMOT_EINVAL;
   if (S <= 0 || S > 256 || kmax < 3) return MMMOT_EINVAL;
   hipLaunchKernelGGL(cr_coeff_kernel, dim3(N, 2, (S + 63) / 64), dim3(64), 0, s, boxes, S, kmax, work);
   hipLaunchKernelGGL(cr_resize_kernel, dim3(N, S), dim3(256), 0, s, img, H, W, boxes, S, kmax, work, mean_std, out,
                      out_u8);
+  return mm_check(hipGetLastError());
+}
+
+// ToTensor + Normalize of 8-bit crops [N][S][S][3] -> fp32 [N][3][S][S] (the same IEEE divisions as cr_resize_kernel):
+// the model input for the paths that cannot take the bytes directly (exact-fp32 trunk, unfused first layer).
+__global__ __launch_bounds__(256) void cr_u8_normalize_kernel(const unsigned char* __restrict__ u8, long npix, int S2,
+                                                               const float* __restrict__ ms, float* __restrict__ out) {
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
+    const long n = p / S2;
+    const int r = (int)(p - n * S2);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float x = __fdiv_rn((float)u8[p * 3 + c], 255.f);
+      out[(n * 3 + c) * S2 + r] = __fdiv_rn(__fsub_rn(x, ms[c]), ms[3 + c]);
+    }
+  }
+}
+
+extern "C" int mmmot_u8_normalize(const unsigned char* u8, int N, int S, const float* mean_std, float* out, void* stream) {
+  if (!u8 || !mean_std || !out || N <= 0 || S <= 0) return MMMOT_EINVAL;
+  const long npix = (long)N * S * S;
+  const int grid = (int)((npix + 255) / 256 < 8192 ? (npix + 255) / 256 : 8192);
+  hipLaunchKernelGGL(cr_u8_normalize_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, u8, npix, S * S, mean_std, out);
   return mm_check(hipGetLastError());
 }

@@ -159,6 +159,7 @@ class Engine:
             raise ValueError('%d crops of %dx%d in one launch sequence exceed the 32-bit piece offsets of the trunk kernels '
                              '(L*S*S*16 < 2^31): split the batch' % (Lt, S, S))
         x, H, W = crops, S, S
+        u8 = crops.dtype == torch.uint8  # the 8-bit crops of the resize [Lt][S][S][3]: ToTensor + Normalize on the device
         # q8: activations travel as hq8 records (fp16 hi + two e4m3 copies, same bytes)
         q8 = (self.trunk == 'f16q8') and S >= self.q8_min_crop
         f16 = self.trunk in ('f16x3', 'f16q8')  # activations travel in the hl16 split-half / hq8 format (same bytes)
@@ -167,6 +168,12 @@ class Engine:
         fuse1 = (f16 and self.fuse_conv1 and len(vgg) > 1 and vgg[0]['cout'] == 64 and
                  vgg[1]['cin'] == 64 and vgg[1]['cout'] == 64 and vgg[1]['pool'] and not vgg[0]['last'] and
                  not vgg[0]['pool'])
+        if u8 and not fuse1:
+            # exact-fp32 trunk / unfused first layer: they read the fp32 model input - made here from the bytes with the
+            # same IEEE arithmetic as the host pipeline (one small kernel; the fused first launch takes the bytes itself)
+            x = self.buf('vgg_crops32', Lt, 3, S, S)
+            ops.u8_normalize(crops, self._mean_std(crops.device), x, Lt, S)
+            u8 = False
         fmt = 'raw'  # format of x: 'raw' NCHW crops, 'f32' NHWC fp32, 'hl16', 'hq8' (same bytes per value)
         for li, cv in enumerate(vgg):
             if fuse1 and li == 0:
@@ -189,7 +196,11 @@ class Engine:
                 e0.record()
             if fuse1 and li == 1:
                 c0 = vgg[0]
-                if lq8:
+                if u8:
+                    from .crops import MEAN, STD
+                    ops.conv1_fused_u8(x, MEAN, STD, c0['wp16'], c0['bias'], c0['oscale'], cv['wpq8'] if lq8 else cv['wp16'],
+                                       cv['bias'], cv['oscale'], out, Lt, H, W, q8=lq8)
+                elif lq8:
                     ops.conv1_fused_hq8(x, c0['wp16'], c0['bias'], c0['oscale'], cv['wpq8'], cv['bias'], cv['oscale'],
                                         out, Lt, H, W)
                 else:
@@ -222,6 +233,13 @@ class Engine:
             if cv['last']:
                 self._stash('vgg_stage%d' % cv['stage'], x)
                 self._skippool(plan, cv['stage'], x, H * W, cv['cout'], cat, hl16={'hq8': 2, 'hl16': 1, 'f32': 0}[fmt])
+
+    def _mean_std(self, dev):
+        key = ('mean_std', str(dev))
+        if key not in self.ws:
+            from .crops import MEAN, STD
+            self.ws[key] = torch.tensor(list(MEAN) + list(STD), dtype=torch.float32, device=dev)
+        return self.ws[key]
 
     def trunk_elements(self, plan):
         """activation elements the trunk writes per forward (the denominator of the range guard's fractions)"""
@@ -589,8 +607,12 @@ class Engine:
         self.dev = dev
         Lt = plan.Lt
         cat = self.buf('cat', Lt, 1024)
-        if need_img and (crops is None or tuple(crops.shape) != (Lt, 3, plan.S, plan.S) or not crops.is_contiguous()):
-            raise ValueError('crops must be a contiguous [%d,3,%d,%d] tensor' % (Lt, plan.S, plan.S))
+        if need_img:
+            ok_f32 = crops is not None and crops.dtype == torch.float32 and tuple(crops.shape) == (Lt, 3, plan.S, plan.S)
+            ok_u8 = crops is not None and crops.dtype == torch.uint8 and tuple(crops.shape) == (Lt, plan.S, plan.S, 3)
+            if not (ok_f32 or ok_u8) or not crops.is_contiguous():
+                raise ValueError('crops must be a contiguous fp32 [%d,3,%d,%d] tensor (the reference\'s normalised `dets`) or '
+                                 'the uint8 [%d,%d,%d,3] crops of the resize' % (Lt, plan.S, plan.S, Lt, plan.S, plan.S))
         if need_pts:
             kin = int(self.P['pointnet']['w1'].shape[1])  # 3 (xyz) or 4 (xyz + reflectivity)
             if points is None or tuple(points.shape) != (plan.P, kin) or not points.is_contiguous():

@@ -555,7 +555,9 @@ class TrackingNet(nn.Module):
             ps = ps_t.detach().to('cpu').numpy().astype(np.int64)  # one D2H copy (reference: 2 .item() per detection)
             points = det_info['points']
             points = points.reshape(-1, points.shape[-1]).contiguous()  # [P][3] or [P][4] (with reflectivity)
-        S = int(dets.shape[-1]) if dets is not None else 0
+        # dets: the reference's normalised fp32 [L,3,S,S] crops, or the uint8 [L,S,S,3] crops of the resize
+        # (mmmot_amd.crops.crop_resize_u8): ToTensor / Normalize then happen inside the first trunk launch
+        S = (int(dets.shape[1]) if dets.dtype == torch.uint8 else int(dets.shape[-1])) if dets is not None else 0
         dev = points.device if points is not None else dets.device
         key = (tuple(fc), None if ps is None else ps.tobytes(), S, rows, str(dev))
         plan = self._plans.get(key)

@@ -139,6 +139,18 @@ class HipOps:
                                             _ptr(bias2), _ptr(self._osv(oscale2, 64, out)), _ptr(out), L, H, W, self._stream())
         _lib.check(st, 'mmmot_conv1_fused_hq8')
 
+    def conv1_fused_u8(self, crops_u8, mean, std, w1, bias1, oscale1, w2, bias2, oscale2, out, L, H, W, q8=False):
+        """conv1_fused_hl16 / _hq8 fed by the 8-bit crops [L][H][W][3]: ToTensor + Normalize in the loader"""
+        st = self.lib.mmmot_conv1_fused_u8(_ptr(crops_u8, torch.uint8), float(mean[0]), float(mean[1]), float(mean[2]),
+                                           float(std[0]), float(std[1]), float(std[2]), _ptr(w1), _ptr(bias1),
+                                           float(oscale1), _ptr(w2), _ptr(bias2), _ptr(self._osv(oscale2, 64, out)),
+                                           _ptr(out), L, H, W, int(bool(q8)), self._stream())
+        _lib.check(st, 'mmmot_conv1_fused_u8')
+
+    def u8_normalize(self, crops_u8, mean_std, out, N, S):
+        st = self.lib.mmmot_u8_normalize(_ptr(crops_u8, torch.uint8), N, S, _ptr(mean_std), _ptr(out), self._stream())
+        _lib.check(st, 'mmmot_u8_normalize')
+
     def trunk_range_read(self, device, reset=True):
         """(e4m3-saturated, fp16-clamped, conv1_1 hits, 0) activation-element counters of the trunk epilogues on
         ``device`` since the last reset; synchronises the current stream (see mmmot_trunk_range_read)."""

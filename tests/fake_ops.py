@@ -101,6 +101,22 @@ class TorchOps:
         self._count(2, (tmp > 65000.0).any())
         self.conv3x3_hl16_patch(to_hl16(tmp.clamp(max=65000.0)), w2, bias2, out, L, H, W, 64, 64, True, oscale2)
 
+    @staticmethod
+    def _normalize_u8(u8, mean, std):
+        """ToTensor + Normalize with the reference's fp32 operation order: [L][H][W][3] uint8 -> [L][3][H][W] fp32"""
+        x = u8.permute(0, 3, 1, 2).to(torch.float32) / 255.0
+        m = torch.tensor(list(mean), dtype=torch.float32).view(1, 3, 1, 1)
+        sd = torch.tensor(list(std), dtype=torch.float32).view(1, 3, 1, 1)
+        return ((x - m) / sd).contiguous()
+
+    def conv1_fused_u8(self, crops_u8, mean, std, w1, bias1, oscale1, w2, bias2, oscale2, out, L, H, W, q8=False):
+        x = self._normalize_u8(crops_u8.reshape(L, H, W, 3), mean, std)
+        (self.conv1_fused_hq8 if q8 else self.conv1_fused_hl16)(x, w1, bias1, oscale1, w2, bias2, oscale2, out, L, H, W)
+
+    def u8_normalize(self, crops_u8, mean_std, out, N, S):
+        ms = mean_std.reshape(-1).tolist()
+        out.reshape(-1)[:N * 3 * S * S].view(N, 3, S, S).copy_(self._normalize_u8(crops_u8.reshape(N, S, S, 3), ms[:3], ms[3:]))
+
     def _conv_hq8(self, x, wp, bias, L, H, W, Cin, Cout, pool, oscale):
         """the hq8 arithmetic: hi*hi + 2^-3 (a8 * w_lo8 + a_lo8 * w8), x = decoded parts (hi, a8, al8) NHWC"""
         from mmmot_amd.pack import hq8_parts

@@ -59,3 +59,33 @@ def test_properties_at_full_size():
     out3, u3 = CR.crop_resize_normalize(img, bb, S, return_u8=True)
     ref_u8, _ = O.crop_resize_normalize(img.cpu().numpy(), bb[:3], S)
     assert np.array_equal(u3[:3].cpu().numpy(), ref_u8)
+
+
+@pytest.mark.parametrize('trunk', ['f16x3', 'f16q8', 'f32'])
+def test_forward_from_uint8_crops_is_bitwise_the_forward_from_the_normalised_tensor(trunk):
+    """SURVEY 8f rank 3 as written ("fuse into the first conv's loader"): frame + boxes -> 8-bit crops
+    (mmmot_crop_resize_norm, out_u8 only) -> TrackingNet.forward; ToTensor / Normalize happen while the fused
+    conv1_1 + conv1_2 launch fetches its raw window (f32 trunk: one small kernel).  Same IEEE operations as the host
+    pipeline => the scores are bit-identical to feeding the fp32 `dets` tensor made by the same kernel."""
+    import numpy as np
+    from common import build_model, case_inputs, get_case
+    from mmmot_amd.crops import crop_resize_normalize, crop_resize_u8
+    c, base = get_case('s2_C_multiply_none')
+    m = build_model(c, base, device='cuda:0')
+    m.set_trunk(trunk)
+    _, info, ds = case_inputs(c)
+    L = sum(int(d) for d in ds)
+    g = torch.Generator().manual_seed(5)
+    frame = torch.randint(0, 256, (375, 1242, 3), generator=g, dtype=torch.uint8).cuda()
+    xy = torch.rand(L, 2, generator=g) * torch.tensor([1100.0, 300.0])
+    wh = torch.rand(L, 2, generator=g) * 120 + 20
+    bboxes = torch.cat([xy, xy + wh], 1).numpy().astype(np.float64)
+    f32, u8ref = crop_resize_normalize(frame, bboxes, size=c['S'], return_u8=True)
+    u8 = crop_resize_u8(frame, bboxes, size=c['S'])
+    assert u8.dtype == torch.uint8 and torch.equal(u8, u8ref)
+    dinfo = {k: v.cuda() for k, v in info.items()}
+    with torch.no_grad():
+        a = m(f32, dinfo, ds)
+        b = m(u8, dinfo, ds)
+    for x, y in ((a[0], b[0]), (a[1][0], b[1][0]), (a[2], b[2]), (a[3], b[3])):
+        assert torch.equal(x, y)

@@ -195,3 +195,22 @@ def test_crop_sides_follow_the_reference_pooling():
     for bad in (30, 41):
         with pytest.raises(ValueError, match='crop side'):
             m(torch.zeros(dets.shape[0], 3, bad, bad), info, ds)
+
+
+@pytest.mark.parametrize('trunk', ['f16x3', 'f32'])
+def test_uint8_crops_are_the_same_forward_as_the_normalised_tensor(trunk):
+    """the forward takes the 8-bit crops of the resize; ToTensor / Normalize then run on the device with
+    the reference's fp32 arithmetic (inside the fused first trunk launch, or as one small kernel for the fp32 trunk)"""
+    from mmmot_amd.crops import MEAN, STD
+    c, base = get_case('s2_C_multiply_none')
+    m = build_model(c, base, ops=TorchOps())
+    m.set_trunk(trunk)
+    dets, info, ds = case_inputs(c)
+    g = torch.Generator().manual_seed(1)
+    u8 = torch.randint(0, 256, (dets.shape[0], c['S'], c['S'], 3), generator=g, dtype=torch.uint8)
+    ref_in = TorchOps._normalize_u8(u8, MEAN, STD)
+    a = m(ref_in, info, ds)
+    b = m(u8, info, ds)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1][0], b[1][0]) and torch.equal(a[3], b[3])
+    with pytest.raises(ValueError, match='crops must be'):
+        m(u8.permute(0, 3, 1, 2).contiguous(), info, ds)
