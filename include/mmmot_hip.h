@@ -467,6 +467,13 @@ typedef struct mmmot_gemm_tn_args {
   float* db;                            /* [nsplit][N] or NULL                                */
 } mmmot_gemm_tn_args;
 int mmmot_gemm_tn(const mmmot_gemm_tn_args* a, void* stream);
+/* mmmot_gemm_tn on the fp16 matrix cores (3-term hi/lo split, fp32 accumulation; csrc/gemm_tn_f16.hip): same arguments
+ * and results contract (tiles of at most 128 rows).  dyamax: device pointer to max |dY| (mmmot_absmax below) - dY is
+ * scaled by the power of two that puts its maximum at 2^10 before the fp16 split (gradients of 1e-6 would otherwise sit
+ * in fp16's subnormals) and the result scaled back exactly; NULL = no scaling. */
+int mmmot_gemm_tn_f16(const mmmot_gemm_tn_args* a, const float* dyamax, void* stream);
+/* *out (one device float) = max |X[r][c]| over a [R][C] tensor with row stride ld; C % 4 == 0.  Asynchronous. */
+int mmmot_absmax(const float* X, int ld, long R, int C, float* out, void* stream);
 /* backward of the pairwise operand generation (gcn.py:6-41): side 0 accumulates d op / d a over j into
  * dF[aoff[g] + i], side 1 d op / d b over i into dF[boff[g] + j]; one workgroup per entry of (blk_group, blk_idx)
  * = every (group, i) resp. (group, j); dF is accumulated into (+=), rows of one launch are distinct. */

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.environ.get('MMMOT_LIB_PATH', os.path.join(_HERE, 'libmmmot_hip.so'))  # override: tools' timing-experiment builds
 SOURCES = ['conv3x3.hip', 'hl16_format.hip', 'conv3x3_hl16_patch.hip', 'gemm_rows.hip',
-           'gemm_ares.hip', 'gemm_wres.hip', 'pn_mlp64.hip', 'gram.hip', 'points_gather.hip', 'crop_resize.hip', 'small_kernels.hip', 'backward.hip', 'train.hip', 'train_vgg.hip']
+           'gemm_ares.hip', 'gemm_wres.hip', 'pn_mlp64.hip', 'gram.hip', 'points_gather.hip', 'crop_resize.hip', 'small_kernels.hip', 'backward.hip', 'train.hip', 'train_vgg.hip', 'gemm_tn_f16.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 HIPFLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
 
@@ -124,6 +124,8 @@ SIGNATURES = {
     'mmmot_gn_bwd_finalize': [c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f],
     'mmmot_gn_bwd_apply': [c_f, c_i, c_f, c_i, c_i, c_f, c_f, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_i, c_f, c_i, c_f],
     'mmmot_gemm_tn': [ctypes.POINTER(GemmTnArgs), c_f],
+    'mmmot_gemm_tn_f16': [ctypes.POINTER(GemmTnArgs), c_f, c_f],
+    'mmmot_absmax': [c_f, c_i, ctypes.c_long, c_i, c_f, c_f],
     'mmmot_pair_bwd': [c_f, c_i, c_f, c_i, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f],
     'mmmot_pair_expand_bwd': [c_f, c_i, c_f, c_i, c_i, c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_f],
     'mmmot_rowdot_bwd': [c_f, c_i, c_i, c_f, ctypes.c_float, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_i,

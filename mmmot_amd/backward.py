@@ -80,6 +80,23 @@ def _unit(eng, C, dev):
     return eng.ws[key]
 
 
+def dgrad_gemm(eng, W, tiles, X, Y):
+    """Y = X W for a forward weight W [N_f][K_f] (the input gradient dA_in = dY W of a 1x1 layer): the row GEMM with the
+    transposed weight, exact fp32 matrix cores.  (Not the f16x3 row GEMM: its A operand - here the GRADIENT dY, 1e-4 ..
+    1e-7 - is split into fp16 halves unscaled, i.e. into fp16's subnormals; measured: the SGD-step parity went from 2e-6
+    to > 1e-5.  The weight-gradient GEMM scales dY by its maximum first, mmmot_gemm_tn_f16.)  The transposed copy is cached
+    on the engine per (storage, version) of W, so a backward does not re-transpose an unchanged weight."""
+    Nf, Kf = int(W.shape[0]), int(W.shape[1])
+    cache = eng.__dict__.setdefault('_wt_cache', {})
+    key = (W.data_ptr(), W._version, Nf, Kf)
+    wt = cache.get(key)
+    if wt is None:
+        if len(cache) > 64:
+            cache.clear()
+        wt = cache[key] = W.detach().t().contiguous()  # data movement
+    eng.ops.gemm(wt, tiles, Kf, Nf, X=X, Y=Y)
+
+
 class _Layer:
     """One 'GEMM -> GroupNorm -> ReLU' layer on the tape: pre-norm output Y, its statistics, its parameters."""
 
@@ -186,7 +203,6 @@ def affinity_backward(eng, plan, F, t, d_link, d_new, d_end):
     aux = _aux(plan)
     Ff = F.reshape(nR * Lt, 512)
     new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-    tr = lambda name: lk[name].t().contiguous()  # transposed weight for dA_in = dY W (data movement)
     g = {}
 
     def weight_grad(name, bname, dY, tiles, N, K, **kw):
@@ -213,11 +229,11 @@ def affinity_backward(eng, plan, F, t, d_link, d_new, d_end):
     dY6, g['g7'], g['be7'] = _gn_backward(eng, plan, L7, dA6)
     weight_grad('w6', 'b6', dY6, PT, 128, 512, X=L4.Y, sc=L4.sc, sh=L4.sh, amode=A_NORM_RELU)
     dA3 = new(R, 512)
-    ops.gemm(tr('w6'), PT, 512, 128, X=dY6, Y=dA3)
+    dgrad_gemm(eng, lk['w6'], PT, dY6, dA3)
     dY3, g['g4'], g['be4'] = _gn_backward(eng, plan, L4, dA3)
     weight_grad('w3', 'b3', dY3, PT, 512, 512, X=L1.Y, sc=L1.sc, sh=L1.sh, amode=A_NORM_RELU)
     dA1 = new(R, 512)
-    ops.gemm(tr('w3'), PT, 512, 512, X=dY3, Y=dA1)
+    dgrad_gemm(eng, lk['w3'], PT, dY3, dA1)
     dYa = new(R, 1024)
     _, g['g1'], g['be1'] = _gn_backward(eng, plan, L1, dA1, out=dYa[:, 512:1024])
     # ---- new / end branch, from the scores back to dYa[:, :512] ----
@@ -229,11 +245,11 @@ def affinity_backward(eng, plan, F, t, d_link, d_new, d_end):
     dYv1, g['ng4'], g['nbe4'] = _gn_backward(eng, plan, V4, dAv1)
     weight_grad('nw3', 'nb3', dYv1, VT, 128, 512, X=V1.Y, sc=V1.sc, sh=V1.sh, amode=A_NORM_RELU)
     dAv0 = new(VT.R, 512)
-    ops.gemm(tr('nw3'), VT, 512, 128, X=dYv1, Y=dAv0)
+    dgrad_gemm(eng, lk['nw3'], VT, dYv1, dAv0)
     dYv0, g['ng1'], g['nbe1'] = _gn_backward(eng, plan, V1, dAv0)
     weight_grad('nw0', 'nb0', dYv0, VT, 512, 512, X=t['V'], amode=A_PLAIN)
     dV = new(VT.R, 512)
-    ops.gemm(tr('nw0'), VT, 512, 512, X=dYv0, Y=dV)
+    dgrad_gemm(eng, lk['nw0'], VT, dYv0, dV)
     dAne = new(R, 512)
     ops.pair_expand_bwd(dV, dAne, 512, PT, PT.g_row0, plan.pg_N, plan.pg_M, aux.vrow0)
     _, g['g_ne0'], g['be_ne0'] = _gn_backward(eng, plan, NE0, dAne, out=dYa[:, 0:512])
@@ -241,7 +257,7 @@ def affinity_backward(eng, plan, F, t, d_link, d_new, d_end):
     weight_grad('wa', 'ba', dYa, PT, 1024, 512, FA=Ff, FB=Ff, pair=t['pair'], amode=A_PAIR, pairop=t['pairop'])
     dWa, dba = g.pop('wa'), g.pop('ba')
     dX = new(R, 512)
-    ops.gemm(tr('wa'), PT, 512, 1024, X=dYa, Y=dX)
+    dgrad_gemm(eng, lk['wa'], PT, dYa, dX)
     dF = torch.zeros(nR * Lt, 512, dtype=torch.float32, device=dev)
     common = (PT.g_row0, plan.pg_N, plan.pg_M, plan.pg_aoff, plan.pg_boff)
     ops.pair_bwd(dX, Ff, dF, 512, *common, aux.a_grp, aux.a_idx, t['pairop'], 0)
@@ -314,7 +330,7 @@ def fusion_backward(eng, plan, cat, t, dF):
         dy0, out[fm + 'input_w.1.weight'], out[fm + 'input_w.1.bias'] = _gn_backward(eng, plan, L0, dF[2], relu=False)
         out[fm + 'input_w.0.weight'], out[fm + 'input_w.0.bias'] = wgrad(dy0, 512, 1024, cat)
         dconv = new(Lt, 1024)
-        ops.gemm(fu['w0'].t().contiguous(), D, 1024, 512, X=dy0, Y=dconv)
+        dgrad_gemm(eng, fu['w0'], D, dy0, dconv)
         ops.add_rows(dconv[:, 0:512], dF[0], dcat[:, 0:512], 512)
         ops.add_rows(dconv[:, 512:1024], dF[1], dcat[:, 512:1024], 512)
         return dcat, out
@@ -327,7 +343,7 @@ def fusion_backward(eng, plan, cat, t, dF):
             out[fm + names[j][1] + '.0.weight'], out[fm + names[j][1] + '.0.bias'] = wgrad(
                 dy, 512, 512, cat[:, 512 * j:512 * (j + 1)])
             dconv = new(Lt, 512)
-            ops.gemm(fu['w%d' % j].t().contiguous(), D, 512, 512, X=dy, Y=dconv)
+            dgrad_gemm(eng, fu['w%d' % j], D, dy, dconv)
             ops.add_rows(dconv, dF[j], dcat[:, 512 * j:512 * (j + 1)], 512)
         return dcat, out
     # C: gates + normalised inputs
@@ -344,7 +360,7 @@ def fusion_backward(eng, plan, cat, t, dF):
         out[fm + names[j][0] + '.0.weight'], out[fm + names[j][0] + '.0.bias'] = dW[0:512], db[0:512]
         out[fm + names[j][1] + '.0.weight'], out[fm + names[j][1] + '.0.bias'] = dW[512:1024], db[512:1024]
         dconv = new(Lt, 512)
-        ops.gemm(fu['w%d' % j].t().contiguous(), D, 512, 1024, X=DY[j], Y=dconv)
+        dgrad_gemm(eng, fu['w%d' % j], D, DY[j], dconv)
         ops.add_rows(dconv, dF[j], dcat[:, 512 * j:512 * (j + 1)], 512)
     return dcat, out
 
@@ -404,13 +420,13 @@ def det_backward(eng, model, plan, F, t, d_det):
     ops.gemm_tn(dY1, T, 256, 512, dW, db, X=D0.Y, sc=D0.sc, sh=D0.sh, amode=A_NORM_RELU)
     out['w_det.3.weight'], out['w_det.3.bias'] = dW.view(256, 512), db.view(256)
     dA0 = new(R, 512)
-    ops.gemm(_t2(wd[3].weight).t().contiguous(), T, 512, 256, X=dY1, Y=dA0)
+    dgrad_gemm(eng, _t2(wd[3].weight), T, dY1, dA0)
     dY0, out['w_det.1.weight'], out['w_det.1.bias'] = _gn_backward(eng, plan, D0, dA0)
     dW, db = new(1, 512 * 512), new(1, 512)
     ops.gemm_tn(dY0, T, 512, 512, dW, db, X=X, amode=A_PLAIN)
     out['w_det.0.weight'], out['w_det.0.bias'] = dW.view(512, 512), db.view(512)
     dF = new(R, 512)
-    ops.gemm(_t2(wd[0].weight).t().contiguous(), T, 512, 512, X=dY0, Y=dF)
+    dgrad_gemm(eng, _t2(wd[0].weight), T, dY0, dF)
     return dF.view(plan.nR, plan.Lt, 512), out
 
 

@@ -8,6 +8,7 @@ there is no fallback.
 """
 import contextlib
 import ctypes
+import os
 import threading
 
 import torch
@@ -55,6 +56,9 @@ class HipOps:
     def __init__(self):
         self.lib = _lib.load()
         self._osvecs = {}
+        self._scr = {}
+        # weight-gradient GEMMs: fp16 matrix cores with the 3-term split (default) or MMMOT_GEMM_TN=f32: exact fp32 MFMA
+        self.tn_f16 = os.environ.get('MMMOT_GEMM_TN', 'f16x3') != 'f32'
         # the stream a launch sequence was pinned to is per THREAD: two threads sharing one model, each under its own
         # torch.cuda.stream(), must not see each other's pin
         self._tls = threading.local()
@@ -66,6 +70,13 @@ class HipOps:
     @_pinned_stream.setter
     def _pinned_stream(self, v):
         self._tls.stream = v
+
+    def _scratch(self, name, n, device):
+        key = (name, n, str(device))
+        t = self._scr.get(key)
+        if t is None:
+            t = self._scr[key] = torch.empty(n, dtype=torch.float32, device=device)
+        return t
 
     def _osv(self, oscale, Cout, like):
         """The [Cout] per-output-channel scale vector of the trunk entry points; a python float (the kernel tests'
@@ -346,6 +357,12 @@ class HipOps:
             a.grp_aoff, a.grp_boff = _iptr(pair['aoff']), _iptr(pair['boff'])
         a.T, a.N, a.K, a.amode, a.pairop = tiles.T, N, K, amode, pairop
         a.dW, a.db = _ptr(dW), _ptr(db)
+        if self.tn_f16:
+            # fp16 matrix cores (3-term split), dY scaled by a power of two taken from its maximum on the device
+            amax = self._scratch('tn_amax', 1, dY.device)
+            _lib.check(self.lib.mmmot_absmax(_ptr(dY), _ld(dY), tiles.R, N, _ptr(amax), self._stream()), 'mmmot_absmax')
+            _lib.check(self.lib.mmmot_gemm_tn_f16(ctypes.byref(a), _ptr(amax), self._stream()), 'mmmot_gemm_tn_f16')
+            return
         _lib.check(self.lib.mmmot_gemm_tn(ctypes.byref(a), self._stream()), 'mmmot_gemm_tn')
 
     def pair_bwd(self, dX, F, dF, C, row0, gN, gM, aoff, boff, blk_group, blk_idx, pairop, side):

@@ -28,7 +28,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as Fn
 
-from .backward import _aux, _colsum, _current_engine, _gn_backward, _norm_layer, head_autograd
+from .backward import _aux, _colsum, _current_engine, _gn_backward, _norm_layer, dgrad_gemm, head_autograd
 from .ops import ACT_RELU, A_NORM_RELU, A_PLAIN, LOSS_KINDS
 from .plan import Segments
 
@@ -132,14 +132,13 @@ def pointnet_backward(eng, plan, points, W, t, dOut):
     dev = points.device
     aux = _paux(plan)
     new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-    tr = lambda name: W[name].t().contiguous()  # transposed weight for dA_in = dY W (data movement)
     g = {}
     p1 = t['p1']
     # ---- PointNet_v1 head: conv2 + GroupNorm(16) + ReLU over the detections (point_net.py:40) ----
     dyc2, g['gc2'], g['bec2'] = _gn_backward(eng, plan, t['c2'], dOut)
     g['wc2'], g['bc2'] = _weight_grad(eng, dyc2, D, 512, 512, X=t['seg512'], amode=A_PLAIN)
     dseg512 = new(Lt, 512)
-    ops.gemm(tr('wc2'), D, 512, 512, X=dyc2, Y=dseg512)
+    dgrad_gemm(eng, W['wc2'], D, dyc2, dseg512)
     # ---- per-detection average of relu(gn(conv1)) (point_net.py:32-39), conv1 1088 -> 512 + GroupNorm(512) ----
     dAc1 = new(Pn, 512)
     ops.rows_gather_scale(dseg512, plan.row_det, aux.inv_cnt, dAc1, 512)
@@ -149,9 +148,9 @@ def pointnet_backward(eng, plan, points, W, t, dOut):
     ops.segment_mean(dyc1, 512, aux.det_sum, ddbias, use_group=False)
     g['wc1b'], g['bc1'] = _weight_grad(eng, ddbias, D, 512, 1024, X=t['seg1024'], amode=A_PLAIN)
     dseg1024 = new(Lt, 1024)
-    ops.gemm(tr('wc1b'), D, 1024, 512, X=ddbias, Y=dseg1024)
+    dgrad_gemm(eng, W['wc1b'], D, ddbias, dseg1024)
     dA1c = new(Pn, 64)
-    ops.gemm(tr('wc1a'), T, 64, 512, X=dyc1, Y=dA1c)
+    dgrad_gemm(eng, W['wc1a'], T, dyc1, dA1c)
     # ---- PointNetfeatGN: average of relu(gn5(conv5)) back to the points, then the conv5 .. conv2 chain ----
     dA = new(Pn, 1024)
     ops.rows_gather_scale(dseg1024, plan.row_det, aux.inv_cnt, dA, 1024)
@@ -160,7 +159,7 @@ def pointnet_backward(eng, plan, points, W, t, dOut):
         dy, g['g%d' % i], g['be%d' % i] = _gn_backward(eng, plan, Li, dA)
         g['w%d' % i], g['b%d' % i] = _weight_grad(eng, dy, T, N, K, X=Lp.Y, sc=Lp.sc, sh=Lp.sh, amode=A_NORM_RELU)
         dA = new(Pn, K)
-        ops.gemm(tr('w%d' % i), T, K, N, X=dy, Y=dA)
+        dgrad_gemm(eng, W['w%d' % i], T, dy, dA)
     dA1 = new(Pn, 64)
     ops.add_rows(dA, dA1c, dA1, 64)  # relu(gn1(.)) feeds conv2 and the 64-channel skip of PointNet_v1.conv1
     dy1, g['g1'], g['be1'] = _gn_backward(eng, plan, p1, dA1)

@@ -17,7 +17,7 @@ DropBlock (``dropblock`` > 0, random; every shipped config sets 0) is not built.
 import numpy as np
 import torch
 
-from .backward import _colsum, _gn_backward, _norm_layer, det_batch_stats
+from .backward import _colsum, _gn_backward, _norm_layer, det_batch_stats, dgrad_gemm
 from .ops import ACT_NONE, ACT_RELU, A_NORM_RELU, A_PLAIN
 from .pack import VGG_STAGES
 from .plan import RowTiles, Segments
@@ -150,11 +150,11 @@ def _head_backward(eng, plan, hd, dOut, g):
     L2 = hd['L2']
     g[pre + '4.weight'], g[pre + '4.bias'] = _weight_grad(eng, dh2, T1, 128, C4, X=L2.Y, sc=L2.sc, sh=L2.sh, amode=A_NORM_RELU)
     dA1 = new(L, C4)
-    ops.gemm(hd['w4'].t().contiguous(), T1, C4, 128, X=dh2, Y=dA1)
+    dgrad_gemm(eng, hd['w4'], T1, dh2, dA1)
     dh1, g[pre + '2.weight'], g[pre + '2.bias'] = _gn_backward(eng, plan, L2, dA1)
     g[pre + '1.weight'], g[pre + '1.bias'] = _weight_grad(eng, dh1, T1, C4, C, X=hd['x0'], amode=A_PLAIN)
     dx0 = new(L, C)
-    ops.gemm(hd['w1'].t().contiguous(), T1, C, C4, X=dh1, Y=dx0)
+    dgrad_gemm(eng, hd['w1'], T1, dh1, dx0)
     dP, g[pre + '0.weight'], g[pre + '0.bias'] = _gn_backward(eng, plan, hd['L0'], dx0, relu=False)
     return dP
 
