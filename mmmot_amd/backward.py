@@ -170,7 +170,13 @@ def affinity_forward_train(eng, plan, F):
 
 def _colsum(eng, X):
     """column sums of a [rows][C] tensor (C % 4 == 0) through the strided-mean kernel with divisor 1"""
-    seg = Segments([0], [X.shape[0]], [1], [0], X.device, div=[1])
+    cache = eng.__dict__.setdefault('_colsum_segs', {})  # the one-segment table per row count: 5 small uploads saved per call
+    key = (int(X.shape[0]), str(X.device))
+    seg = cache.get(key)
+    if seg is None:
+        if len(cache) > 256:
+            cache.clear()
+        seg = cache[key] = Segments([0], [X.shape[0]], [1], [0], X.device, div=[1])
     out = torch.empty(1, X.shape[1], dtype=torch.float32, device=X.device)
     eng.ops.segment_mean(X, X.shape[1], seg, out, use_group=False)
     return out[0]
@@ -455,7 +461,8 @@ class _HeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cat, eng, model, plan, keys, *params):
         c = cat.detach().contiguous()
-        det, link, new, end, tape = head_forward_train(eng, model, plan, c)
+        with eng.fp32_mlp():
+            det, link, new, end, tape = head_forward_train(eng, model, plan, c)
         eng._last_head_tape = tape  # head_autograd reads the batch statistics from here (grad mode or not)
         ctx.eng, ctx.model, ctx.plan, ctx.tape, ctx.keys = eng, model, plan, tape, keys
         ctx.save_for_backward(cat)
@@ -511,14 +518,16 @@ def _current_engine(model):
     generations of weights."""
     eng = model.engine()
     if hasattr(model, 'head_is_current') and not model.head_is_current():
-        eng = model.refresh_head()
+        # on the device (no host packing; the fp16-split copies go stale and the training forward uses fp32 weights)
+        eng = model.refresh_head_device() if hasattr(model, 'refresh_head_device') else model.refresh_head()
     return eng
 
 
 class _AffinityFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, F, eng, plan, keys, *params):
-        link, new, end, tape = affinity_forward_train(eng, plan, F.detach().contiguous())
+        with eng.fp32_mlp():
+            link, new, end, tape = affinity_forward_train(eng, plan, F.detach().contiguous())
         ctx.eng, ctx.plan, ctx.tape, ctx.keys = eng, plan, tape, keys
         ctx.save_for_backward(F)
         ctx.shapes = [tuple(p.shape) for p in params]

@@ -11,6 +11,7 @@ chain of  GEMM(+stats epilogue) -> finalize -> next GEMM(normalise prologue).
 ``ops`` is the operator backend: ``mmmot_amd.ops.HipOps`` in the product.  The
 engine itself only allocates memory and orders launches.
 """
+import contextlib
 import os
 import threading
 import warnings
@@ -128,6 +129,16 @@ class Engine:
             self.ops.gemm(d[name + '_h16'], tiles, N, K, w_hl16=True, oscale=d[name + '_os'], **kw)
         else:
             self.ops.gemm(d[name], tiles, N, K, **kw)
+
+    @contextlib.contextmanager
+    def fp32_mlp(self):
+        """row GEMMs on the fp32 weights inside the block (the training forward: the fp16-split copies of the head are not
+        rebuilt after an optimizer step - TrackingNet.refresh_head_device)"""
+        prev, self.mlp = self.mlp, 'f32'
+        try:
+            yield
+        finally:
+            self.mlp = prev
 
     def _side_stream(self, dev):
         key = str(dev)

@@ -427,7 +427,54 @@ class TrackingNet(nn.Module):
     _HEADS = ('fusion_module', 'w_det', 'w_link')
 
     def _current_head_versions(self):
-        return tuple(v._version for k, v in self.state_dict().items() if k.split('.')[0] in self._HEADS)
+        # parameters and buffers of the three head modules, in module order (a state_dict() walk costs 15 ms)
+        out = []
+        for name in self._HEADS:
+            m = getattr(self, name)
+            out += [p._version for p in m.parameters()] + [b._version for b in m.buffers()]
+        return tuple(out)
+
+    def refresh_head_device(self):
+        """What a TRAINING step needs after ``optimizer.step()``: the fp32 packed tensors of fusion_module and w_link
+        recomputed from the live parameters ON THE DEVICE (concatenations and reshapes - no host round trip except the
+        two scalar output biases) and copied into the engine's tensors in place.  refresh_head() does the same on the
+        host in float64 and also rebuilds the fp16-split copies (0.2 s per call: 95 % of a training step, measured);
+        here those copies go stale, so the training forward runs its GEMMs on the fp32 weights (Engine.fp32_mlp) and the
+        next EVAL forward re-packs everything (``_trained_since_pack``)."""
+        eng = self.engine()
+        with torch.no_grad():
+            fm, lk = self.fusion_module, self.w_link
+            fl = lambda conv: conv.weight.detach().flatten(1)
+            fu = eng.P['fusion']
+            new = {}
+            if self.score_fusion_arch == 'A':
+                new.update(w0=fl(fm.input_w[0]), b0=fm.input_w[0].bias, g0=fm.input_w[1].weight, be0=fm.input_w[1].bias)
+            elif self.score_fusion_arch == 'B':
+                for j, m in enumerate((fm.input_p, fm.input_i)):
+                    new.update({'w%d' % j: fl(m[0]), 'b%d' % j: m[0].bias, 'g%d' % j: m[1].weight, 'be%d' % j: m[1].bias})
+            else:
+                for j, (gt, inp) in enumerate(((fm.gate_p, fm.input_p), (fm.gate_i, fm.input_i))):
+                    one, zero = torch.ones_like(inp[1].weight), torch.zeros_like(inp[1].bias)
+                    new.update({'w%d' % j: torch.cat([fl(gt[0]), fl(inp[0])], 0), 'b%d' % j: torch.cat([gt[0].bias, inp[0].bias], 0),
+                                'g%d' % j: torch.cat([one, inp[1].weight], 0), 'be%d' % j: torch.cat([zero, inp[1].bias], 0)})
+            for k, v in new.items():
+                fu[k].copy_(v.detach())
+            ne, c1, P = lk.w_new_end, lk.conv1, eng.P['w_link']
+            pairs = dict(wa=torch.cat([fl(ne.conv0[0]), fl(c1[0])], 0), ba=torch.cat([ne.conv0[0].bias, c1[0].bias], 0),
+                         g_ne0=ne.conv0[1].weight, be_ne0=ne.conv0[1].bias, g1=c1[1].weight, be1=c1[1].bias,
+                         w3=fl(c1[3]), b3=c1[3].bias, g4=c1[4].weight, be4=c1[4].bias, w6=fl(c1[6]), b6=c1[6].bias,
+                         g7=c1[7].weight, be7=c1[7].bias, w9=c1[9].weight.reshape(-1),
+                         nw0=fl(ne.conv1[0]), nb0=ne.conv1[0].bias, ng1=ne.conv1[1].weight, nbe1=ne.conv1[1].bias,
+                         nw3=fl(ne.conv1[3]), nb3=ne.conv1[3].bias, ng4=ne.conv1[4].weight, nbe4=ne.conv1[4].bias,
+                         nw6=ne.conv1[6].weight.reshape(-1))
+            for k, v in pairs.items():
+                P[k].copy_(v.detach())
+            P['b9'], P['nb6'] = float(c1[9].bias.item()), float(ne.conv1[6].bias.item())
+        eng._h16_head_stale = True
+        self._trained_since_pack = True
+        self._pack_version += 1  # a captured eval graph would replay the stale fp16-split copies
+        self._head_versions = self._current_head_versions()
+        return eng
 
     def head_is_current(self):
         """False once a head parameter / buffer was modified in place (``optimizer.step()``, the BatchNorm momentum
@@ -490,6 +537,11 @@ class TrackingNet(nn.Module):
     def forward_batch(self, plan, crops, points):
         """crops [Lt,3,S,S], points [P,3] (device, concatenated over the plan's samples).
         Returns per-sample reference-shaped tuples."""
+        if getattr(self, '_trained_since_pack', False):
+            # parameters were updated by training steps since the weights were packed: everything the inference engine
+            # holds (folded BatchNorm, fp16-split copies, folded transforms) is stale
+            self._trained_since_pack = False
+            self.invalidate()
         if self.training:
             raise NotImplementedError('forward_batch / forward_rows compute the eval-mode forward (call .eval()); the '
                                       'training-mode forward of tracking_model.py:50-66 is model(dets, det_info, dets_split) '

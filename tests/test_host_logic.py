@@ -83,13 +83,16 @@ def test_build_model_from_reference_yaml_dict():
     assert model_kwargs_from_config(common)['seq_len'] == 2
 
 
-def test_inference_only_and_no_cpu_fallback():
+def test_modes_and_no_cpu_fallback():
     c, base = get_case('s1_A_multiply_none')
     m = build_model(c, base)
-    # train() / eval() only record the flag (the reference toggles them around validation, tracking_model.py:32-48);
-    # a forward in training mode is refused
+    # train() / eval() record the flag (the reference toggles them around validation, tracking_model.py:32-48); the
+    # batched / single-modality entry points are eval-only, a training-mode forward goes to mmmot_amd/train.py - and, like
+    # every path, refuses CPU tensors with the default backend
     assert m.train() is m and m.training
     with pytest.raises(NotImplementedError):
+        m.forward_rows(*case_inputs(c), rows=(0,))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
         m(*case_inputs(c))
     assert m.eval() is m and not m.training
     # default backend = HipOps: CPU tensors must be refused, never computed on the host
