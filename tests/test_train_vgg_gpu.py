@@ -151,3 +151,39 @@ def test_one_full_sgd_step_on_the_device():
     assert len(errs) == len(ref_params) and errs[-1] < 5e-3 and errs[len(errs) // 2] < 5e-5
     for bn in (m.appearance.layers[0][1], m.w_det[1]):
         assert int(bn.num_batches_tracked) >= 1
+
+
+def test_eval_after_training_uses_the_updated_weights():
+    """train -> eval: the inference engine's packed weights (folded BatchNorm with the UPDATED running statistics,
+    fp16-split copies, folded transforms) are rebuilt after training steps; the eval forward matches the oracle's eval
+    forward on the model's current state_dict"""
+    c, base = get_case('s2_C_minus_abs_dual_add')
+    m = build_model(c, base, device=DEV)
+    dets, info, ds = case_inputs(c)
+    ddets, dinfo = dets.to(DEV), {k: v.to(DEV) for k, v in info.items()}
+    with torch.no_grad():
+        before = m(ddets, dinfo, ds)[1][0].clone()   # packs the engine from the initial weights
+    counts = [int(d) for d in ds]
+    gts = make_gts(counts, 13)
+    crit = TrackingLoss(detloss_type='bce', linkloss_type='l2', det_ratio=1.5, trans_ratio=0.001)
+    opt = torch.optim.SGD(m.parameters(), lr=0.05)
+    dg = lambda x: [t.to(DEV) for t in x] if isinstance(x, list) else x.to(DEV)
+    m.train()
+    for _ in range(2):
+        det, links, new, end, trans = m(ddets, dinfo, ds)
+        loss = crit(ds, dg(gts[0]), dg(gts[1]), dg(gts[2]), dg(gts[3]), det, links, new, end, trans)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    m.eval()
+    with torch.no_grad():
+        out = m(ddets, dinfo, ds)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    cfg = dict(fusion=c['fusion'], affinity_op=c['aff'], softmax_mode=c['sm'], neg_threshold=base['neg_threshold'],
+               score_arch=base['score_arch'])
+    with torch.no_grad():
+        ref = R.tracking_forward(sd, cfg, dets, info['points'], info['points_split'], counts)
+    err = max((out[0].cpu() - ref[0]).abs().max().item(), (out[1][0].cpu() - ref[1][0]).abs().max().item(),
+              (out[2].cpu() - ref[2]).abs().max().item(), (out[3].cpu() - ref[3]).abs().max().item())
+    assert err < 1e-3, err
+    assert (out[1][0] - before).abs().max().item() > 1e-4   # and it is not the forward of the initial weights
