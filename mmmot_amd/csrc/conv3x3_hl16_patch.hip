@@ -249,14 +249,18 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   // the raw-window offsets of the 8 k values a lane gathers are fixed too (k >= 27: offset 0 - the weight is zero
   // and the window value finite, so the gather needs no branch)
   f16x8 w1h[4], w1l[4];
+  f32x4 binit[4];  // folded conv1_1 bias / 2^-shift of this lane's 16 channels: the accumulators start from it
   int roff[8];
   if constexpr (FUSE1) {
     const int l15 = threadIdx.x & 15, kg1 = (threadIdx.x & 63) >> 4;
+    const float inv1 = 1.f / fz.oscale1;  // a power of two
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
       const u32x4* p = fz.w1 + ((mb * 16 + l15) * 4 + kg1) * 2;
       w1h[mb] = __builtin_bit_cast(f16x8, p[0]);
       w1l[mb] = __builtin_bit_cast(f16x8, p[1]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) binit[mb][r] = fz.bias1[mb * 16 + 4 * kg1 + r] * inv1;
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -612,92 +616,100 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
 #pragma unroll
     for (int k = 0; k < 3; ++k)
       if (tid + 512 * k < 1200) R[tid + 512 * k] = rawv[k];
-    if (tid < 64) R[1200 + tid] = fz.bias1[tid];
     __syncthreads();
     // ---- conv1_1 on the 324 patch pixels as C^T = W1 X^T: MFMA rows = channels, columns = pixels, so a lane
     // ends up with ONE pixel (lane & 15 of pixel tile g) and, per 16-channel block, 4 consecutive channels: their
     // hi and lo halves leave as two 8-byte LDS stores and all per-pixel work (coordinates, swizzle, image
     // mask) is done once per lane.  16-pixel tiles (16x16x32 MFMA, K = 32 in one step): 21 tiles over 8 waves =
     // at most 3 per wave (32-pixel tiles: 11 tiles, two waves' worth of work for waves 0-2 while 3-7 wait). ----
-    const float* B1 = reinterpret_cast<const float*>(smem + RAW_OFF + 4800);  // conv1_1 bias [64] (staged above)
     float c11max = 0.f;  // range guard of the conv1_1 outputs (pt_range[2])
     const int l15 = lane & 15, kg1 = lane >> 4;
-#pragma nounroll
-    for (int g = wave; g < (EXP == 8 ? 0 : 21); g += 8) {  // EXP 8: timing experiment without the conv1_1 prologue
-      const int n = g * 16 + l15;  // this lane's patch pixel
+    // Three rounds per wave (tiles wave, wave + 8, wave + 16; waves 5-7 have two), written branch-free so that the
+    // scheduler overlaps the LDS gather of round i + 1 with the matrix-core chain and the VALU epilogue of round i
+    // (two waves per SIMD hide nothing of a dependent ds_read -> cvt -> MFMA x3 -> VALU chain on their own):
+    //  * the folded bias is the INITIAL VALUE of the accumulators (binit, 16 registers for the whole kernel) - no LDS
+    //    read and no fma in the epilogue, the 2^-shift of the weights is one packed multiply;
+    //  * patch pixels outside the image (conv1_2's zero padding applies to conv1_1's OUTPUT) get 0 as the upper bound of
+    //    the ReLU / fp16-range clamp - the mask costs no instruction;
+    //  * lanes past pixel 323 (last tile) recompute pixel 323 and store the same bytes to the same place.
+    auto gather1 = [&](int g, f16x8& xh, f16x8& xl) {
+      const int n = g * 16 + l15;
       const int nc = n < 324 ? n : 323;
       const int ppy = nc / 18, ppx = nc - ppy * 18;
       const int rbase = ppy * 20 + ppx;  // window position of tap (0,0)
-      f16x8 xh, xl;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float v = R[rbase + roff[e]];
         xh[e] = (_Float16)v;
         xl[e] = (_Float16)(v - (float)xh[e]);
       }
-      f32x4 c1[4];
+    };
+    auto mma1 = [&](const f16x8& xh, const f16x8& xl, f32x4 (&c1)[4]) {
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) {
-        c1[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        c1[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1l[mb], xh, c1[mb], 0, 0, 0);
+        c1[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1l[mb], xh, binit[mb], 0, 0, 0);
         c1[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[mb], xl, c1[mb], 0, 0, 0);
         c1[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[mb], xh, c1[mb], 0, 0, 0);
       }
-      if (n < 324) {
-        // bias + ReLU; zero outside the image (conv1_2's zero padding applies to conv1_1's OUTPUT)
-        const int gy = by0 * 16 - 1 + ppy, gx = bx0 * 16 - 1 + ppx;
-        const bool inimg = (b0 < nblk) && ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
-        const int sw = pt_swz_a(ppy, ppx);
-        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-        const int hh = kg1 & 1;  // which half (4 channels) of an 8-channel unit
-        // out-of-image patch pixels exist only in tiles on a crop's border: a wave whose pixels are all inside skips
-        // the per-value select (wave-uniform branch).  (With the fmed3 below: 3 instead of 5 VALU operations per value;
-        // tools/bench_fused1.py shows no change of the launch time - the prologue's 0.12 ms per pair is not set by
-        // its VALU instruction count.)
-        const bool allin = __builtin_amdgcn_ballot_w64(!inimg) == 0;
-        auto emit = [&](auto MASKED) {
+    };
+    auto emit1 = [&](int g, const f32x4 (&c1)[4]) {
+      const int n0_ = g * 16 + l15;
+      const int n = n0_ < 324 ? n0_ : 323;
+      const int ppy = n / 18, ppx = n - ppy * 18;
+      const int gy = by0 * 16 - 1 + ppy, gx = bx0 * 16 - 1 + ppx;
+      const bool inimg = (b0 < nblk) && ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
+      const float top = inimg ? 65504.f : 0.f;  // fp16 maximum (the guard below reports anything above PT_SAT_FP16)
+      const int sw = pt_swz_a(ppy, ppx);
+      typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+      const int hh = kg1 & 1;  // which half (4 channels) of an 8-channel unit
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {  // channels 16 mb + 4 kg1 .. + 3 = slab mb >> 1, unit q, half hh
-          const int q = (mb & 1) * 2 + (kg1 >> 1);
-          const int rb = ((mb >> 1) == 0 ? pcur : pnext) + n * P_ROWB;  // this pixel's record in slab mb >> 1
-          const f32x4 bq = *reinterpret_cast<const f32x4*>(&B1[mb * 16 + 4 * kg1]);
-          f16x4 hi, lo;
-          float vv[4];
+      for (int mb = 0; mb < 4; ++mb) {  // channels 16 mb + 4 kg1 .. + 3 = slab mb >> 1, unit q, half hh
+        const int q = (mb & 1) * 2 + (kg1 >> 1);
+        const int rb = ((mb >> 1) == 0 ? pcur : pnext) + n * P_ROWB;  // this pixel's record in slab mb >> 1
+        f16x4 hi, lo;
+        float vv[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float v = fmaf(c1[mb][r], fz.oscale1, bq[r]);
-            if constexpr (decltype(MASKED)::value) {
-              if (!inimg) v = 0.f;
-            }
-            c11max = fmaxf(c11max, v);                    // c11max >= 0: same as taking the maximum after the ReLU
-            v = __builtin_amdgcn_fmed3f(v, 0.f, 65000.f);  // ReLU and the fp16 range clamp in one instruction
-            vv[r] = v;
-            hi[r] = (_Float16)v;
-            lo[r] = (_Float16)(v - (float)hi[r]);
-          }
-          if constexpr (Q8) {
-            // record = [fp16 hi: pieces 0..3 | e4m3(a/4): pieces 4,5 | e4m3(a_lo*512): pieces 6,7]
-            *reinterpret_cast<f16x4*>(smem + rb + ((q ^ sw) << 4) + 8 * hh) = hi;
-            int pa = 0, pl = 0;
-            pa = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(vv[0] * 0.25f, 448.f), fminf(vv[1] * 0.25f, 448.f), pa, false);
-            pa = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(vv[2] * 0.25f, 448.f), fminf(vv[3] * 0.25f, 448.f), pa, true);
-            float ll[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ll[r] = __builtin_amdgcn_fmed3f((vv[r] - (float)hi[r]) * 512.f, -448.f, 448.f);
-            pl = __builtin_amdgcn_cvt_pk_fp8_f32(ll[0], ll[1], pl, false);
-            pl = __builtin_amdgcn_cvt_pk_fp8_f32(ll[2], ll[3], pl, true);
-            const int bo = 8 * (q & 1) + 4 * hh;  // byte of channel 8q + 4hh inside its 16-channel piece
-            *reinterpret_cast<int*>(smem + rb + (((4 + (q >> 1)) ^ sw) << 4) + bo) = pa;
-            *reinterpret_cast<int*>(smem + rb + (((6 + (q >> 1)) ^ sw) << 4) + bo) = pl;
-          } else {
-            *reinterpret_cast<f16x4*>(smem + rb + hh * 8 + (((2 * q) ^ sw) << 4)) = hi;
-            *reinterpret_cast<f16x4*>(smem + rb + hh * 8 + (((2 * q + 1) ^ sw) << 4)) = lo;
-          }
+        for (int r = 0; r < 4; ++r) {
+          float v = c1[mb][r] * fz.oscale1;
+          v = __builtin_amdgcn_fmed3f(v, 0.f, top);  // ReLU, the fp16 range clamp and the image mask in one instruction
+          c11max = fmaxf(c11max, v);
+          vv[r] = v;
+          hi[r] = (_Float16)v;
+          lo[r] = (_Float16)(v - (float)hi[r]);
         }
-        };
-        if (allin) emit(std::false_type{});
-        else emit(std::true_type{});
+        if constexpr (Q8) {
+          // record = [fp16 hi: pieces 0..3 | e4m3(a/4): pieces 4,5 | e4m3(a_lo*512): pieces 6,7]
+          *reinterpret_cast<f16x4*>(smem + rb + ((q ^ sw) << 4) + 8 * hh) = hi;
+          int pa = 0, pl = 0;
+          pa = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(vv[0] * 0.25f, 448.f), fminf(vv[1] * 0.25f, 448.f), pa, false);
+          pa = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(vv[2] * 0.25f, 448.f), fminf(vv[3] * 0.25f, 448.f), pa, true);
+          float ll[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ll[r] = __builtin_amdgcn_fmed3f((vv[r] - (float)hi[r]) * 512.f, -448.f, 448.f);
+          pl = __builtin_amdgcn_cvt_pk_fp8_f32(ll[0], ll[1], pl, false);
+          pl = __builtin_amdgcn_cvt_pk_fp8_f32(ll[2], ll[3], pl, true);
+          const int bo = 8 * (q & 1) + 4 * hh;  // byte of channel 8q + 4hh inside its 16-channel piece
+          *reinterpret_cast<int*>(smem + rb + (((4 + (q >> 1)) ^ sw) << 4) + bo) = pa;
+          *reinterpret_cast<int*>(smem + rb + (((6 + (q >> 1)) ^ sw) << 4) + bo) = pl;
+        } else {
+          *reinterpret_cast<f16x4*>(smem + rb + hh * 8 + (((2 * q) ^ sw) << 4)) = hi;
+          *reinterpret_cast<f16x4*>(smem + rb + hh * 8 + (((2 * q + 1) ^ sw) << 4)) = lo;
+        }
       }
+    };
+    if constexpr (EXP != 8) {  // EXP 8: timing experiment without the conv1_1 prologue
+      f16x8 xh0, xl0, xh1, xl1;
+      f32x4 ca[4], cb[4];
+      gather1(wave, xh0, xl0);
+      gather1(wave + 8, xh1, xl1);
+      mma1(xh0, xl0, ca);
+      mma1(xh1, xl1, cb);
+      const bool third = wave + 16 < 21;  // wave-uniform
+      if (third) gather1(wave + 16, xh0, xl0);
+      emit1(wave, ca);
+      if (third) mma1(xh0, xl0, ca);
+      emit1(wave + 8, cb);
+      if (third) emit1(wave + 16, ca);
     }
     if (c11max > (Q8 ? PT_SAT_E4M3 : PT_SAT_FP16)) atomicAdd(&rng[2], 1u);
     pt_wait_vm<2 * NBL>();  // weight stage 0 landed (this wave's part)
