@@ -124,7 +124,9 @@ int mmmot_conv3x3_bn_relu_hl16_patch(const void* in, const void* wp, const float
  * layers 0-6 of vgg16_bn.features): the patch kernel computes conv1_1 for the haloed 18x18 patch of every tile in
  * its prologue instead of reading it, so the [L][H][W][64] tensor (537 MB per cfg3 pair) is never written.
  *   crops NCHW fp32 [L][3][H][W];  w1 hl16 [64][32] (k = (ky*3+kx)*3 + colour, zero-padded), bias1 [64], oscale1 (scalar);
- *   w2 hl16 [9][64][64], bias2 [64], oscale2 [64];  out hl16 NHWC [L][H/2][W/2][64].  H, W even. */
+ *   w2 hl16 [9][64][64], bias2 [64], oscale2 [64];  out hl16 NHWC [L][H/2][W/2][64].  H, W even.
+ *   bias1 travels through the matrix cores in the k = 27 slot of w1's records (split hi + lo like a weight):
+ *   |bias1[n]| / oscale1 must stay below 65504 (host: pack.conv1_weight_shift picks the shift for weights AND bias). */
 int mmmot_conv1_fused_hl16(const float* crops, const void* w1, const float* bias1, float oscale1,
                            const void* w2, const float* bias2, const float* oscale2, void* out, int L, int H, int W,
                            void* stream);

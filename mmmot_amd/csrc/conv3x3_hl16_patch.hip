@@ -218,19 +218,29 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   constexpr int RING0 = 2 * G::BYTES;
   constexpr int LOOP_BYTES = RING0 + 3 * B_BYTES;
   constexpr int RAW_OFF = LOOP_BYTES;                      // FUSE1: raw input window [3][20][20] fp32
-  constexpr int RAW_BYTES = FUSE1 ? 3 * 20 * 20 * 4 + 256 : 0;  // + conv1_1 bias [64]
+  constexpr int RAW_BYTES = FUSE1 ? 3 * 20 * 20 * 4 + 64 : 0;
+  constexpr bool OVL = FUSE1 && !Q8;                       // conv1_1 of the next tile under this tile's K loop (below)
   // pooled layers take the 2x2 maximum in registers (the four pixels of a window are four consecutive accumulator
   // registers of one lane: quad-ordered rows) and stage the 64 pooled rows only - one chunk
   constexpr int SROWS = POOL ? P_BM / 4 : P_BM;            // staged rows per tile
   constexpr int NCH = (FUSE1 || POOL) ? 1 : (SROWS / 2 * CLD * 4 <= G::BYTES) ? 2 : 4;
   constexpr int RCH = SROWS / NCH;                         // staged rows per epilogue chunk
-  static_assert(FUSE1 ? (SROWS * CLD * 4 <= LOOP_BYTES) : (RCH * CLD * 4 <= G::BYTES), "epilogue staging does not fit");
+  static_assert((FUSE1 && !OVL) ? (SROWS * CLD * 4 <= LOOP_BYTES) : (RCH * CLD * 4 <= G::BYTES), "epilogue staging does not fit");
   // STREAM: tiles are chained through transition slabs.  The successor's patch source table is made during the
   // tile's own prologue (low register pressure) and parked in LDS: [PA][512] words behind the ring.  The 8x8-block
   // variants have no room for it: they chain only onto a successor with the same pixel tile (same table).
   constexpr bool STREAM = !FUSE1 && G::NB == 1;
-  constexpr int POFF_OFF = LOOP_BYTES + RAW_BYTES;
-  constexpr int SMEM = POFF_OFF + (STREAM ? G::PA * 512 * 4 : 0);
+  // OVL (the f16x3 fused first layer): the conv1_1 patches of the NEXT tile are computed underneath the K loop of the
+  // current one.  A third patch buffer makes that possible: a tile reads (X, Y) = its two 32-channel slabs; while its
+  // second slab runs, the successor's first slab is written to Z and its second one to X (dead by then); the
+  // epilogue stages through Y; the successor then works on (Z, X) with Y as its third buffer.  The prologue's VALU
+  // work (conversions, ReLU, hi/lo split: ~150 instructions per 16-pixel round and wave, 3 rounds per wave and tile)
+  // is cut into MFMA-slot-sized slices and issued in the shadow of the main loop's matrix instructions.
+  constexpr int P2_OFF = (LOOP_BYTES + RAW_BYTES + 255) / 256 * 256;
+  constexpr int POFF_OFF = OVL ? P2_OFF + G::BYTES : LOOP_BYTES + RAW_BYTES;
+  // FUSE1: conv1_1 weights as MFMA A fragments [mb][lane][hi | lo] (8 KB) - read per use, not held in 32 registers
+  constexpr int W1_OFF = POFF_OFF;
+  constexpr int SMEM = POFF_OFF + (STREAM ? G::PA * 512 * 4 : 0) + (FUSE1 ? 8192 : 0);
   static_assert(SMEM <= 160 * 1024, "LDS budget");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
 
@@ -245,22 +255,29 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   // launch-time workgroup per tile would leave the CU idle for a dispatch latency between tiles: with a
   // single resident workgroup nothing overlaps it (measured: fixed cost of ~2 channel slabs per tile).
   // FUSE1: conv1_1 weight fragments (A operand of v_mfma_f32_16x16x32_f16: channel 16 mb + (lane & 15),
-  // k = 8 (lane >> 4) .. + 7 - the whole K = 32 in one step) stay in registers for the whole (persistent) kernel;
-  // the raw-window offsets of the 8 k values a lane gathers are fixed too (k >= 27: offset 0 - the weight is zero
-  // and the window value finite, so the gather needs no branch)
-  f16x8 w1h[4], w1l[4];
-  f32x4 binit[4];  // folded conv1_1 bias / 2^-shift of this lane's 16 channels: the accumulators start from it
+  // k = 8 (lane >> 4) .. + 7 - the whole K = 32 in one step) are staged in LDS once per workgroup ([W1_OFF]; read per
+  // use by the serial form; the overlapped form (OVL) keeps them in 32 registers - the K loop of this layer is bound by
+  // LDS reads, one per MFMA).  The folded bias / 2^-shift rides in the k = 27 slot of the K = 32 step (27 taps x colours
+  // padded to 32): its "window value" is the constant 1, so the matrix cores add it - no fma and no bias read in the
+  // epilogue of a round; hi + lo keep 22 bits of it like of every weight (|bias| / 2^-shift must stay below 65504:
+  // pack.conv1_weight_shift).  The raw-window offsets of the 8 k values a lane gathers are fixed (k >= 28: offset 0 -
+  // the weight is zero and the window value finite, so the gather needs no branch)
   int roff[8];
+  f16x8 w1h[4], w1l[4];  // OVL only
   if constexpr (FUSE1) {
-    const int l15 = threadIdx.x & 15, kg1 = (threadIdx.x & 63) >> 4;
-    const float inv1 = 1.f / fz.oscale1;  // a power of two
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-      const u32x4* p = fz.w1 + ((mb * 16 + l15) * 4 + kg1) * 2;
-      w1h[mb] = __builtin_bit_cast(f16x8, p[0]);
-      w1l[mb] = __builtin_bit_cast(f16x8, p[1]);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) binit[mb][r] = fz.bias1[mb * 16 + 4 * kg1 + r] * inv1;
+    const int kg1 = (threadIdx.x & 63) >> 4;
+    {
+      const int t = threadIdx.x;
+      const int mb = t >> 7, ln = (t >> 1) & 63, hl = t & 1;
+      u32x4 wv = fz.w1[((mb * 16 + (ln & 15)) * 4 + (ln >> 4)) * 2 + hl];
+      if ((ln >> 4) == 3) {  // k = 24 .. 31 of this channel: element 3 = k 27 takes the bias (the window value there is 1)
+        const float bs = fz.bias1[mb * 16 + (ln & 15)] * (1.f / fz.oscale1);  // oscale1 is a power of two
+        const _Float16 bh = (_Float16)bs;
+        const _Float16 bl = (_Float16)(bs - (float)bh);
+        const unsigned bits = (unsigned)__builtin_bit_cast(unsigned short, hl == 0 ? bh : bl);
+        wv[1] = (wv[1] & 0x0000ffffu) | (bits << 16);
+      }
+      reinterpret_cast<u32x4*>(smem + W1_OFF)[t] = wv;
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -298,15 +315,19 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
       const int c = i / 400, rem = i - c * 400;
       const int wy = rem / 20, wx = rem - wy * 20;
       const int gy = by * 16 - 2 + wy, gx = bx * 16 - 2 + wx;
-      float v = 0.f;
-      if (i < 1200 && mtile < nblk && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
-        if (fz.raw8) {
-          const float x = __fdiv_rn((float)fz.raw8[(((long)crop * H + gy) * W + gx) * 3 + c], 255.f);  // ToTensor
-          v = __fdiv_rn(__fsub_rn(x, fz.mean[c]), fz.stdv[c]);                                          // Normalize
-        } else {
-          v = fz.raw[(((long)crop * 3 + c) * H + gy) * W + gx];
-        }
+      // every wave issues exactly one load per k (invalid lanes read element 0 and select 0): the counted vmcnt waits
+      // of the overlapped prologue rely on the number of loads in flight
+      const bool ok = i < 1200 && mtile < nblk && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      float v;
+      if (fz.raw8) {
+        const long idx = ok ? (((long)crop * H + gy) * W + gx) * 3 + c : 0;
+        const float x = __fdiv_rn((float)fz.raw8[idx], 255.f);                                          // ToTensor
+        v = __fdiv_rn(__fsub_rn(x, fz.mean[ok ? c : 0]), fz.stdv[ok ? c : 0]);                          // Normalize
+      } else {
+        const long idx = ok ? (((long)crop * 3 + c) * H + gy) * W + gx : 0;
+        v = fz.raw[idx];
       }
+      if (!ok) v = 0.f;
       rawv[k] = v;
     }
   };
@@ -379,6 +400,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   bool primed = false;  // this tile's patch slab 0 and weight stages 0..2 were streamed in by the previous tile
   int pcur = P0_OFF;    // patch buffer of the current slab (byte offset in smem)
   int pnext = P1_OFF;   // patch buffer being filled for the next slab (of this tile or the next one)
+  int bufX = P0_OFF, bufY = P1_OFF, bufZ = OVL ? P2_OFF : 0;  // OVL: this tile's two slabs and the free buffer
   for (int item = blockIdx.x >> 3; item < clen; item += gridDim.x >> 3) {
   unsigned long long tprev_ = 0;
   PT_STAMP(-1)
@@ -601,12 +623,33 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
       if constexpr (G::PA > 6) pk[6 * 512] = poff_round(std::integral_constant<int, 6>{}, tb);
     }
   }
+  float c11max = 0.f;  // range guard of the conv1_1 outputs (pt_range[2])
+  // OVL: the successor's block origin (its conv1_1 patches are made under this tile's K loop) and the tile after it
+  // (whose raw window is fetched meanwhile)
+  int nx_gy0 = 0, nx_gx0 = 0;
+  bool nx_valid = false, has_next2 = false;
+  int mt_next2 = 0;
+  if constexpr (OVL) {
+    if (has_next) {
+      const int crop = mt_next / nbpc, br = mt_next - crop * nbpc;
+      const int by = br / nbx;
+      nx_gy0 = by * 16 - 1;
+      nx_gx0 = (br - by * nbx) * 16 - 1;
+      nx_valid = mt_next < nblk;
+      const int nitem2_ = nitem_ + (gridDim.x >> 3);
+      has_next2 = nitem2_ < clen;
+      int nt2_ = 0;
+      if (has_next2) decode_item(nitem2_, mt_next2, nt2_);
+    }
+    pcur = bufX;
+    pnext = bufY;
+  }
   if constexpr (FUSE1) {
-    pcur = P0_OFF;
-    pnext = P1_OFF;
-    issue_b(0, 0, 0);  // conv1_2's weight ring flies while the patch is computed
-    issue_b(1, 0, 1);
-    issue_b(2, 0, 2);
+  if (!OVL || !primed) {  // OVL: only the first tile of a workgroup computes its own patches up front
+    if constexpr (!OVL) {
+      pcur = P0_OFF;
+      pnext = P1_OFF;
+    }
     // ---- raw window: image rows by*16-2 .. +19, columns bx*16-2 .. +19 of the 3 colour planes (zero outside) ----
     float* R = reinterpret_cast<float*>(smem + RAW_OFF);
     const int b0 = mt;  // NB == 1
@@ -616,13 +659,25 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
 #pragma unroll
     for (int k = 0; k < 3; ++k)
       if (tid + 512 * k < 1200) R[tid + 512 * k] = rawv[k];
+    if constexpr (OVL) {
+      if (has_next) fetch_raw(mt_next);  // older than the ring loads below: landed when the counted wait passes
+    }
+    issue_b(0, 0, 0);  // conv1_2's weight ring flies while the patch is computed
+    issue_b(1, 0, 1);
+    issue_b(2, 0, 2);
     __syncthreads();
+    if constexpr (OVL) {  // the overlapped rounds take their weight fragments from registers
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        w1h[mb] = *reinterpret_cast<const f16x8*>(smem + W1_OFF + ((mb * 64 + lane) * 2) * 16);
+        w1l[mb] = *reinterpret_cast<const f16x8*>(smem + W1_OFF + ((mb * 64 + lane) * 2 + 1) * 16);
+      }
+    }
     // ---- conv1_1 on the 324 patch pixels as C^T = W1 X^T: MFMA rows = channels, columns = pixels, so a lane
     // ends up with ONE pixel (lane & 15 of pixel tile g) and, per 16-channel block, 4 consecutive channels: their
     // hi and lo halves leave as two 8-byte LDS stores and all per-pixel work (coordinates, swizzle, image
     // mask) is done once per lane.  16-pixel tiles (16x16x32 MFMA, K = 32 in one step): 21 tiles over 8 waves =
     // at most 3 per wave (32-pixel tiles: 11 tiles, two waves' worth of work for waves 0-2 while 3-7 wait). ----
-    float c11max = 0.f;  // range guard of the conv1_1 outputs (pt_range[2])
     const int l15 = lane & 15, kg1 = lane >> 4;
     // Three rounds per wave (tiles wave, wave + 8, wave + 16; waves 5-7 have two), written branch-free so that the
     // scheduler overlaps the LDS gather of round i + 1 with the matrix-core chain and the VALU epilogue of round i
@@ -639,7 +694,8 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
       const int rbase = ppy * 20 + ppx;  // window position of tap (0,0)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float v = R[rbase + roff[e]];
+        float v = R[rbase + roff[e]];
+        if (e == 3 && kg1 == 3) v = 1.f;  // k = 27: the bias slot
         xh[e] = (_Float16)v;
         xl[e] = (_Float16)(v - (float)xh[e]);
       }
@@ -647,9 +703,11 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     auto mma1 = [&](const f16x8& xh, const f16x8& xl, f32x4 (&c1)[4]) {
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) {
-        c1[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1l[mb], xh, binit[mb], 0, 0, 0);
-        c1[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[mb], xl, c1[mb], 0, 0, 0);
-        c1[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[mb], xh, c1[mb], 0, 0, 0);
+        const f16x8 w1h = *reinterpret_cast<const f16x8*>(smem + W1_OFF + ((mb * 64 + lane) * 2) * 16);
+        const f16x8 w1l = *reinterpret_cast<const f16x8*>(smem + W1_OFF + ((mb * 64 + lane) * 2 + 1) * 16);
+        c1[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1l, xh, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        c1[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h, xl, c1[mb], 0, 0, 0);
+        c1[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h, xh, c1[mb], 0, 0, 0);
       }
     };
     auto emit1 = [&](int g, const f32x4 (&c1)[4]) {
@@ -697,7 +755,16 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
         }
       }
     };
-    if constexpr (EXP != 8) {  // EXP 8: timing experiment without the conv1_1 prologue
+    if constexpr (OVL) {  // once per workgroup: plain rounds (the register budget belongs to the overlapped form)
+#pragma nounroll
+      for (int g = wave; g < (EXP == 8 ? 0 : 21); g += 8) {
+        f16x8 xh0, xl0;
+        f32x4 ca[4];
+        gather1(g, xh0, xl0);
+        mma1(xh0, xl0, ca);
+        emit1(g, ca);
+      }
+    } else if constexpr (EXP != 8) {  // EXP 8: timing experiment without the conv1_1 prologue
       f16x8 xh0, xl0, xh1, xl1;
       f32x4 ca[4], cb[4];
       gather1(wave, xh0, xl0);
@@ -712,8 +779,17 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
       if (third) emit1(wave + 16, ca);
     }
     if (c11max > (Q8 ? PT_SAT_E4M3 : PT_SAT_FP16)) atomicAdd(&rng[2], 1u);
+    c11max = 0.f;
     pt_wait_vm<2 * NBL>();  // weight stage 0 landed (this wave's part)
     __syncthreads();        // both patch slabs are complete
+    if constexpr (OVL) {
+      if (has_next) {  // the successor's raw window (every wave is past its gathers from the old one)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          if (tid + 512 * k < 1200) R[tid + 512 * k] = rawv[k];
+      }
+    }
+  }
   } else {
     if (!primed) {  // first tile of this workgroup
       issue_tile_head(pcur);
@@ -735,9 +811,88 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   // Transition slab (last slab of a tile that has a successor): poff = the successor's table, pslab = ws2 = 0,
   // wb2 = the successor's weights - the same code, so every counted vmcnt is the interior one.
   // MODE 1: last slab of the workgroup's last tile (nothing to prefetch).
-  auto stage = [&](auto TAPC, auto MODEC, int slab, int pslab, const u32x4* wb2, int ws2) {
+  // OVL: one 16-pixel conv1_1 round of the SUCCESSOR tile (see the serial form above) cut into 36 slices = the MFMA
+  // slots of three stages; round rr of a wave runs in stages 3 rr .. 3 rr + 2 of the current tile's second slab.
+  //   0: pixel of this lane            1-4: window gather (2 values each)     5: image mask, swizzle
+  //   6-9: hi/lo split of the gathered values (2 each)                        12-23: the 12 MFMAs (16x16x32)
+  //   15-30: one output value per slot (scale, ReLU/clamp/mask, hi/lo split), 8-byte stores after each fourth
+  // Slab 0 of the successor (channels 0-31) goes to bufZ, slab 1 to bufX (this tile's first slab: dead).
+  int pr_ppy = 0, pr_ppx = 0, pr_rbase = 0, pr_rec = 0, pr_sw = 0;
+  float pr_top = 0.f;
+  float pr_v[8];
+  f16x8 pr_xh, pr_xl;
+  f32x4 pr_c[4];
+  typedef _Float16 pr_f16x4 __attribute__((ext_vector_type(4)));
+  pr_f16x4 pr_hi, pr_lo;
+  auto pro_slot = [&](auto SC, auto RC) {
+    constexpr int sl = decltype(SC)::value;
+    constexpr int rr = decltype(RC)::value;
+    if constexpr (OVL && EXP != 8) {
+      const float* R = reinterpret_cast<const float*>(smem + RAW_OFF);
+      if constexpr (sl == 0) {
+        const int g0 = wave + 8 * rr;
+        const int g = g0 < 21 ? g0 : 20;  // waves 5-7 repeat tile 20 in their third round (same bytes, same place)
+        // laundered lane id: everything below depends on the lane only, would be hoisted out of the tile loop for all
+        // three rounds and spilled (scratch reloads with vmcnt(0) inside the K loop)
+        int lane_ = lane;
+        asm volatile("" : "+v"(lane_));
+        const int n = g * 16 + (lane_ & 15);
+        const int nc = n < 324 ? n : 323;
+        pr_ppy = nc / 18;
+        pr_ppx = nc - pr_ppy * 18;
+        pr_rbase = pr_ppy * 20 + pr_ppx;
+        pr_rec = nc * P_ROWB;
+      } else if constexpr (sl >= 1 && sl <= 4) {
+        constexpr int e = 2 * (sl - 1);
+        pr_v[e] = R[pr_rbase + roff[e]];
+        pr_v[e + 1] = R[pr_rbase + roff[e + 1]];
+        if constexpr (e + 1 == 3) {
+          if ((lane >> 4) == 3) pr_v[3] = 1.f;  // k = 27: the bias slot
+        }
+      } else if constexpr (sl == 5) {
+        const int gy = nx_gy0 + pr_ppy, gx = nx_gx0 + pr_ppx;
+        const bool inimg = nx_valid & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);  // no branches
+        pr_top = inimg ? 65504.f : 0.f;
+        pr_sw = pt_swz_a(pr_ppy, pr_ppx);
+      } else if constexpr (sl >= 6 && sl <= 9) {
+        constexpr int e = 2 * (sl - 6);
+#pragma unroll
+        for (int k = e; k < e + 2; ++k) {
+          pr_xh[k] = (_Float16)pr_v[k];
+          pr_xl[k] = (_Float16)(pr_v[k] - (float)pr_xh[k]);
+        }
+      }
+      if constexpr (sl >= 12 && sl <= 23 && EXP != 13) {  // EXP 13: timing experiment without the small MFMAs
+        constexpr int mb = (sl - 12) / 3, term = (sl - 12) % 3;
+        if constexpr (term == 0)
+          pr_c[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1l[mb], pr_xh, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        else if constexpr (term == 1)
+          pr_c[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[mb], pr_xl, pr_c[mb], 0, 0, 0);
+        else
+          pr_c[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[mb], pr_xh, pr_c[mb], 0, 0, 0);
+      }
+      if constexpr (sl >= 15 && sl <= 30 && EXP != 14) {  // EXP 14: timing experiment without the value epilogue
+        constexpr int mb = (sl - 15) / 4, r = (sl - 15) % 4;
+        float v = pr_c[mb][r] * fz.oscale1;
+        v = __builtin_amdgcn_fmed3f(v, 0.f, pr_top);
+        c11max = fmaxf(c11max, v);
+        pr_hi[r] = (_Float16)v;
+        pr_lo[r] = (_Float16)(v - (float)pr_hi[r]);
+        if constexpr (r == 3) {
+          const int kg1 = lane >> 4;
+          const int q = (mb & 1) * 2 + (kg1 >> 1);
+          const int rb = ((mb >> 1) == 0 ? bufZ : bufX) + pr_rec + (kg1 & 1) * 8;
+          *reinterpret_cast<pr_f16x4*>(smem + rb + (((2 * q) ^ pr_sw) << 4)) = pr_hi;
+          *reinterpret_cast<pr_f16x4*>(smem + rb + (((2 * q + 1) ^ pr_sw) << 4)) = pr_lo;
+        }
+      }
+    }
+  };
+  bool rawfly = false;  // OVL: three raw-window loads were issued in stage 0 of the second slab (counted waits below)
+  auto stage = [&](auto TAPC, auto MODEC, auto PROC, int slab, int pslab, const u32x4* wb2, int ws2) {
     constexpr int tap = decltype(TAPC)::value;
     constexpr int MODE = decltype(MODEC)::value;
+    constexpr bool PRO = decltype(PROC)::value != 0;  // OVL: the successor's conv1_1 slices ride in the MFMA slots
     constexpr bool last = (MODE == 1);
     // loads this wave issued one stage earlier (they may stay in flight across this stage's barrier)
     constexpr int ptap = (tap + 8) % 9;  // tap of the previous stage
@@ -758,6 +913,10 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
         read_one(f1, IC, TAPC, std::integral_constant<int, 1>{}, pcur);
         __builtin_amdgcn_sched_barrier(0);
       }
+      if constexpr (PRO && i < 6) {
+        pro_slot(std::integral_constant<int, (tap % 3) * 12 + i>{}, std::integral_constant<int, tap / 3>{});
+        __builtin_amdgcn_sched_barrier(0);
+      }
     };
     half1(std::integral_constant<int, 0>{});
     half1(std::integral_constant<int, 1>{});
@@ -771,7 +930,11 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     half1(std::integral_constant<int, 9>{});
     half1(std::integral_constant<int, 10>{});
     half1(std::integral_constant<int, 11>{});
-    if constexpr (EXP != 1) pt_wait_vm<prev_issued>();  // weights of stage t+1 (and every older load) landed
+    if constexpr (PRO && (tap == 1 || tap == 2)) {
+      // the three raw-window loads of stage 0 are younger than the weights this barrier needs: they may stay in flight
+      if (rawfly) pt_wait_vm<prev_issued + 3>();
+      else pt_wait_vm<prev_issued>();
+    } else if constexpr (EXP != 1) pt_wait_vm<prev_issued>();  // weights of stage t+1 (and every older load) landed
     // lgkmcnt(0) as a compiler-visible s_waitcnt (vmcnt 63 / expcnt 7 / lgkmcnt 0): the waitcnt pass then
     // knows the second step's fragments have landed and does not re-wait after the next reads are issued
     __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -801,6 +964,16 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
           else if constexpr (MODE == 0) issue_b1(BI{}, wb2, tap + 3 - 9, ws2, tap % 3);
           __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (PRO && tap == 0 && i == 5) {
+          // raw window of the tile after the successor: issued AFTER this stage's weights (so that the waits of the next
+          // two stages can leave it in flight), consumed after the K loop
+          if (rawfly) fetch_raw(mt_next2);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if constexpr (PRO && i < 6) {
+        pro_slot(std::integral_constant<int, (tap % 3) * 12 + 6 + i>{}, std::integral_constant<int, tap / 3>{});
+        __builtin_amdgcn_sched_barrier(0);
       }
     };
     half2(std::integral_constant<int, 0>{});
@@ -816,21 +989,37 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     half2(std::integral_constant<int, 10>{});
     half2(std::integral_constant<int, 11>{});
   };
-  auto slab_body = [&](auto LASTC, int slab, int pslab, const u32x4* wb2, int ws2) {
-    stage(std::integral_constant<int, 0>{}, LASTC, slab, pslab, wb2, ws2);
-    stage(std::integral_constant<int, 1>{}, LASTC, slab, pslab, wb2, ws2);
-    stage(std::integral_constant<int, 2>{}, LASTC, slab, pslab, wb2, ws2);
-    stage(std::integral_constant<int, 3>{}, LASTC, slab, pslab, wb2, ws2);
-    stage(std::integral_constant<int, 4>{}, LASTC, slab, pslab, wb2, ws2);
-    stage(std::integral_constant<int, 5>{}, LASTC, slab, pslab, wb2, ws2);
-    stage(std::integral_constant<int, 6>{}, LASTC, slab, pslab, wb2, ws2);
-    stage(std::integral_constant<int, 7>{}, LASTC, slab, pslab, wb2, ws2);
-    stage(std::integral_constant<int, 8>{}, LASTC, slab, pslab, wb2, ws2);
+  auto slab_body = [&](auto LASTC, auto PROC, int slab, int pslab, const u32x4* wb2, int ws2) {
+    stage(std::integral_constant<int, 0>{}, LASTC, PROC, slab, pslab, wb2, ws2);
+    stage(std::integral_constant<int, 1>{}, LASTC, PROC, slab, pslab, wb2, ws2);
+    stage(std::integral_constant<int, 2>{}, LASTC, PROC, slab, pslab, wb2, ws2);
+    stage(std::integral_constant<int, 3>{}, LASTC, PROC, slab, pslab, wb2, ws2);
+    stage(std::integral_constant<int, 4>{}, LASTC, PROC, slab, pslab, wb2, ws2);
+    stage(std::integral_constant<int, 5>{}, LASTC, PROC, slab, pslab, wb2, ws2);
+    stage(std::integral_constant<int, 6>{}, LASTC, PROC, slab, pslab, wb2, ws2);
+    stage(std::integral_constant<int, 7>{}, LASTC, PROC, slab, pslab, wb2, ws2);
+    stage(std::integral_constant<int, 8>{}, LASTC, PROC, slab, pslab, wb2, ws2);
   };
   // slabs 0 .. nslab-2 are interior; the last one is a transition slab when the tile has a successor
   // 8x8-block variants (no LDS room to park a table): chained when the successor works on the same pixel tile
   // (another channel tile of it - the usual order inside an XCD's chunk), whose table is the one in registers
   const bool chain = !FUSE1 && has_next && (G::NB == 1 || mt_next == mt);
+  if constexpr (OVL) {
+    using I1 = std::integral_constant<int, 1>;
+    slab_body(I0{}, I0{}, 0, 1, wbase, 1);
+    pcur = bufY;
+    pnext = bufZ;  // the successor's first slab: its first fragments are read at the end of the transition slab
+    if (has_next) {
+      rawfly = has_next2;
+      slab_body(I0{}, I1{}, 1, 0, wbase, 0);  // transition slab (same weights for every tile) + the successor's conv1_1
+      if (c11max > PT_SAT_FP16) atomicAdd(&rng[2], 1u);
+      c11max = 0.f;
+    } else {
+      rawfly = false;
+      slab_body(I1{}, I0{}, 1, 0, wbase, 0);
+    }
+    primed = has_next;
+  } else {
   if (chain) wbase_next = wp + (long)(nt_next * BN) * (cin8 * 2);
   const int nloop = chain ? nslab : nslab - 1;
   for (int slab = 0; slab < nloop; ++slab) {
@@ -842,7 +1031,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
         for (int k = 0; k < G::PA; ++k) poff[k] = pk[k * 512];
       }
     }
-    slab_body(std::integral_constant<int, 0>{}, slab, trans ? 0 : slab + 1, trans ? wbase_next : wbase,
+    slab_body(std::integral_constant<int, 0>{}, I0{}, slab, trans ? 0 : slab + 1, trans ? wbase_next : wbase,
               trans ? 0 : slab + 1);
     if (!trans) {
       const int t = pcur;
@@ -850,10 +1039,11 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
       pnext = t;
     }
   }
-  if (!chain) slab_body(std::integral_constant<int, 1>{}, nslab - 1, 0, wbase, 0);
+  if (!chain) slab_body(std::integral_constant<int, 1>{}, I0{}, nslab - 1, 0, wbase, 0);
   primed = chain;
+  }
 
-  if constexpr (FUSE1) {
+  if constexpr (FUSE1 && !OVL) {
     raw_ready = has_next;
     if (raw_ready) fetch_raw(mt_next);
   }
@@ -894,7 +1084,15 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   // wait for the successor's loads and for this tile's own global stores
   pt_lds_barrier();  // every wave is past its last read of the buffer that becomes the staging area
   PT_STAMP(2)
-  float* Cs = reinterpret_cast<float*>(smem + (FUSE1 ? 0 : pcur));
+  float* Cs = reinterpret_cast<float*>(smem + ((FUSE1 && !OVL) ? 0 : pcur));
+  if constexpr (OVL) {
+    if (rawfly) {  // every wave is past its gathers from the successor's window: the one after it moves in
+      float* R = reinterpret_cast<float*>(smem + RAW_OFF);
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (tid + 512 * k < 1200) R[tid + 512 * k] = rawv[k];
+    }
+  }
   const int cout8 = Cout >> 3;
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
@@ -1068,6 +1266,12 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   mt = mt_next;
   nt = nt_next;
   wbase = wbase_next;
+  if constexpr (OVL) {  // (X, Y, Z) <- (Z, X, Y)
+    const int t = bufX;
+    bufX = bufZ;
+    bufZ = bufY;
+    bufY = t;
+  }
   if constexpr (!FUSE1) {
     if (chain) {  // the successor's slab 0 sits in pnext
       const int t = pcur;
@@ -1150,7 +1354,7 @@ extern "C" int mmmot_set_patch_grid_limit(int n) {
 // WRONG results by construction (they remove loads / barriers / MFMAs / stores to time what is left).
 static int g_patch_exp = 0;
 extern "C" int mmmot_set_patch_variant(int v) {
-  if (v < 0 || v > 12) return MMMOT_EINVAL;
+  if (v < 0 || v > 14) return MMMOT_EINVAL;
   g_patch_exp = v;
   return MMMOT_OK;
 }
@@ -1249,6 +1453,12 @@ extern "C" int mmmot_conv1_fused_hl16(const float* crops, const void* w1, const 
   if (!crops || !w1 || !bias1 || !w2 || !bias2 || !oscale2 || !out || L <= 0 || H <= 0 || W <= 0) return MMMOT_EINVAL;
   if ((H & 1) || (W & 1) || !mm_al16(w1) || !mm_al16(w2) || !mm_al16(out)) return MMMOT_EINVAL;
   Fuse1Args fz{crops, (const u32x4*)w1, bias1, oscale1, nullptr, {0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}};
+#ifdef MMMOT_DEBUG
+  if (g_patch_exp == 4) return launch_patch_e<64, 16, true, 4, true>(nullptr, w2, bias2, out, L, H, W, 64, 64, oscale2, s, fz);
+  if (g_patch_exp == 8) return launch_patch_e<64, 16, true, 8, true>(nullptr, w2, bias2, out, L, H, W, 64, 64, oscale2, s, fz);
+  if (g_patch_exp == 13) return launch_patch_e<64, 16, true, 13, true>(nullptr, w2, bias2, out, L, H, W, 64, 64, oscale2, s, fz);
+  if (g_patch_exp == 14) return launch_patch_e<64, 16, true, 14, true>(nullptr, w2, bias2, out, L, H, W, 64, 64, oscale2, s, fz);
+#endif
   return launch_patch_e<64, 16, true, 0, true>(nullptr, w2, bias2, out, L, H, W, 64, 64, oscale2, s, fz);
 }
 

@@ -106,6 +106,17 @@ def hl16_weight_shift(w):
     return 0 if m == 0.0 else max(-14, min(24, int(math.floor(math.log2(16384.0 / m)))))
 
 
+def conv1_weight_shift(wp, bias):
+    """Pre-scale of the fused first layer's [Cout][32] weights: the folded bias rides in the k = 27 slot of the same fp16
+    hi/lo records (csrc/conv3x3_hl16_patch.hip, FUSE1), so |bias| * 2^shift has to stay inside fp16 as well."""
+    import math
+    shift = hl16_weight_shift(wp)
+    mb = float(bias.abs().max())
+    if mb > 0.0:
+        shift = min(shift, int(math.floor(math.log2(32768.0 / mb))))
+    return max(-14, shift)
+
+
 def hl16_channel_shifts(wp):
     """Per-OUTPUT-channel power-of-two pre-scales of a trunk weight [9][Cout][Cin] (fp64): channel n is scaled so that
     max|w[:, n, :]| lands in (2^13, 2^14].  A trained, BatchNorm-folded VGG layer has per-channel gains
@@ -182,7 +193,8 @@ def pack_weights(sd, fusion, device, eps=1e-5):
                 if cin == 3:
                     # fp16-split (hl16) copy of the first layer's [Cout][32] weights for the fused conv1_1+conv1_2
                     # kernel: one power-of-two scale for the layer (hl16 keeps 22 bits down to 2^-17 of the maximum)
-                    shift = hl16_weight_shift(wp)
+                    # (the bias travels in the k = 27 slot of these records: conv1_weight_shift)
+                    shift = conv1_weight_shift(wp, b)
                     cv['wp16'] = to_hl16(wp * (2.0 ** shift)).contiguous().to(device)
                     cv['oscale'] = 2.0 ** (-shift)
                 else:

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from fake_ops import TorchOps
-from mmmot_amd.pack import from_hl16, hl16_weight_shift, to_hl16  # noqa: F401
+from mmmot_amd.pack import conv1_weight_shift, from_hl16, hl16_weight_shift, to_hl16  # noqa: F401
 from test_kernels_gpu import close, hip, rnd  # noqa: F401  (hip is a fixture)
 
 pytestmark = pytest.mark.gpu
@@ -152,7 +152,7 @@ def test_conv1_fused_matches_two_layer_reference(hip, L, H, W):
     b2 = rnd(64, seed=504, scale=0.1)
     w1p = torch.zeros(64, 32)
     w1p[:, :27] = w1.permute(0, 2, 3, 1).reshape(64, 27)
-    s1, s2 = hl16_weight_shift(w1p), hl16_weight_shift(w2)
+    s1, s2 = conv1_weight_shift(w1p, b1), hl16_weight_shift(w2)
     w1h, w2h = to_hl16(w1p.double() * 2.0 ** s1), to_hl16(w2.double() * 2.0 ** s2)
     # float64 reference built from the SAME (hl16-rounded) weights
     w1r = (from_hl16(w1h) * 2.0 ** -s1)[:, :27].view(64, 3, 3, 3).permute(0, 3, 1, 2).double()

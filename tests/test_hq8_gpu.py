@@ -13,7 +13,7 @@ import torch
 
 from common import TOL, build_model, case_inputs, case_names, compare_outputs, get_case, golden
 from fake_ops import TorchOps
-from mmmot_amd.pack import (_e4m3, _hq8_records, from_hl16, from_hq8_act, hl16_weight_shift, hq8_parts, to_hl16,
+from mmmot_amd.pack import (conv1_weight_shift, _e4m3, _hq8_records, from_hl16, from_hq8_act, hl16_weight_shift, hq8_parts, to_hl16,
                             to_hq8_act, to_hq8_w)
 from mmmot_amd.plan import Segments
 from test_conv_patch_gpu import CASES
@@ -159,7 +159,7 @@ def test_conv1_fused_hq8(hip, L, H, W):
     b2 = rnd(64, seed=664, scale=0.1)
     w1p = torch.zeros(64, 32)
     w1p[:, :27] = w1.permute(0, 2, 3, 1).reshape(64, 27)
-    s1, s2 = hl16_weight_shift(w1p), hl16_weight_shift(w2)
+    s1, s2 = conv1_weight_shift(w1p, b1), hl16_weight_shift(w2)
     w1h, w2q = to_hl16(w1p.double() * 2.0 ** s1), to_hq8_w(w2.double() * 2.0 ** s2)
     emu = TorchOps(torch.float64)
     want = torch.zeros(L * (H // 2) * (W // 2), 64)
