@@ -790,6 +790,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
       }
     }
   }
+  PT_STAMP(1)
   } else {
     if (!primed) {  // first tile of this workgroup
       issue_tile_head(pcur);
@@ -1456,6 +1457,7 @@ extern "C" int mmmot_conv1_fused_hl16(const float* crops, const void* w1, const 
 #ifdef MMMOT_DEBUG
   if (g_patch_exp == 4) return launch_patch_e<64, 16, true, 4, true>(nullptr, w2, bias2, out, L, H, W, 64, 64, oscale2, s, fz);
   if (g_patch_exp == 8) return launch_patch_e<64, 16, true, 8, true>(nullptr, w2, bias2, out, L, H, W, 64, 64, oscale2, s, fz);
+  if (g_patch_exp == 9) return launch_patch_e<64, 16, true, 9, true>(nullptr, w2, bias2, out, L, H, W, 64, 64, oscale2, s, fz);
   if (g_patch_exp == 13) return launch_patch_e<64, 16, true, 13, true>(nullptr, w2, bias2, out, L, H, W, 64, 64, oscale2, s, fz);
   if (g_patch_exp == 14) return launch_patch_e<64, 16, true, 14, true>(nullptr, w2, bias2, out, L, H, W, 64, 64, oscale2, s, fz);
 #endif
