@@ -158,7 +158,9 @@ __global__ __launch_bounds__(MM_THREADS, 2) void gemm_rows_kernel(mmmot_gemm_arg
         }
       }
     }
-    if (!rval[i]) x = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (!F16) {  // (the f16 path zeroes rows beyond the tile with its range clamp: see the staging loop)
+      if (!rval[i]) x = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     return x;
   };
 
@@ -170,10 +172,13 @@ __global__ __launch_bounds__(MM_THREADS, 2) void gemm_rows_kernel(mmmot_gemm_arg
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const f32x4 x0 = a_value(i, 0), x1 = a_value(i, 1);
+        // fp16 range clamp and the zeroing of rows beyond the tile in ONE v_med3_f32 per value (bound 0 for such rows;
+        // NORM_RELU values are >= 0 already, so the lower bound does no harm there)
+        const float top = rval[i] ? 65000.f : 0.f;
         f16x8 h, l;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float y0 = fminf(fmaxf(x0[e], -65000.f), 65000.f), y1 = fminf(fmaxf(x1[e], -65000.f), 65000.f);
+          const float y0 = __builtin_amdgcn_fmed3f(x0[e], -top, top), y1 = __builtin_amdgcn_fmed3f(x1[e], -top, top);
           h[e] = (_Float16)y0;
           l[e] = (_Float16)(y0 - (float)h[e]);
           h[4 + e] = (_Float16)y1;
