@@ -28,6 +28,9 @@ python $R/tools/rocpd_summary.py stats $(find /tmp/prof_lat -name "*_results.db"
 timeout 300 python $R/tools/bench_backward.py > $O/bench_backward.log 2>&1
 timeout 300 python $R/tools/bench_train.py > $O/bench_train.log 2>&1
 timeout 300 python $R/tools/bench_conv_variants.py --rounds 4 --variants 11,15,18 > $O/conv_variants_winograd_proxy.log 2>&1
+timeout 300 python $R/tools/bench_fused1.py > $O/bench_fused1.log 2>&1
+timeout 300 python $R/tools/fused1_phase_timers.py > $O/fused1_phase_timers.log 2>&1
+timeout 300 python $R/bench.py --steps 10 --warmup 3 --pairs 32 $Q > $O/bench_pairs32_probe.log 2>&1
 cd $R
 # the tree compiles from clean on the box (no prebuilt objects reused), then the smoke check runs on that build
 ( MMMOT_FORCE_BUILD=1 timeout 900 python -c "import time, __graft_entry__ as g; t = time.time(); print(g.build()); print('forced rebuild of every HIP source: %.0f s' % (time.time() - t)); g.smoke()" ) > $O/smoke_forced_build.log 2>&1
