@@ -8,7 +8,8 @@ Metric (BASELINE.json): frame-pairs/sec of the full eval-mode
 N_det=64 configuration the metric is quoted on, ``configs[2]`` (= SURVEY cfg3):
 Fusion C, N=M=64 (128 crops of 128x128), 2048 LiDAR points per detection.
 One step = one pass of the hot path over one batch of ``--pairs`` synthetic
-frame pairs per GPU.
+frame pairs per GPU (default 16 = 2 048 crops: 11.6 GB of the 288 GB; the ~1 ms of
+small-kernel time per step does not grow with the batch).
 
 Multi-GPU: one process per GPU (torch.distributed, RCCL), samples sharded, no
 data-path collective, one flat result gather per step (weak scaling: per-GPU
@@ -32,7 +33,11 @@ Prints ONE JSON line on rank 0 with the contract fields plus
   cpu_baseline - the oracle (CPU restatement of the reference) on the host cores
   parity       - L-inf of pair 0 against the committed output of the IMPORTED reference (tests/golden/f_*.npz,
                  same seed) and of the CPU-baseline pairs against the oracle
-  extra        - the other arithmetic legs; latency of one reference-shaped call (B=1, cfg1 shape)
+  end_to_end   - F_ref / F_exec per pair and the whole-step fraction of the f16x3 ceiling (north_star: >= 0.50)
+  extra        - the other arithmetic legs; ``workloads``: the other BASELINE.json configs at their batch sizes
+                 (cfg2 B=32, cfg4 32 pairs/GPU, cfg5 image-only / LiDAR-only rows), each with value, roofline and
+                 parity against its reference golden; ``rccl_world1``: the N-GPU step's collective sequence on a
+                 one-rank nccl group (child process); latency of one reference-shaped call (B=1, cfg1 shape)
 """
 import argparse
 import json
