@@ -286,6 +286,11 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
       roff[e] = (k < 27) ? c * 400 + (tap / 3) * 20 + (tap % 3) : 0;
     }
   }
+  // EXP 15 (correct results): static priority for the later-dispatched half of the workgroup (the arbitration loser
+  // of every stage: microarchitecture guide, "two waves per SIMD", item 4)
+  if constexpr (EXP == 15) {
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+  }
   const int nitems = ntm * ntn;
   const int xq = nitems >> 3, xr = nitems & 7;
   const int xcd = blockIdx.x & 7;
@@ -1355,7 +1360,7 @@ extern "C" int mmmot_set_patch_grid_limit(int n) {
 // WRONG results by construction (they remove loads / barriers / MFMAs / stores to time what is left).
 static int g_patch_exp = 0;
 extern "C" int mmmot_set_patch_variant(int v) {
-  if (v < 0 || v > 14) return MMMOT_EINVAL;
+  if (v < 0 || v > 15) return MMMOT_EINVAL;
   g_patch_exp = v;
   return MMMOT_OK;
 }
@@ -1414,6 +1419,7 @@ static int launch_patch(const void* in, const void* wp, const float* bias, void*
       case 5: return launch_patch_e<BN, BS, POOL, 5>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
       case 6: return launch_patch_e<BN, BS, POOL, 6>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
       case 12: return launch_patch_e<BN, BS, POOL, 12>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
+      case 15: return launch_patch_e<BN, BS, POOL, 15>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
       default: break;
     }
   }
