@@ -48,6 +48,7 @@ class Engine:
         self._range_buf = self._range_host = self._range_pending = None
         self._busy = threading.Lock()  # see forward()
         self._last_stream = None
+        self._image_token = None  # image_first(): the image branch of the next forward is already in the workspace
         # f16q8 only: trunk layers (indices into P['vgg'], 1..12) that run the hq8 arithmetic; None = all of them
         # (MMMOT_Q8_LAYERS=all).  The others run f16x3; at a boundary the activation tensor is re-encoded (hq8 <-> hl16,
         # two small kernels).  Default: conv3_1 .. conv5_3 (layers 4..12).  Measured on trained-like statistics
@@ -610,6 +611,44 @@ class Engine:
         finally:
             self._busy.release()
 
+    def _check_crops(self, plan, crops):
+        Lt = plan.Lt
+        ok_f32 = crops is not None and crops.dtype == torch.float32 and tuple(crops.shape) == (Lt, 3, plan.S, plan.S)
+        ok_u8 = crops is not None and crops.dtype == torch.uint8 and tuple(crops.shape) == (Lt, plan.S, plan.S, 3)
+        if not (ok_f32 or ok_u8) or not crops.is_contiguous():
+            raise ValueError('crops must be a contiguous fp32 [%d,3,%d,%d] tensor (the reference\'s normalised `dets`) or '
+                             'the uint8 [%d,%d,%d,3] crops of the resize' % (Lt, plan.S, plan.S, Lt, plan.S, plan.S))
+
+    def image_first(self, plan, crops):
+        """Issue the image branch (trunk + SkipPool heads -> the appearance half of `cat`) of the NEXT ``forward`` now.
+        The trunk needs the detections' counts only, not the point split: the reference-shaped call (TrackingNet.forward)
+        launches it before it reads ``points_split`` back and builds the full plan, so that ~0.3 ms of host work hide
+        behind ~2 ms of device work.  `plan` may be any plan with the same frame counts and crop side (its image tables are
+        the ones used); the next ``forward`` with the same crops tensor skips its own image branch."""
+        if not self._busy.acquire(blocking=False):
+            raise RuntimeError('mmmot_amd: concurrent forwards on one engine (its workspace arena is shared mutable state); '
+                               'use one TrackingNet per thread, or serialise the calls')
+        try:
+            self._check_crops(plan, crops)
+            pin = getattr(self.ops, 'on_current_stream', None)
+            cur = None
+            if crops.is_cuda:
+                cur = torch.cuda.current_stream(crops.device)
+                last = self._last_stream
+                if last is not None and last != cur and not torch.cuda.is_current_stream_capturing():
+                    cur.wait_stream(last)
+                self._last_stream = cur
+            self.dev = crops.device
+            cat = self.buf('cat', plan.Lt, 1024)
+            if pin is None:
+                self._guarded_appearance(plan, crops, cat)
+            else:
+                with pin(cur):
+                    self._guarded_appearance(plan, crops, cat)
+            self._image_token = (crops.data_ptr(), plan.Lt, plan.S, crops.dtype)
+        finally:
+            self._busy.release()
+
     def _forward(self, plan, crops=None, points=None):
         rows = plan.rows
         need_img = (0 in rows) or (2 in rows)
@@ -618,12 +657,11 @@ class Engine:
         self.dev = dev
         Lt = plan.Lt
         cat = self.buf('cat', Lt, 1024)
+        token, self._image_token = self._image_token, None
         if need_img:
-            ok_f32 = crops is not None and crops.dtype == torch.float32 and tuple(crops.shape) == (Lt, 3, plan.S, plan.S)
-            ok_u8 = crops is not None and crops.dtype == torch.uint8 and tuple(crops.shape) == (Lt, plan.S, plan.S, 3)
-            if not (ok_f32 or ok_u8) or not crops.is_contiguous():
-                raise ValueError('crops must be a contiguous fp32 [%d,3,%d,%d] tensor (the reference\'s normalised `dets`) or '
-                                 'the uint8 [%d,%d,%d,3] crops of the resize' % (Lt, plan.S, plan.S, Lt, plan.S, plan.S))
+            self._check_crops(plan, crops)
+        # image_first() ran the image branch of exactly these crops into `cat` already
+        img_done = need_img and token is not None and token == (crops.data_ptr(), Lt, plan.S, crops.dtype)
         if need_pts:
             kin = int(self.P['pointnet']['w1'].shape[1])  # 3 (xyz) or 4 (xyz + reflectivity)
             if points is None or tuple(points.shape) != (plan.P, kin) or not points.is_contiguous():
@@ -640,10 +678,11 @@ class Engine:
             side.wait_stream(main)  # inputs (and the previous forward's readers of the workspace) are ordered before
             with self.ops.on_stream(side):
                 self.pointnet(plan, points, cat)
-            self._guarded_appearance(plan, crops, cat)
+            if not img_done:
+                self._guarded_appearance(plan, crops, cat)
             main.wait_stream(side)
         else:
-            if need_img:
+            if need_img and not img_done:
                 self._guarded_appearance(plan, crops, cat)
             if need_pts:
                 self.pointnet(plan, points, cat)

@@ -396,6 +396,9 @@ class TrackingNet(nn.Module):
         self._engine = None
         self._engine_key = None
         self._plans = {}
+        self._img_plans = {}   # image-only plans of forward()'s trunk-first launch, keyed by (frame counts, crop side)
+        # forward(): launch the trunk before the point split is read back and the plan is built (MMMOT_IMAGE_FIRST=0: after)
+        self.image_first = os.environ.get('MMMOT_IMAGE_FIRST', '1') != '0'
         self.freeze_appearance = False  # training mode: True = frozen eval-mode image features instead of the training trunk
         self._pack_version = 0     # bumped whenever packed weights are REPLACED (captured graphs go stale)
         self._head_versions = None  # parameter versions the live engine's head was packed from
@@ -593,6 +596,41 @@ class TrackingNet(nn.Module):
             return forward_train(self, dets, det_info, dets_split)
         return self.forward_rows(dets, det_info, dets_split, rows=(0, 1, 2))
 
+    def _split_behind_trunk(self, ps_t, fc, S, crops):
+        """The point split (device tensor) is needed on the host to build the plan; the trunk is not waiting for it.  Copy it
+        on a side stream, launch the image branch (Engine.image_first: its tables depend on the frame counts only and are
+        cached per (counts, crop side)), then wait for the copy alone: the read-back and the plan build that follows run
+        beside ~2 ms of trunk time instead of in front of it.  Returns the split as int64 numpy, or None when the engine is
+        not the HIP one (injected test backends take the plain path)."""
+        if getattr(self, '_trained_since_pack', False):
+            self._trained_since_pack = False
+            self.invalidate()
+        eng = self.engine()
+        if eng.ops.name != 'hip':
+            return None
+        dev = crops.device
+        n = int(ps_t.numel())
+        st = getattr(self, '_split_stage', None)
+        if st is None or st[0].numel() < n or st[0].dtype != ps_t.dtype or st[1].device != dev:
+            st = (torch.empty(max(64, 2 * n), dtype=ps_t.dtype).pin_memory(), torch.cuda.Stream(dev), torch.cuda.Event())
+            self._split_stage = st
+        host, side, ev = st
+        cur = torch.cuda.current_stream(dev)
+        side.wait_stream(cur)  # the producer of points_split is ordered before the copy; nothing of this forward is queued yet
+        with torch.cuda.stream(side):
+            host[:n].copy_(ps_t.detach(), non_blocking=True)
+            ev.record(side)
+        key = (tuple(fc), S, str(dev))
+        plan_img = self._img_plans.get(key)
+        if plan_img is None:
+            if len(self._img_plans) > 256:
+                self._img_plans.clear()
+            plan_img = BatchPlan([(fc, None)], S, dev, rows=(0,), use_points=False)
+            self._img_plans[key] = plan_img
+        eng.image_first(plan_img, crops)
+        ev.synchronize()
+        return host[:n].numpy().astype(np.int64)
+
     def forward_rows(self, dets, det_info, dets_split, rows=(0, 1, 2)):
         """Single-modality variant: rows=(0,) image-only skips PointNet+fusion, rows=(1,) LiDAR-only
         skips VGG+fusion; the returned tensors hold only the requested modality rows."""
@@ -600,16 +638,21 @@ class TrackingNet(nn.Module):
         rows = tuple(rows)
         need_pts = (1 in rows) or (2 in rows)
         need_img = (0 in rows) or (2 in rows)
-        ps = None
-        points = None
-        if need_pts:
-            ps_t = det_info['points_split'].reshape(-1)
-            ps = ps_t.detach().to('cpu').numpy().astype(np.int64)  # one D2H copy (reference: 2 .item() per detection)
-            points = det_info['points']
-            points = points.reshape(-1, points.shape[-1]).contiguous()  # [P][3] or [P][4] (with reflectivity)
         # dets: the reference's normalised fp32 [L,3,S,S] crops, or the uint8 [L,S,S,3] crops of the resize
         # (mmmot_amd.crops.crop_resize_u8): ToTensor / Normalize then happen inside the first trunk launch
         S = (int(dets.shape[1]) if dets.dtype == torch.uint8 else int(dets.shape[-1])) if dets is not None else 0
+        ps = None
+        points = None
+        crops = dets.contiguous() if need_img else None
+        if need_pts:
+            ps_t = det_info['points_split'].reshape(-1)
+            if (need_img and ps_t.is_cuda and crops.is_cuda and self.image_first and not self.training
+                    and not torch.cuda.is_current_stream_capturing()):
+                ps = self._split_behind_trunk(ps_t, fc, S, crops)
+            if ps is None:
+                ps = ps_t.detach().to('cpu').numpy().astype(np.int64)  # one D2H copy (reference: 2 .item() per detection)
+            points = det_info['points']
+            points = points.reshape(-1, points.shape[-1]).contiguous()  # [P][3] or [P][4] (with reflectivity)
         dev = points.device if points is not None else dets.device
         key = (tuple(fc), None if ps is None else ps.tobytes(), S, rows, str(dev))
         plan = self._plans.get(key)
@@ -618,7 +661,6 @@ class TrackingNet(nn.Module):
                 self._plans.clear()
             plan = BatchPlan([(fc, ps)], S, dev, rows=rows, use_points=need_pts)
             self._plans[key] = plan
-        crops = dets.contiguous() if need_img else None
         det, links, new, end = self.forward_batch(plan, crops, points)[0]
         trans = self.trans() if need_pts else None
         return det, links, new, end, trans

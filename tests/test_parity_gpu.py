@@ -157,6 +157,36 @@ def test_batched_equals_single_and_is_deterministic():
         assert torch.equal(det, det2) and torch.equal(links[0], links2[0])
 
 
+def test_trunk_first_launch_order_is_bitwise_neutral():
+    """TrackingNet.forward launches the image branch before it reads the point split back (Engine.image_first) - the
+    same kernels on the same data as the plain order, whatever follows on the engine."""
+    c, base = get_case('s2_C_minus_abs_dual_add')
+    m = build_model(c, base, device=DEV)
+    a, b = make_pair(6, 3, 64, 35, seed=910, ragged=True), make_pair(2, 8, 32, 20, seed=911, ragged=True)
+    with torch.no_grad():
+        assert m.image_first
+        first = [m(*to_dev(x)) for x in (a, b, a)]
+        assert m.engine()._image_token is None  # consumed by the forward it was issued for
+        m.image_first = False
+        plain = [m(*to_dev(x)) for x in (a, b, a)]
+    for (d1, l1, n1, e1, _), (d2, l2, n2, e2, _) in zip(first, plain):
+        assert torch.equal(d1, d2) and torch.equal(l1[0], l2[0]) and torch.equal(n1, n2) and torch.equal(e1, e2)
+    # an image branch issued for one crops tensor is not taken for another
+    m.image_first = True
+    with torch.no_grad():
+        dets, info, ds = to_dev(a)
+        eng = m.engine()
+        plan_img = m.make_plan([([6, 3], None)], 64, rows=(0,))
+        eng.image_first(plan_img, dets)
+        other = to_dev(make_pair(6, 3, 64, 35, seed=912, ragged=True))
+        m.image_first = False
+        got = m(*other)
+        m2 = build_model(c, base, device=DEV)
+        m2.image_first = False
+        want = m2(*other)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1][0], want[1][0])
+
+
 def test_full_size_properties_cfg3_sizes_with_cfg4_modes():
     """cfg3 SIZES (N=M=64, 128x128 crops, 2048 pts/det) with cfg4's MODES (Fusion C, minus_abs, dual_add - the
     softmax makes property (4) checkable); cfg3's own modes at full size are pinned by the reference golden
