@@ -451,7 +451,8 @@ def latency_b1(dev, trunk):
         torch.cuda.synchronize()
     return {'latency_ms_b1_hipgraph_replay': round(tg[len(tg) // 2] * 1e3, 3), 'device_ms_b1_eager': round(e0.elapsed_time(e1), 3),'shape': 'cfg1: Fusion A, N=10, M=12, 224x224 crops, ragged ~300 pts/det, B=1, trunk %s' % trunk,
             'latency_ms_b1': round(ts[len(ts) // 2] * 1e3, 3), 'latency_ms_b1_plan_cached': round(ts_cached[len(ts_cached) // 2] * 1e3, 3),
-            'includes': 'points_split D2H + BatchPlan build/upload (plan-cache miss) + launches + D2H of the scores'}
+            'includes': 'points_split D2H + BatchPlan build/upload (plan-cache miss) + launches + D2H of the scores; the module '
+                        'call launches the trunk first and PointNet beside it (MMMOT_IMAGE_FIRST / MMMOT_PN_BESIDE_TRUNK)'}
 
 
 def main():

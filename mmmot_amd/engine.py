@@ -68,6 +68,8 @@ class Engine:
         # r02): cfg3 x 8 pairs 275.3 -> 276.0 pairs/s (noise) while every trunk launch's own duration grows by the time
         # it waits for CUs; B = 1 hipGraph replay 2.85 -> 2.71 ms, eager latency unchanged.
         self.two_streams = os.environ.get('MMMOT_TWO_STREAMS', '0') == '1'
+        # forward() after image_first(): PointNet on a side stream beside the already running trunk (MMMOT_PN_BESIDE_TRUNK=0: behind it)
+        self.pn_beside_trunk = os.environ.get('MMMOT_PN_BESIDE_TRUNK', '1') != '0'
         self._side = {}
         # SkipPool heads: one launch per stage (MMMOT_SP_FUSED=0: LayerNorm / GEMM / LayerNorm / GEMM / LayerNorm launches)
         self.sp_fused = os.environ.get('MMMOT_SP_FUSED', '1') != '0'
@@ -640,6 +642,11 @@ class Engine:
                 self._last_stream = cur
             self.dev = crops.device
             cat = self.buf('cat', plan.Lt, 1024)
+            # what was queued before the trunk: the point the LiDAR branch of the coming forward may start from (side stream)
+            self._pre_image = None
+            if cur is not None and self.pn_beside_trunk and not torch.cuda.is_current_stream_capturing():
+                self._pre_image = torch.cuda.Event()
+                self._pre_image.record(cur)
             if pin is None:
                 self._guarded_appearance(plan, crops, cat)
             else:
@@ -671,7 +678,21 @@ class Engine:
         # all its LDS and registers) - the branches never share a CU, only PointNet's small-grid launches and the
         # uneven tail of a trunk layer leave CUs to the other stream.  Fork / join are events: capturable in a hipGraph.
         side = None
-        if need_img and need_pts and self.two_streams and dev.type == 'cuda' and hasattr(self.ops, 'on_stream'):
+        pre, self._pre_image = getattr(self, '_pre_image', None), None
+        if (img_done and need_pts and pre is not None and dev.type == 'cuda' and hasattr(self.ops, 'on_stream')
+                and not torch.cuda.is_current_stream_capturing()):
+            # the trunk of this forward is already running (image_first): the LiDAR branch goes beside it - it starts from
+            # the point the trunk was launched at, not behind it.  At the reference's call shape (one frame pair) the last
+            # trunk layers leave CUs idle (conv5 of 22 crops: 176 tiles on 256 CUs) and PointNet's ~15 small launches
+            # hide there
+            main = torch.cuda.current_stream(dev)
+            sd = self._side_stream(dev)
+            sd.wait_event(pre)
+            with self.ops.on_stream(sd):
+                self.pointnet(plan, points, cat)
+            main.wait_stream(sd)
+            need_pts = False  # done
+        elif need_img and need_pts and self.two_streams and dev.type == 'cuda' and hasattr(self.ops, 'on_stream'):
             side = self._side_stream(dev)
         if side is not None:
             main = torch.cuda.current_stream(dev)

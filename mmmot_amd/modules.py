@@ -644,22 +644,43 @@ class TrackingNet(nn.Module):
         ps = None
         points = None
         crops = dets.contiguous() if need_img else None
+        beside = False  # the trunk of this call is already running (Engine.image_first)
         if need_pts:
+            # (before the trunk is launched: a layout copy queued behind it would not be seen by the LiDAR branch, which
+            # runs on a side stream beside the trunk)
+            points = det_info['points']
+            points = points.reshape(-1, points.shape[-1]).contiguous()  # [P][3] or [P][4] (with reflectivity)
             ps_t = det_info['points_split'].reshape(-1)
             if (need_img and ps_t.is_cuda and crops.is_cuda and self.image_first and not self.training
                     and not torch.cuda.is_current_stream_capturing()):
                 ps = self._split_behind_trunk(ps_t, fc, S, crops)
+                beside = ps is not None
             if ps is None:
                 ps = ps_t.detach().to('cpu').numpy().astype(np.int64)  # one D2H copy (reference: 2 .item() per detection)
-            points = det_info['points']
-            points = points.reshape(-1, points.shape[-1]).contiguous()  # [P][3] or [P][4] (with reflectivity)
+        try:
+            return self._forward_rows_tail(fc, ps, S, rows, need_pts, crops, points, dets, beside)
+        except BaseException:
+            if beside and self._engine is not None:  # the image branch that was issued belongs to no forward any more
+                self._engine._image_token = None
+                self._engine._pre_image = None
+            raise
+
+    def _forward_rows_tail(self, fc, ps, S, rows, need_pts, crops, points, dets, beside):
         dev = points.device if points is not None else dets.device
         key = (tuple(fc), None if ps is None else ps.tobytes(), S, rows, str(dev))
         plan = self._plans.get(key)
         if plan is None:
             if len(self._plans) > 64:
                 self._plans.clear()
-            plan = BatchPlan([(fc, ps)], S, dev, rows=rows, use_points=need_pts)
+            if beside:
+                # the plan's tables are uploaded on the engine's side stream - the stream the LiDAR branch will run on -
+                # instead of behind the trunk; the main stream (pairwise head) waits for that upload alone
+                side = self.engine()._side_stream(dev)
+                with torch.cuda.stream(side):
+                    plan = BatchPlan([(fc, ps)], S, dev, rows=rows, use_points=need_pts)
+                torch.cuda.current_stream(dev).wait_stream(side)
+            else:
+                plan = BatchPlan([(fc, ps)], S, dev, rows=rows, use_points=need_pts)
             self._plans[key] = plan
         det, links, new, end = self.forward_batch(plan, crops, points)[0]
         trans = self.trans() if need_pts else None

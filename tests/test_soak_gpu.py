@@ -67,3 +67,34 @@ def test_two_stream_forward_equals_one_stream_and_is_capturable():
     for (d0, l0, n0, e0), (d1, l1, n1, e1) in zip(res, one):
         assert torch.equal(d0, d1) and torch.equal(n0, n1) and torch.equal(e0, e1)
         assert all(torch.equal(a, b) for a, b in zip(l0, l1))
+
+
+def test_reference_call_with_trunk_first_and_lidar_beside_it_is_race_free():
+    """TrackingNet.forward launches the trunk before the point split is back (Engine.image_first), uploads the plan tables on
+    the side stream and runs the LiDAR branch there beside the trunk: 150 alternating calls of three shapes (plan-cache hits
+    and misses, fresh input tensors every call) give the bits of the plain single-stream order."""
+    model = TrackingNet(**{**KW, 'score_fusion_arch': 'A'})
+    init_module(model, seed=0)
+    model.eval().cuda()
+    shapes = [(10, 12, 224, 300), (3, 17, 64, 40), (20, 2, 128, 120)]
+    cases = [make_pair(N, M, S, pts, seed=760 + i, ragged=True) for i, (N, M, S, pts) in enumerate(shapes)]
+
+    def dev(c):
+        dets, info, ds = c
+        return dets.cuda(), {k: v.cuda() for k, v in info.items()}, ds
+
+    model.image_first = False
+    with torch.no_grad():
+        want = []
+        for c in cases:
+            det, links, new, end, _ = model(*dev(c))
+            want.append([t.clone() for t in (det, links[0], new, end)])
+        model.image_first = True
+        assert model.engine().pn_beside_trunk
+        for r in range(150):
+            i = (r * 7 + r // 5) % 3
+            if r % 11 == 0:
+                model._plans.clear()  # plan-cache miss: tables built and uploaded while the trunk runs
+            det, links, new, end, _ = model(*dev(cases[i]))
+            for a, b, k in zip(want[i], (det, links[0], new, end), ('det', 'link', 'new', 'end')):
+                assert torch.equal(a, b), 'call %d (shape %d) differs in %s' % (r, i, k)
