@@ -315,16 +315,8 @@ class GraphedForward:
             torch.cuda.synchronize()
             # (the range guard sees the capture and only binds the engine's counter block: check_range() reads it)
             self.graph = torch.cuda.CUDAGraph()
-            # small batches (a frame pair or two): the last trunk layers leave CUs idle, so the LiDAR branch is captured on
-            # a side stream beside the trunk (fork / join by events; same bits: tests/test_soak_gpu.py).  Big batches
-            # fill every CU with trunk workgroups - nothing to gain there (measured neutral).
-            two, eng.two_streams = eng.two_streams, eng.two_streams or (plan.Lt <= 64 and self.points is not None
-                                                                           and self.crops is not None)
-            try:
-                with torch.cuda.graph(self.graph):
-                    self.result = model.forward_batch(plan, self.crops, self.points)
-            finally:
-                eng.two_streams = two
+            with torch.cuda.graph(self.graph):
+                self.result = model.forward_batch(plan, self.crops, self.points)
         # the graph holds raw pointers into the engine's packed weights and workspace arena: keep BOTH alive (every
         # tensor of eng.P and eng.ws at capture time) even if the model is re-packed or a later, larger forward
         # re-allocates workspace buffers - a replay then reads valid memory.  It would still compute with the weights
