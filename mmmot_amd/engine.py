@@ -49,6 +49,7 @@ class Engine:
         self._busy = threading.Lock()  # see forward()
         self._last_stream = None
         self._image_token = None  # image_first(): the image branch of the next forward is already in the workspace
+        self._pre_image = None    # ... and the event recorded in front of it (where the LiDAR branch may start from)
         # f16q8 only: trunk layers (indices into P['vgg'], 1..12) that run the hq8 arithmetic; None = all of them
         # (MMMOT_Q8_LAYERS=all).  The others run f16x3; at a boundary the activation tensor is re-encoded (hq8 <-> hl16,
         # two small kernels).  Default: conv3_1 .. conv5_3 (layers 4..12).  Measured on trained-like statistics
@@ -678,7 +679,7 @@ class Engine:
         # all its LDS and registers) - the branches never share a CU, only PointNet's small-grid launches and the
         # uneven tail of a trunk layer leave CUs to the other stream.  Fork / join are events: capturable in a hipGraph.
         side = None
-        pre, self._pre_image = getattr(self, '_pre_image', None), None
+        pre, self._pre_image = self._pre_image, None
         if (img_done and need_pts and pre is not None and dev.type == 'cuda' and hasattr(self.ops, 'on_stream')
                 and not torch.cuda.is_current_stream_capturing()):
             # the trunk of this forward is already running (image_first): the LiDAR branch goes beside it - it starts from
