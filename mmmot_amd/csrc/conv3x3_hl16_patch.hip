@@ -1257,7 +1257,13 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
         pt_split8(v, hi, lo);
         const long pix = ((long)crop * H + gy) * W + gx;
         u32x4* o = out + (pix * cout8 + (n0 >> 3) + eu) * 2;
-        if constexpr (EXP != 6) {
+        if constexpr (EXP == 16) {
+          // A/B variant: streaming stores, as the hq8 branch uses.  +1.4 / +4.6 / +3.6 % on the 64 -> 128 / 256 -> 256 /
+          // 512 -> 512 layers at 4 pairs per launch, -1.7 / -0.9 / 0 % at the 16 pairs per launch of the benchmark
+          // (tools/bench_conv_variants.py --crops 2048 --variants 11,20): not adopted for the f16x3 arithmetic
+          __builtin_nontemporal_store(hi, &o[0]);
+          __builtin_nontemporal_store(lo, &o[1]);
+        } else if constexpr (EXP != 6) {
           o[0] = hi;
           o[1] = lo;
         } else if (hi[0] == 0x12345678u && lo[1] == 0x9abcdef0u) {
@@ -1360,7 +1366,7 @@ extern "C" int mmmot_set_patch_grid_limit(int n) {
 // WRONG results by construction (they remove loads / barriers / MFMAs / stores to time what is left).
 static int g_patch_exp = 0;
 extern "C" int mmmot_set_patch_variant(int v) {
-  if (v < 0 || v > 15) return MMMOT_EINVAL;
+  if (v < 0 || v > 16) return MMMOT_EINVAL;
   g_patch_exp = v;
   return MMMOT_OK;
 }
@@ -1420,6 +1426,7 @@ static int launch_patch(const void* in, const void* wp, const float* bias, void*
       case 6: return launch_patch_e<BN, BS, POOL, 6>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
       case 12: return launch_patch_e<BN, BS, POOL, 12>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
       case 15: return launch_patch_e<BN, BS, POOL, 15>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
+      case 16: return launch_patch_e<BN, BS, POOL, 16>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
       default: break;
     }
   }
