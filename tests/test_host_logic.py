@@ -217,3 +217,37 @@ def test_uint8_crops_are_the_same_forward_as_the_normalised_tensor(trunk):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1][0], b[1][0]) and torch.equal(a[3], b[3])
     with pytest.raises(ValueError, match='crops must be'):
         m(u8.permute(0, 3, 1, 2).contiguous(), info, ds)
+
+
+def test_image_first_token_semantics():
+    """Engine.image_first issues the image branch of the NEXT forward: that forward (same crops tensor, same geometry)
+    skips its own image branch and returns the same scores; the token is consumed by one forward and never taken for
+    other crops."""
+    c, base = get_case('s2_C_minus_abs_dual_add')
+    m = build_model(c, base, ops=TorchOps())
+    dets, info, ds = case_inputs(c)
+    fc = [int(d) for d in ds]
+    ps = info['points_split'].reshape(-1).long().numpy()
+    S = int(dets.shape[-1])
+    plan = m.make_plan([(fc, ps)], S)
+    plan_img = m.make_plan([(fc, None)], S, rows=(0,))
+    crops = dets.contiguous()
+    points = info['points'].reshape(-1, 3).contiguous()
+    eng = m.engine()
+    with torch.no_grad():
+        want = {k: v.clone() for k, v in eng.forward(plan, crops, points).items() if k in ('det', 'link', 'new', 'end')}
+        calls = []
+        orig = eng._guarded_appearance
+        eng._guarded_appearance = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        eng.image_first(plan_img, crops)
+        assert len(calls) == 1 and eng._image_token is not None
+        got = eng.forward(plan, crops, points)
+        assert len(calls) == 1 and eng._image_token is None          # skipped its own image branch, token consumed
+        for k in want:
+            assert torch.equal(got[k], want[k]), k
+        eng.forward(plan, crops, points)
+        assert len(calls) == 2                                        # the next forward runs it again
+        eng.image_first(plan_img, crops)
+        other = crops.clone()
+        eng.forward(plan, other, points)
+        assert len(calls) == 4 and eng._image_token is None          # other tensor: not taken, and dropped
