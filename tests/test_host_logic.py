@@ -251,3 +251,19 @@ def test_image_first_token_semantics():
         other = crops.clone()
         eng.forward(plan, other, points)
         assert len(calls) == 4 and eng._image_token is None          # other tensor: not taken, and dropped
+
+
+def test_conv1_weight_shift_keeps_weights_and_bias_inside_fp16():
+    """The fused first layer carries its folded bias in the k = 27 slot of the fp16 hi/lo weight records
+    (csrc/conv3x3_hl16_patch.hip): one power-of-two scale has to keep BOTH inside fp16's range."""
+    from mmmot_amd.pack import conv1_weight_shift, hl16_weight_shift
+    g = torch.Generator().manual_seed(5)
+    for wscale, bscale in ((0.3, 0.1), (0.3, 40.0), (1e-3, 5.0), (20.0, 0.0), (0.5, 1e-6)):
+        w = torch.randn(64, 32, generator=g, dtype=torch.float64) * wscale
+        b = torch.randn(64, generator=g, dtype=torch.float64) * bscale
+        s = conv1_weight_shift(w, b)
+        assert s <= hl16_weight_shift(w)
+        assert float(w.abs().max()) * 2.0 ** s <= 32768.0
+        assert float(b.abs().max()) * 2.0 ** s <= 32768.0 < 65504.0
+        if bscale == 0.0:
+            assert s == hl16_weight_shift(w)
