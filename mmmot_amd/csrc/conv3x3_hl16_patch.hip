@@ -1296,7 +1296,13 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   }
   // LDS-only: the staging area is the successor's next patch buffer (FUSE1: the next tile's raw window / patches);
   // the tile's own stores drain under the next tile, the raw-window registers are waited for where they are used
-  pt_lds_barrier();
+  // (EXP 17, timing experiment: chained tiles without this barrier - the staging buffer is next written by the patch DMA
+  // the successor issues after ITS first stage barrier.  Unverified for correctness; see the roadmap in DESIGN.md section 7)
+  if constexpr (EXP == 17) {
+    if (!chain) pt_lds_barrier();
+  } else {
+    pt_lds_barrier();
+  }
   PT_STAMP(5)
   if constexpr (EXP == 9 || EXP == 10) {
     if (threadIdx.x == 0) atomicAdd(&pt_dbg[7], 1ull);
@@ -1366,7 +1372,7 @@ extern "C" int mmmot_set_patch_grid_limit(int n) {
 // WRONG results by construction (they remove loads / barriers / MFMAs / stores to time what is left).
 static int g_patch_exp = 0;
 extern "C" int mmmot_set_patch_variant(int v) {
-  if (v < 0 || v > 16) return MMMOT_EINVAL;
+  if (v < 0 || v > 17) return MMMOT_EINVAL;
   g_patch_exp = v;
   return MMMOT_OK;
 }
@@ -1427,6 +1433,7 @@ static int launch_patch(const void* in, const void* wp, const float* bias, void*
       case 12: return launch_patch_e<BN, BS, POOL, 12>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
       case 15: return launch_patch_e<BN, BS, POOL, 15>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
       case 16: return launch_patch_e<BN, BS, POOL, 16>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
+      case 17: return launch_patch_e<BN, BS, POOL, 17>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
       default: break;
     }
   }

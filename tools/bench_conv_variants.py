@@ -7,7 +7,8 @@ Interleaved rounds in one process (variants x layers), median ms and TFLOP/s-equ
 Variants: 11 = hl16 arithmetic (f16x3 trunk), 12..17 = its timing experiments 1..6 (WRONG results by construction:
 no loads / no barriers / no fragment reads / no MFMAs / no epilogue / no stores), 18 = every fourth MFMA only (the
 matrix-core work per streamed weight byte of a Winograd F(2x2,3x3) stage), 19 = the product kernel with
-`s_setprio 1` for waves 4-7, 20 = with streaming stores in the unpooled epilogue (both: correct results), 21 = hq8 arithmetic (f16q8 trunk),
+`s_setprio 1` for waves 4-7, 20 = with streaming stores in the unpooled epilogue (both: correct results), 23 = chained tiles without
+their closing LDS barrier (timing experiment, correctness unverified), 21 = hq8 arithmetic (f16q8 trunk),
 24 / 25 / 27 / 28 / 32 = its experiments 3 / 4 / 6 / 7 / 11.  The experiments exist only in the -DMMMOT_DEBUG build of
 the library, which this tool builds and loads (libmmmot_hip_debug.so).  Runs on the GPU box only."""
 import argparse
@@ -58,11 +59,11 @@ def main():
             for v in variants:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                if v >= 21:
+                if v >= 21 and v != 23:
                     lib.mmmot_set_patch_variant(v - 21)
                     ops.conv3x3_hq8(xq8, wq8, bias, out, L, H, W, Cin, Cout, bool(pool), osc)
                 else:
-                    lib.mmmot_set_patch_variant({18: 12, 19: 15, 20: 16}.get(v, v - 11))  # 18: a quarter of the MFMAs; 19: s_setprio 1 for waves 4-7; 20: streaming stores
+                    lib.mmmot_set_patch_variant({18: 12, 19: 15, 20: 16, 23: 17}.get(v, v - 11))  # 18: a quarter of the MFMAs; 19: s_setprio 1 for waves 4-7; 20: streaming stores
                     ops.conv3x3_hl16_patch(x16, w16, bias, out, L, H, W, Cin, Cout, bool(pool), osc)
                 e1.record()
                 torch.cuda.synchronize()
