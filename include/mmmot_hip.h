@@ -172,6 +172,10 @@ int mmmot_trunk_range_bind(unsigned int* counters4);
 /* tests: cap the persistent grid of the patch kernels (multiple of 8, 0 = one workgroup per CU) so that small
  * problems run several chained tiles per workgroup like production sizes do.  Results do not depend on it. */
 int mmmot_set_patch_grid_limit(int n);
+/* ABI 7.  tests: smallest block edge the trunk dispatcher may choose - 0 / 4 = automatic (maps of at most 4 x 4 pixels,
+ * conv5_x at 64-pixel crops /root/reference/modules/vgg.py:67-80, run 16 whole maps per 256-row tile without halo),
+ * 8 = such maps run as one haloed 8 x 8 block at 25 % fill like before ABI 7.  Results do not depend on it, bit for bit. */
+int mmmot_set_patch_min_block(int bs);
 #ifdef MMMOT_DEBUG
 /* -DMMMOT_DEBUG builds only (tools/, never the product library): timing experiments of the patch kernel
  * (0 = product; 1..8 remove loads / barriers / MFMAs / stores and give WRONG results) and their phase timers. */

@@ -97,6 +97,7 @@ SIGNATURES = {
     'mmmot_conv1_fused_hq8': [c_f, c_f, c_f, ctypes.c_float, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f],
     'mmmot_conv3x3_first_hl16': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
     'mmmot_set_patch_grid_limit': [c_i],
+    'mmmot_set_patch_min_block': [c_i],
     'mmmot_trunk_range_read': [ctypes.POINTER(ctypes.c_uint), c_i],
     'mmmot_trunk_range_bind': [c_f],
     'mmmot_hl16_pack': [c_f, c_f, ctypes.c_long, c_f],

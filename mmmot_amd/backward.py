@@ -85,15 +85,19 @@ def dgrad_gemm(eng, W, tiles, X, Y):
     transposed weight, exact fp32 matrix cores.  (Not the f16x3 row GEMM: its A operand - here the GRADIENT dY, 1e-4 ..
     1e-7 - is split into fp16 halves unscaled, i.e. into fp16's subnormals; measured: the SGD-step parity went from 2e-6
     to > 1e-5.  The weight-gradient GEMM scales dY by its maximum first, mmmot_gemm_tn_f16.)  The transposed copy is cached
-    on the engine per (storage, version) of W, so a backward does not re-transpose an unchanged weight."""
+    on the engine per (storage, version) of W, so a backward does not re-transpose an unchanged weight.  An entry keeps
+    a reference to W itself: the key contains W's ADDRESS, and a weight that is freed (the folded PointNet weights are
+    fresh tensors every step) would hand its address - at version 0 - to the next step's fold, which would then hit the
+    previous step's transpose (tests/test_train_cpu.py runs three steps against the oracle)."""
     Nf, Kf = int(W.shape[0]), int(W.shape[1])
     cache = eng.__dict__.setdefault('_wt_cache', {})
     key = (W.data_ptr(), W._version, Nf, Kf)
-    wt = cache.get(key)
-    if wt is None:
-        if len(cache) > 64:
-            cache.clear()
-        wt = cache[key] = W.detach().t().contiguous()  # data movement
+    ent = cache.get(key)
+    if ent is None:
+        while len(cache) >= 32:  # oldest first (per-step weights pass through, persistent ones are re-inserted on use)
+            cache.pop(next(iter(cache)))
+        ent = cache[key] = (W, W.detach().t().contiguous())  # data movement; W pinned while the entry lives
+    wt = ent[1]
     eng.ops.gemm(wt, tiles, Kf, Nf, X=X, Y=Y)
 
 

@@ -133,17 +133,34 @@ __device__ __forceinline__ void pt_dma16(const u32x4* src, unsigned char* dst) {
 
 template <int BS>
 struct PatchGeom {
-  static constexpr int NB = P_BM / (BS * BS);     // blocks per workgroup tile: 1 / 4
-  static constexpr int PW = BS + 2;               // patch row length (pixels)
+  // WHOLE (BS <= 4): a block is a WHOLE feature map of at most BS x BS pixels (conv5 at 64-pixel crops: 4 x 4), so every
+  // halo pixel lies outside the image.  The patch is stored WITHOUT halo (256 pixel records = 32 KB per slab instead of
+  // the 73 KB sixteen haloed 6 x 6 patches would take) and a tap that leaves the block reads a zero page in LDS:
+  // sixteen 4 x 4 maps fill a 256-row tile completely, where the 8 x 8 geometry runs them at 25 % fill.
+  static constexpr bool WHOLE = (BS <= 4);
+  static constexpr int NB = P_BM / (BS * BS);     // blocks per workgroup tile: 1 / 4 / 16
+  static constexpr int PW = WHOLE ? BS : BS + 2;  // patch row length (pixels)
   static constexpr int PP = PW * PW;              // patch pixels per block
-  static constexpr int NCH = NB * PP * 8;         // 16-byte pieces per slab patch: 2592 / 3200
-  static constexpr int FULL = NCH / 512;          // rounds in which all 8 waves move 1 KB each: 5 / 6
-  static constexpr int REM = NCH - FULL * 512;    // pieces of the last, partial round: 32 / 128
+  static constexpr int NCH = NB * PP * 8;         // 16-byte pieces per slab patch: 2592 / 3200 / 2048
+  static constexpr int FULL = NCH / 512;          // rounds in which all 8 waves move 1 KB each: 5 / 6 / 4
+  static constexpr int REM = NCH - FULL * 512;    // pieces of the last, partial round: 32 / 128 / 0
   static constexpr int RL = REM / 8;              // active lanes per wave in the partial round: 4 / 16
-  static constexpr int PA = FULL + (REM ? 1 : 0); // DMA rounds per slab patch: 6 / 7
-  static constexpr int BYTES = NCH * 16;          // 41 472 / 51 200
+  static constexpr int PA = FULL + (REM ? 1 : 0); // DMA rounds per slab patch: 6 / 7 / 4
+  // bytes between the patch buffers: the patch itself, or (WHOLE) the 64 x (128 + 4) fp32 rows of an epilogue chunk
+  static constexpr int BYTES = WHOLE ? 34 * 1024 : NCH * 16;  // 41 472 / 51 200 / 34 816
+  static constexpr int NTB = WHOLE ? 1 : NB;      // per-block origins kept by tile_blocks (WHOLE: only the first crop)
   static_assert(REM % 8 == 0 && PA <= 7, "patch rounds must fit taps 0..6 of the previous slab");
+  static_assert(NCH * 16 <= BYTES, "patch buffer");
 };
+
+// patch swizzle of the WHOLE geometry: the 16 lanes of a ds_read_b128 group are, per 32-row M-tile, two diagonal
+// quads of each of its two blocks = 4 consecutive rows (mod 4 distinct under every tap shift) x 2 blocks x 2 column
+// parities (= record parity, the 128-byte half of the 256-byte bank row)
+template <int BS>
+__device__ __forceinline__ int pt_swz_w(int blk, int py) {
+  static_assert(BS == 4, "whole-map geometry: 4 x 4 blocks");
+  return ((py & 3) + 4 * (blk & 1)) & 7;
+}
 
 // decode row i (0..31) of M-tile g (0..7) of the workgroup tile -> block, pixel inside the block
 template <int BS>
@@ -153,10 +170,14 @@ __device__ __forceinline__ void pt_row_to_pixel(int g, int i, int& blk, int& y, 
     blk = 0;
     y = 2 * g + ((i >> 1) & 1);
     x = 2 * q + (i & 1);
-  } else {
+  } else if constexpr (BS == 8) {
     blk = g >> 1;
     y = 2 * (2 * (g & 1) + (q >> 2)) + ((i >> 1) & 1);
     x = 2 * (q & 3) + (i & 1);
+  } else {  // 4 x 4: two blocks per M-tile, four quads each
+    blk = 2 * g + (q >> 2);
+    y = 2 * ((q >> 1) & 1) + ((i >> 1) & 1);
+    x = 2 * (q & 1) + (i & 1);
   }
 }
 
@@ -229,7 +250,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   // STREAM: tiles are chained through transition slabs.  The successor's patch source table is made during the
   // tile's own prologue (low register pressure) and parked in LDS: [PA][512] words behind the ring.  The 8x8-block
   // variants have no room for it: they chain only onto a successor with the same pixel tile (same table).
-  constexpr bool STREAM = !FUSE1 && G::NB == 1;
+  constexpr bool STREAM = !FUSE1 && (G::NB == 1 || G::WHOLE);
   // OVL (the f16x3 fused first layer): the conv1_1 patches of the NEXT tile are computed underneath the K loop of the
   // current one.  A third patch buffer makes that possible: a tile reads (X, Y) = its two 32-channel slabs; while its
   // second slab runs, the successor's first slab is written to Z and its second one to X (dead by then); the
@@ -240,13 +261,19 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   constexpr int POFF_OFF = OVL ? P2_OFF + G::BYTES : LOOP_BYTES + RAW_BYTES;
   // FUSE1: conv1_1 weights as MFMA A fragments [mb][lane][hi | lo] (8 KB) - read per use, not held in 32 registers
   constexpr int W1_OFF = POFF_OFF;
-  constexpr int SMEM = POFF_OFF + (STREAM ? G::PA * 512 * 4 : 0) + (FUSE1 ? 8192 : 0);
+  // WHOLE: 256 zero bytes (one bank row) that stand in for every pixel outside the block
+  constexpr int ZOFF = POFF_OFF + (STREAM ? G::PA * 512 * 4 : 0) + (FUSE1 ? 8192 : 0);
+  static_assert(ZOFF % 256 == 0, "zero page: one aligned bank row");
+  constexpr int SMEM = ZOFF + (G::WHOLE ? 256 : 0);
   static_assert(SMEM <= 160 * 1024, "LDS budget");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA destinations stay in SGPRs
+  if constexpr (G::WHOLE) {  // ordered before the first fragment read by the prologue barrier of the first tile
+    if (tid < 16) reinterpret_cast<u32x4*>(smem + ZOFF)[tid] = u32x4{0u, 0u, 0u, 0u};
+  }
 
   // Persistent workgroups: gridDim.x (a multiple of 8, at most one workgroup per CU - LDS allows no more)
   // workgroups walk the nitems = ntm * ntn tiles.  The dispatcher places workgroup b on XCD b % 8; every XCD
@@ -343,12 +370,18 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   // computed while the slower waves still issue their stores, ahead of the closing barrier of the tile.
   unsigned poff[G::PA];
   struct TileBlocks {
-    int crop[G::NB], gy0[G::NB], gx0[G::NB];  // wave-uniform: crop (-1: no such block) and patch origin of each block
+    int crop[G::NTB], gy0[G::NTB], gx0[G::NTB];  // wave-uniform: crop (-1: no such block) and patch origin of each block
   };
   auto tile_blocks = [&](int mtile, TileBlocks& tb) {
+    if constexpr (G::WHOLE) {  // block q of the tile = crop mtile * NB + q, origin (0, 0), no halo
+      tb.crop[0] = mtile * G::NB;
+      tb.gy0[0] = 0;
+      tb.gx0[0] = 0;
+      return;
+    }
     const int nbpc_ = nby * nbx;
 #pragma unroll
-    for (int q = 0; q < G::NB; ++q) {
+    for (int q = 0; q < G::NTB; ++q) {
       const int b = mtile * G::NB + q;
       const int crop = b / nbpc_, br = b - crop * nbpc_;
       const int by = br / nbx;
@@ -372,15 +405,22 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
       const int rem = n - blk * G::PP;
       const int py = rem / G::PW, px = rem - py * G::PW;
       int crop = tb.crop[0], gy = tb.gy0[0] + py, gx = tb.gx0[0] + px;
+      if constexpr (G::WHOLE) {
+        crop += blk;
+        if (crop >= nblk) crop = -1;
+      }
 #pragma unroll
-      for (int q = 1; q < G::NB; ++q)
+      for (int q = 1; q < G::NTB; ++q)
         if (blk == q) {
           crop = tb.crop[q];
           gy = tb.gy0[q] + py;
           gx = tb.gx0[q] + px;
         }
+      int swz;
+      if constexpr (G::WHOLE) swz = pt_swz_w<BS>(blk, py);
+      else swz = pt_swz_a(py, px);
       if (crop >= 0 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
-        off = (unsigned)(((crop * H + gy) * W + gx) * cin16 + (c ^ pt_swz_a(py, px)));
+        off = (unsigned)(((crop * H + gy) * W + gx) * cin16 + (c ^ swz));
     }
     return off;
   };
@@ -391,8 +431,8 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     poff[1] = poff_round(std::integral_constant<int, 1>{}, tb);
     poff[2] = poff_round(std::integral_constant<int, 2>{}, tb);
     poff[3] = poff_round(std::integral_constant<int, 3>{}, tb);
-    poff[4] = poff_round(std::integral_constant<int, 4>{}, tb);
-    poff[5] = poff_round(std::integral_constant<int, 5>{}, tb);
+    if constexpr (G::PA > 4) poff[4] = poff_round(std::integral_constant<int, 4>{}, tb);
+    if constexpr (G::PA > 5) poff[5] = poff_round(std::integral_constant<int, 5>{}, tb);
     if constexpr (G::PA > 6) poff[6] = poff_round(std::integral_constant<int, 6>{}, tb);
   };
   int mt = 0, nt = 0;
@@ -472,8 +512,8 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     issue_patch_round(std::integral_constant<int, 1>{}, 0, pbuf);
     issue_patch_round(std::integral_constant<int, 2>{}, 0, pbuf);
     issue_patch_round(std::integral_constant<int, 3>{}, 0, pbuf);
-    issue_patch_round(std::integral_constant<int, 4>{}, 0, pbuf);
-    issue_patch_round(std::integral_constant<int, 5>{}, 0, pbuf);
+    if constexpr (G::PA > 4) issue_patch_round(std::integral_constant<int, 4>{}, 0, pbuf);
+    if constexpr (G::PA > 5) issue_patch_round(std::integral_constant<int, 5>{}, 0, pbuf);
     if constexpr (G::PA > 6) issue_patch_round(std::integral_constant<int, 6>{}, 0, pbuf);
     issue_b(0, 0, 0);
     issue_b(1, 0, 1);
@@ -485,15 +525,54 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   // (4j + 2h) ^ swz(py + ty, px + tx).  swz(.., ty odd) = swz(.., ty even) ^ 4, so per row three lane
   // values a_sx[tx] = ((swz(py, px + tx) ^ 2h) << 4) cover every tap: byte offset inside the record =
   // a_sx[tx] ^ (64 * (j ^ (ty & 1))); the tap's pixel offset is an immediate.
+  // WHOLE: no halo in LDS.  The swizzle depends on the row only: a_sx[tm][ty] = ((swz(blk, y + ty - 1) ^ 2h) << 4); the
+  // tap's record is a_base + ((ty - 1) * BS + tx - 1) * 128 when the source pixel lies inside the block (bit `tap` of
+  // a_ok) and otherwise the zero page, at the slot the pixel WOULD occupy (a_zb: its record parity for tx = 1, flipped
+  // for tx = 0 / 2), so that the sixteen lanes of a read group stay on sixteen different slots.
   int a_base[TM], a_sx[TM][3];
+  int a_ok[TM], a_zb[TM];
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     int blk, y, x;
     pt_row_to_pixel<BS>(wm * TM + tm, lr, blk, y, x);
     a_base[tm] = (blk * G::PP + y * G::PW + x) * P_ROWB;
+    if constexpr (G::WHOLE) {
+      a_ok[tm] = 0;
 #pragma unroll
-    for (int tx = 0; tx < 3; ++tx) a_sx[tm][tx] = (pt_swz_a(y, x + tx) ^ (Q8 ? h : 2 * h)) << 4;  // Q8: fp16 piece 2j+h
+      for (int t = 0; t < 9; ++t) {
+        const int sy = y + t / 3 - 1, sx = x + t % 3 - 1;
+        if ((unsigned)sy < (unsigned)BS && (unsigned)sx < (unsigned)BS) a_ok[tm] |= 1 << t;
+      }
+      a_zb[tm] = ZOFF + ((x & 1) << 7);
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty) a_sx[tm][ty] = (pt_swz_w<BS>(blk, y + ty - 1) ^ (Q8 ? h : 2 * h)) << 4;
+    } else {
+      a_ok[tm] = 0;
+      a_zb[tm] = 0;
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) a_sx[tm][tx] = (pt_swz_a(y, x + tx) ^ (Q8 ? h : 2 * h)) << 4;  // Q8: fp16 piece 2j+h
+    }
   }
+  // record address (without the buffer-independent immediate of the haloed geometries) and swizzled piece offset of
+  // k-step 0 of one activation fragment read
+  auto a_addr = [&](auto TMC, auto TAPC, int pb, int& rec, int& sxo) {
+    constexpr int tm = decltype(TMC)::value;
+    constexpr int tap = decltype(TAPC)::value;
+    constexpr int ty = tap / 3, tx = tap % 3;
+    if constexpr (G::WHOLE) {
+      constexpr int imm = ((ty - 1) * BS + (tx - 1)) * P_ROWB;
+      const int inside = pb + a_base[tm] + imm;
+      const int outside = (tx == 1) ? a_zb[tm] : (a_zb[tm] ^ 128);
+      rec = ((a_ok[tm] >> tap) & 1) ? inside : outside;
+      sxo = a_sx[tm][ty];
+    } else {
+      rec = pb + a_base[tm];
+      sxo = a_sx[tm][tx] ^ (64 * (ty & 1));
+    }
+  };
+  constexpr auto a_imm = [](int tap) constexpr -> int {  // folded into the ds_read offset field
+    return G::WHOLE ? 0 : ((tap / 3) * G::PW + (tap % 3)) * P_ROWB;
+  };
   int b_off[TN];  // weight row record + swizzled piece of k-step 0 (k-step 1: ^ 64)
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
@@ -525,8 +604,9 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
       constexpr int sel = r % 2;  // k-step (fp16) or 16-byte half q of the 32-byte fp8 fragment
       if constexpr (r < 2 * TM) {
         constexpr int tm = r / 2;
-        const int rec = pb + a_base[tm] + (ty * G::PW + tx) * P_ROWB;
-        const int sxo = a_sx[tm][tx] ^ (64 * (ty & 1));
+        int rec, sxo;
+        a_addr(std::integral_constant<int, tm>{}, TAPC, pb, rec, sxo);
+        rec += a_imm(tap);
         if constexpr (j == 0) {
           const f16x8 v = *reinterpret_cast<const f16x8*>(smem + rec + (sxo ^ (32 * sel)));
           if constexpr (sel == 0) f.ah[tm] = v; else f.al[tm] = v;
@@ -550,9 +630,10 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     } else if constexpr (r < 2 * TM) {
       constexpr int tm = r / 2;
       // record offsets are multiples of 128 and the swizzled piece offset is < 128: xor 16 flips hi <-> lo
-      const int rec = pb + a_base[tm];
-      const int sxo = a_sx[tm][tx] ^ (64 * (j ^ (ty & 1)));
-      constexpr int imm = (ty * G::PW + tx) * P_ROWB;
+      int rec, sxo;
+      a_addr(std::integral_constant<int, tm>{}, TAPC, pb, rec, sxo);
+      sxo ^= 64 * j;
+      constexpr int imm = a_imm(tap);
       if constexpr (r % 2 == 0) f.ah[tm] = *reinterpret_cast<const f16x8*>(smem + (rec + sxo) + imm);
       else f.al[tm] = *reinterpret_cast<const f16x8*>(smem + (rec + (sxo ^ 16)) + imm);
     } else {
@@ -623,8 +704,8 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
       pk[1 * 512] = poff_round(std::integral_constant<int, 1>{}, tb);
       pk[2 * 512] = poff_round(std::integral_constant<int, 2>{}, tb);
       pk[3 * 512] = poff_round(std::integral_constant<int, 3>{}, tb);
-      pk[4 * 512] = poff_round(std::integral_constant<int, 4>{}, tb);
-      pk[5 * 512] = poff_round(std::integral_constant<int, 5>{}, tb);
+      if constexpr (G::PA > 4) pk[4 * 512] = poff_round(std::integral_constant<int, 4>{}, tb);
+      if constexpr (G::PA > 5) pk[5 * 512] = poff_round(std::integral_constant<int, 5>{}, tb);
       if constexpr (G::PA > 6) pk[6 * 512] = poff_round(std::integral_constant<int, 6>{}, tb);
     }
   }
@@ -1009,7 +1090,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
   // slabs 0 .. nslab-2 are interior; the last one is a transition slab when the tile has a successor
   // 8x8-block variants (no LDS room to park a table): chained when the successor works on the same pixel tile
   // (another channel tile of it - the usual order inside an XCD's chunk), whose table is the one in registers
-  const bool chain = !FUSE1 && has_next && (G::NB == 1 || mt_next == mt);
+  const bool chain = !FUSE1 && has_next && (STREAM || mt_next == mt);
   if constexpr (OVL) {
     using I1 = std::integral_constant<int, 1>;
     slab_body(I0{}, I0{}, 0, 1, wbase, 1);
@@ -1074,9 +1155,9 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     }
   }
   // blocks of this tile: validity and first pixel (block-local (0,0)) of each
-  int bcrop[G::NB], bgy0[G::NB], bgx0[G::NB];
+  int bcrop[G::NTB], bgy0[G::NTB], bgx0[G::NTB];
 #pragma unroll
-  for (int k = 0; k < G::NB; ++k) {
+  for (int k = 0; k < G::NTB; ++k) {
     const int b = mt * G::NB + k;
     const int crop = b / nbpc;
     const int br = b - crop * nbpc;
@@ -1084,6 +1165,20 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     bcrop[k] = (b < nblk) ? crop : -1;
     bgy0[k] = by * BS;
     bgx0[k] = (br - by * nbx) * BS;
+  }
+  // pixel (y, x) of block blk of this tile -> crop (-1: no such block), image coordinates (WHOLE: the block is the
+  // whole map of crop mt * NB + blk)
+#define PT_BLK_PIXEL(blk, y, x)                                   \
+  int crop = bcrop[0], gy = bgy0[0] + (y), gx = bgx0[0] + (x);    \
+  if constexpr (G::WHOLE) {                                       \
+    crop = mt * G::NB + (blk);                                    \
+    if (crop >= nblk) crop = -1;                                  \
+  } else {                                                        \
+    _Pragma("unroll") for (int k = 1; k < G::NTB; ++k) if ((blk) == k) { \
+      crop = bcrop[k];                                            \
+      gy = bgy0[k] + (y);                                         \
+      gx = bgx0[k] + (x);                                         \
+    }                                                             \
   }
   if constexpr (EXP != 5) {
   // barriers of the epilogue order LDS traffic only (lgkmcnt): a __syncthreads() would also drain vmcnt, i.e.
@@ -1137,14 +1232,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
         int blk, y, x;
         if constexpr (POOL) pt_row_to_pixel<BS>(it >> 3, (it & 7) * 4, blk, y, x);
         else pt_row_to_pixel<BS>(it >> 5, it & 31, blk, y, x);
-        int crop = bcrop[0], gy = bgy0[0] + y, gx = bgx0[0] + x;
-#pragma unroll
-        for (int k = 1; k < G::NB; ++k)
-          if (blk == k) {
-            crop = bcrop[k];
-            gy = bgy0[k] + y;
-            gx = bgx0[k] + x;
-          }
+        PT_BLK_PIXEL(blk, y, x)
         // pooled layers floor odd maps like nn.MaxPool2d(2, 2) (reference modules/vgg.py:72): a window that sticks out
         // of the image (last row / column of an odd map) produces no output
         if (crop >= 0 && gy < H && gx < W && (!POOL || ((gy >> 1) < Hq && (gx >> 1) < Wq))) {
@@ -1198,14 +1286,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
       if (qdl >= NQ) continue;
       int blk, y, x;
       pt_row_to_pixel<BS>(qd >> 3, (qd & 7) * 4, blk, y, x);
-      int crop = bcrop[0], gy = bgy0[0] + y, gx = bgx0[0] + x;
-#pragma unroll
-      for (int k = 1; k < G::NB; ++k)
-        if (blk == k) {
-          crop = bcrop[k];
-          gy = bgy0[k] + y;
-          gx = bgx0[k] + x;
-        }
+      PT_BLK_PIXEL(blk, y, x)
       if (crop >= 0 && gy < H && gx < W && (gy >> 1) < Hq && (gx >> 1) < Wq) {  // floor pooling: see the hq8 branch
         f32x8 v = *reinterpret_cast<const f32x8*>(&Cs[qdl * CLD + eu * 8]);
 #pragma unroll
@@ -1235,14 +1316,7 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
       const int r = ch * RCH + rl;
       int blk, y, x;
       pt_row_to_pixel<BS>(r >> 5, r & 31, blk, y, x);
-      int crop = bcrop[0], gy = bgy0[0] + y, gx = bgx0[0] + x;
-#pragma unroll
-      for (int k = 1; k < G::NB; ++k)
-        if (blk == k) {
-          crop = bcrop[k];
-          gy = bgy0[k] + y;
-          gx = bgx0[k] + x;
-        }
+      PT_BLK_PIXEL(blk, y, x)
       if (crop >= 0 && gy < H && gx < W) {
         f32x8 v = *reinterpret_cast<const f32x8*>(&Cs[rl * CLD + eu * 8]);
 #pragma unroll
@@ -1378,7 +1452,25 @@ extern "C" int mmmot_set_patch_variant(int v) {
 }
 #endif
 
+static std::atomic<int> g_patch_min_block{0};
+// Test knob: smallest block edge the dispatcher may choose (0 / 4 = automatic; 8 = maps of at most 4 x 4 pixels run in the
+// haloed 8 x 8 geometry like before round 4).  Results do not depend on it - bit for bit: the zero halo adds exact zeros
+// and the order of the accumulation is the same (tests/test_conv_patch_gpu.py).
+extern "C" int mmmot_set_patch_min_block(int bs) {
+  if (bs != 0 && bs != 4 && bs != 8) return MMMOT_EINVAL;
+  g_patch_min_block.store(bs);
+  return MMMOT_OK;
+}
+
 static int pt_num_cu() { return mm_num_cu(); }
+
+// block edge of a layer: 16 x 16 blocks unless the whole map fits an 8 x 8 block; maps of at most 4 x 4 pixels
+// (conv5 at 64-pixel crops) take the halo-free whole-map geometry, 16 maps per tile
+static int pt_block_edge(int H, int W) {
+  if (H > 8 || W > 8) return 16;
+  if (H <= 4 && W <= 4 && g_patch_min_block.load() != 8) return 4;
+  return 8;
+}
 
 // 128- or 64-channel tiles?  128 halves the LDS traffic per MFMA, but a small problem (one reference-shaped frame pair:
 // 22 crops, 14 x 14 maps at conv5 = 88 tiles of 128 channels on 256 CUs) fills the chip better with twice as many
@@ -1387,8 +1479,7 @@ static bool pt_use_bn64(int L, int H, int W, int Cout) {
   if (Cout % 128 != 0) return true;
   const int n_cu = pt_num_cu();
   if (n_cu <= 0) return false;
-  const bool big = (H > 8 || W > 8);
-  const int bs = big ? 16 : 8, nb = big ? 1 : 4;
+  const int bs = pt_block_edge(H, W), nb = 256 / (bs * bs);
   const long nblk = (long)L * ((H + bs - 1) / bs) * ((W + bs - 1) / bs);
   const long i128 = ((nblk + nb - 1) / nb) * (Cout / 128), i64 = 2 * i128;
   auto eff = [&](long items) { return (double)items / (double)(((items + n_cu - 1) / n_cu) * n_cu); };
@@ -1458,12 +1549,14 @@ extern "C" int mmmot_conv3x3_bn_relu_hl16_patch(const void* in, const void* wp, 
   if (Cin % 32 != 0 || Cout % 64 != 0) return MMMOT_EINVAL;  // odd maps: floor pooling (partial windows dropped)
   if (!mm_al16(in) || !mm_al16(wp) || !mm_al16(out)) return MMMOT_EINVAL;
   if ((long)L * H * W * (Cin / 4) >= (1L << 31) - 64) return MMMOT_EINVAL;  // 32-bit piece offsets
-  const bool big = (H > 8 || W > 8);  // 16x16 blocks unless the whole map fits an 8x8 block
+  const int bs = pt_block_edge(H, W);
   if (!pt_use_bn64(L, H, W, Cout))
-    return big ? launch_patch_p<128, 16>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s)
-               : launch_patch_p<128, 8>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
-  return big ? launch_patch_p<64, 16>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s)
-             : launch_patch_p<64, 8>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
+    return bs == 16 ? launch_patch_p<128, 16>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s)
+           : bs == 8 ? launch_patch_p<128, 8>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s)
+                     : launch_patch_p<128, 4>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
+  return bs == 16 ? launch_patch_p<64, 16>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s)
+         : bs == 8 ? launch_patch_p<64, 8>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s)
+                   : launch_patch_p<64, 4>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
 }
 
 // conv1_1 (3 -> 64) + conv1_2 (64 -> 64) + 2x2 max-pool in one kernel: see FUSE1 above.
@@ -1525,12 +1618,14 @@ extern "C" int mmmot_conv3x3_bn_relu_hq8(const void* in, const void* wp, const f
   if (Cin % 32 != 0 || Cout % 64 != 0) return MMMOT_EINVAL;  // odd maps: floor pooling (partial windows dropped)
   if (!mm_al16(in) || !mm_al16(wp) || !mm_al16(out)) return MMMOT_EINVAL;
   if ((long)L * H * W * (Cin / 4) >= (1L << 31) - 64) return MMMOT_EINVAL;
-  const bool big = (H > 8 || W > 8);
+  const int bs = pt_block_edge(H, W);
   if (!pt_use_bn64(L, H, W, Cout))
-    return big ? launch_q8_p<128, 16>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s)
-               : launch_q8_p<128, 8>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
-  return big ? launch_q8_p<64, 16>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s)
-             : launch_q8_p<64, 8>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
+    return bs == 16 ? launch_q8_p<128, 16>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s)
+           : bs == 8 ? launch_q8_p<128, 8>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s)
+                     : launch_q8_p<128, 4>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
+  return bs == 16 ? launch_q8_p<64, 16>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s)
+         : bs == 8 ? launch_q8_p<64, 8>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s)
+                   : launch_q8_p<64, 4>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
 }
 
 extern "C" int mmmot_conv1_fused_hq8(const float* crops, const void* w1, const float* bias1, float oscale1,

@@ -1,5 +1,5 @@
-"""The LDS-resident-patch trunk kernel (conv3x3_hl16_patch.hip) must agree with the fp64 convolution.  Geometry cases exercise both block
-shapes (16x16x1, 8x8x4), partial blocks (maps that are not multiples of the block), maps smaller than a block,
+"""The LDS-resident-patch trunk kernel (conv3x3_hl16_patch.hip) must agree with the fp64 convolution.  Geometry cases exercise the three block
+shapes (16x16x1, 8x8x4, whole maps of at most 4x4 x16), partial blocks (maps that are not multiples of the block), maps smaller than a block,
 tiles that straddle crops, partial last tiles and 2..16 channel slabs."""
 import pytest
 import torch
@@ -88,6 +88,73 @@ def test_conv3x3_hl16_patch_chained_tiles(hip, small_grid, pool, L, H, W, Cin, C
     u2 = torch.zeros_like(o2)
     hip.hl16_unpack(o2, u2)
     assert torch.equal(out.cpu(), u2.cpu()), 'chained and unchained launches differ'
+
+
+# maps of at most 4 x 4 pixels (conv5 at 64-pixel crops, conv4 / conv5 at 32-pixel crops): the whole-map geometry -
+# 16 maps per 256-row tile, no halo in LDS, taps that leave the map read a zero page
+WHOLE_CASES = [
+    # pool L  H  W  Cin Cout
+    (0, 16, 4, 4, 64, 128),      # exactly one full tile
+    (1, 16, 4, 4, 64, 128),
+    (0, 40, 4, 4, 64, 128),      # 2.5 tiles: ragged last tile
+    (1, 37, 4, 4, 96, 64),       # odd slab count, 64-channel tiles
+    (0, 1, 4, 4, 32, 64),        # one map, single slab
+    (0, 5, 3, 3, 64, 64),        # maps smaller than the block: unused pixel slots stay zero
+    (1, 6, 4, 2, 64, 128),       # different sides
+    (1, 7, 3, 4, 64, 64),        # odd side, pooled: 3 -> 1
+    (0, 19, 1, 1, 64, 64),       # 1 x 1 maps (conv5_x output side at 32-pixel crops is 2, pooled to 1)
+    (0, 18, 2, 2, 128, 128),     # 2 x 2 maps (conv5 at 32-pixel crops)
+    (1, 18, 2, 2, 128, 128),
+    (0, 70, 4, 4, 512, 512),     # conv5_1 / conv5_2 shape, several tiles x 4 channel tiles
+    (1, 70, 4, 4, 512, 512),     # conv5_3
+]
+
+
+def _launch(hip, x16, w16, bias, shift, pool, L, H, W, Cin, Cout):
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    o = torch.full((L * Ho * Wo, Cout), float('nan')).cuda()
+    hip.conv3x3_hl16_patch(x16.cuda(), w16.cuda(), bias.cuda(), o, L, H, W, Cin, Cout, bool(pool), 2.0 ** -shift)
+    u = torch.zeros_like(o)
+    hip.hl16_unpack(o, u)
+    return u.cpu()
+
+
+@pytest.mark.parametrize('pool,L,H,W,Cin,Cout', WHOLE_CASES)
+def test_conv3x3_hl16_patch_whole_map_blocks(hip, pool, L, H, W, Cin, Cout):
+    from mmmot_amd import _lib
+    lib = _lib.load()
+    out, ref, (x16, w16, bias, shift) = run_case(hip, pool, L, H, W, Cin, Cout, seed=490)
+    close(out, ref, 2e-6, 'whole-map 4x4 blocks vs fp64')
+    # bit for bit the result of the haloed 8 x 8 geometry (exact zeros from the halo, same accumulation order) ...
+    assert lib.mmmot_set_patch_min_block(8) == 0
+    try:
+        o8 = _launch(hip, x16, w16, bias, shift, pool, L, H, W, Cin, Cout)
+    finally:
+        assert lib.mmmot_set_patch_min_block(0) == 0
+    assert torch.equal(out.cpu(), o8), 'whole-map and haloed 8x8 geometries differ'
+    # ... and of the chained launch (grid capped at 8 workgroups: the successor's patch slab streams in during the last slab)
+    assert lib.mmmot_set_patch_grid_limit(8) == 0
+    try:
+        oc = _launch(hip, x16, w16, bias, shift, pool, L, H, W, Cin, Cout)
+    finally:
+        assert lib.mmmot_set_patch_grid_limit(0) == 0
+    assert torch.equal(out.cpu(), oc), 'chained and unchained whole-map launches differ'
+
+
+def test_whole_map_blocks_long_chains_are_deterministic(hip):
+    """600 maps of 4 x 4 on 8 workgroups: 38 pixel tiles x 4 channel tiles = 19-tile chains per workgroup, repeated."""
+    from mmmot_amd import _lib
+    lib = _lib.load()
+    pool, L, H, W, Cin, Cout = 0, 600, 4, 4, 128, 512
+    out, ref, (x16, w16, bias, shift) = run_case(hip, pool, L, H, W, Cin, Cout, seed=495)
+    close(out, ref, 2e-6, 'whole-map blocks, one workgroup per tile')
+    assert lib.mmmot_set_patch_grid_limit(8) == 0
+    try:
+        for _ in range(5):
+            oc = _launch(hip, x16, w16, bias, shift, pool, L, H, W, Cin, Cout)
+            assert torch.equal(out.cpu(), oc), 'chained whole-map launch differs'
+    finally:
+        assert lib.mmmot_set_patch_grid_limit(0) == 0
 
 
 def test_patch_kernel_is_deterministic(hip):

@@ -105,6 +105,33 @@ def test_conv3x3_hq8_chained_tiles(hip, pool, L, H, W, Cin, Cout):
     close(dec, ref, ENC_TOL, 'chained hq8 tiles vs fp64 statement')
 
 
+@pytest.mark.parametrize('pool,L,H,W,Cin,Cout', [(0, 40, 4, 4, 64, 128), (1, 37, 4, 4, 96, 64), (0, 5, 3, 3, 64, 64),
+                                                 (1, 18, 2, 2, 128, 128), (1, 70, 4, 4, 512, 512)])
+def test_conv3x3_hq8_whole_map_blocks(hip, pool, L, H, W, Cin, Cout):
+    """maps of at most 4 x 4 pixels in the whole-map geometry (16 maps per tile, no halo): the fp64 statement of the hq8
+    arithmetic, and the bytes of the haloed 8 x 8 geometry and of the chained launch"""
+    from mmmot_amd import _lib
+    lib = _lib.load()
+    x = torch.relu(rnd(L * H * W, Cin, seed=690)) * 3.0
+    w = rnd(9, Cout, Cin, seed=691, scale=(2.0 / (9 * Cin)) ** 0.5)
+    bias = rnd(Cout, seed=692, scale=0.1)
+    shift = hl16_weight_shift(w)
+    xrec, wrec = to_hq8_act(x), to_hq8_w(w.double() * 2.0 ** shift)
+    dec, ref, out = run_records(hip, xrec, wrec, bias, pool, L, H, W, Cin, Cout, 2.0 ** -shift)
+    close(dec, ref, ENC_TOL, 'hq8 whole-map blocks vs fp64 statement of the hq8 arithmetic')
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    xs, ws, bs = xrec.cuda(), wrec.cuda(), bias.cuda()
+    for setter, arg, what in ((lib.mmmot_set_patch_min_block, 8, 'haloed 8x8 geometry'),
+                              (lib.mmmot_set_patch_grid_limit, 8, 'chained launch')):
+        assert setter(arg) == 0
+        try:
+            o = torch.full((L * Ho * Wo, Cout), float('nan')).cuda()
+            hip.conv3x3_hq8(xs, ws, bs, o, L, H, W, Cin, Cout, bool(pool), 2.0 ** -shift)
+        finally:
+            assert setter(0) == 0
+        assert torch.equal(bytes_of(out), bytes_of(o)), 'hq8 whole-map blocks differ from the ' + what
+
+
 @pytest.mark.parametrize('which', ['fp8_only', 'fp16_only', 'a8_only', 'al8_only'])
 @pytest.mark.parametrize('pool,L,H,W,Cin,Cout', [(0, 2, 16, 16, 64, 128), (1, 3, 8, 8, 96, 64)])
 def test_conv3x3_hq8_operand_placement(hip, which, pool, L, H, W, Cin, Cout):

@@ -160,3 +160,91 @@ def test_one_sgd_step_matches_the_oracle(name):
     m(dets, info, ds)
     packed = m.engine().P['w_link']['w3']
     assert torch.equal(packed, m.w_link.conv1[3].weight.detach().flatten(1))  # re-packed from the stepped parameters
+
+
+def test_three_sgd_steps_match_the_oracle():
+    """Several steps in a row: the folded PointNet weights are fresh tensors every step, freed after the
+    backward, and the allocator hands their addresses to the next step's fold - a transposed-weight cache keyed by
+    address alone then serves the PREVIOUS step's weights to the input-gradient GEMM from step 2 on (1e-2 off)."""
+    name = 's2_C_multiply_none'
+    c, base = get_case(name)
+    m = build_model(c, base, ops=TorchOps())
+    m.set_trunk('f32')
+    dets, info, ds = case_inputs(c)
+    counts = [int(d) for d in ds]
+    kw = dict(detloss_type='bce', linkloss_type='l2', det_ratio=1.5, trans_ratio=0.001)
+    cfg = dict(fusion=c['fusion'], affinity_op=c['aff'], softmax_mode=c['sm'])
+    lr, steps = 0.05, 3
+    # the oracle's three steps (float64; frozen eval-mode image features: the trunk does not change)
+    with torch.no_grad():
+        img = R.appearance(dets, {k: v.detach().clone() for k, v in m.state_dict().items()}).double()
+    sd = oracle_sd(m)
+    for it in range(steps):
+        gts = make_gts(counts, 20 + it)
+        det, links, new, end, trans = R.tracking_forward_train(sd, cfg, img, info['points'].double(), info['points_split'], ds)
+        loss = R.tracking_loss(counts, gts[0].double(), [g.double() for g in gts[1]], gts[2].double(), gts[3].double(),
+                               det, links, new, end, trans, **kw)
+        loss.backward()
+        nxt = {}
+        for k, v in sd.items():
+            if v.dtype.is_floating_point and v.grad is not None:
+                nxt[k] = (v.detach() - lr * v.grad).requires_grad_(True)
+            else:
+                nxt[k] = v.detach().clone().requires_grad_(v.requires_grad) if v.dtype.is_floating_point else v
+        sd = nxt
+    m.train()
+    m.freeze_appearance = True
+    crit = TrackingLoss(**kw)
+    crit.ops = TorchOps()
+    opt = torch.optim.SGD(m.parameters(), lr=lr)
+    for it in range(steps):
+        gts = make_gts(counts, 20 + it)
+        det, links, new, end, trans = m(dets, info, ds)
+        loss = crit(ds, gts[0], gts[1], gts[2], gts[3], det, links, new, end, trans)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    worst, n = 0.0, 0
+    for k, p in m.named_parameters():
+        if k.startswith(HEADS) and p.grad is not None:
+            ref = sd[k].detach()
+            err = (p.detach().double() - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
+            worst, n = max(worst, err), n + 1
+            assert err < 5e-5, (k, err)
+    assert n >= 76
+    print('three SGD steps, worst relative parameter difference: %.2e over %d tensors' % (worst, n))
+
+
+@pytest.mark.parametrize('what', ['one_step', 'encoder_only'])
+def test_eval_after_training_repacks(what):
+    """eval -> training step(s) -> eval must compute with the UPDATED weights: after exactly one step (the
+    flag refresh_head_device sets is only reached by the NEXT training forward), and after training that leaves the head
+    untouched (PointNet-only: the head's parameter versions never change)."""
+    c, base = get_case('s2_C_multiply_none')
+    m = build_model(c, base, ops=TorchOps())
+    m.set_trunk('f32')
+    dets, info, ds = case_inputs(c)
+    counts = [int(d) for d in ds]
+    m.eval()
+    with torch.no_grad():
+        before = m(dets, info, ds)
+    m.train()
+    m.freeze_appearance = True
+    crit = TrackingLoss(detloss_type='bce', linkloss_type='l2', det_ratio=1.5, trans_ratio=0.001)
+    crit.ops = TorchOps()
+    params = [p for k, p in m.named_parameters() if (what == 'one_step' or k.startswith('point_net.'))]
+    opt = torch.optim.SGD(params, lr=0.05)
+    gts = make_gts(counts, 31)
+    det, links, new, end, trans = m(dets, info, ds)
+    loss = crit(ds, gts[0], gts[1], gts[2], gts[3], det, links, new, end, trans)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    m.eval()
+    with torch.no_grad():
+        after = m(dets, info, ds)
+        m.invalidate()
+        fresh = m(dets, info, ds)
+    assert (after[1][0] - before[1][0]).abs().max().item() > 1e-4, 'the eval forward still runs on the old weights'
+    for a, f in zip((after[0], after[1][0], after[2], after[3]), (fresh[0], fresh[1][0], fresh[2], fresh[3])):
+        assert torch.equal(a, f)
