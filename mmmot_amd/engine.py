@@ -44,6 +44,7 @@ class Engine:
         self.range_check_every = int(os.environ.get('MMMOT_RANGE_CHECK_EVERY', '0'))
         self.q8_sat_limit = float(os.environ.get('MMMOT_Q8_SAT_LIMIT', '1e-4'))  # tolerated fraction of saturated elements
         self.range_events = []
+        self.last_out_of_range_forward = None  # index of the latest forward whose out-of-range results were already returned
         self._n_forward = 0
         self._range_buf = self._range_host = self._range_pending = None
         self._busy = threading.Lock()  # see forward()
@@ -299,9 +300,17 @@ class Engine:
         return None
 
     def _range_event(self, plan, lower, sat, clamp, c11, recomputed):
-        ev = dict(forward=self._n_forward, was=self.trunk, now=lower, e4m3_saturated=sat, fp16_clamped=clamp,
-                  conv1_1_hits=c11, trunk_elements=self.trunk_elements(plan), recomputed=recomputed)
+        # `affected_forward`: index (count of forwards of this engine, from 0) of the forward whose trunk ran out of
+        # range.  recomputed=True: that forward's results were recomputed in the lowered arithmetic before they were
+        # returned; False (asynchronous read-back): they were ALREADY RETURNED - the caller discards / repeats the
+        # forward with that index (`Engine.forward_index` of a result = the value of `_n_forward - 1` after the call;
+        # `Engine.last_out_of_range_forward` keeps the latest such index, None while there was none) - ADVICE r3
+        affected = self._n_forward if recomputed else self._n_forward - 1
+        ev = dict(forward=self._n_forward, affected_forward=affected, was=self.trunk, now=lower, e4m3_saturated=sat,
+                  fp16_clamped=clamp, conv1_1_hits=c11, trunk_elements=self.trunk_elements(plan), recomputed=recomputed)
         self.range_events.append(ev)
+        if not recomputed:
+            self.last_out_of_range_forward = affected
         warnings.warn('mmmot_amd range guard: trunk arithmetic %(was)s -> %(now)s (%(e4m3_saturated)d activation '
                       'elements beyond the e4m3 range, %(fp16_clamped)d beyond the fp16 range, of %(trunk_elements)d '
                       'per forward); ' % ev + ('the trunk of this forward is recomputed' if recomputed else

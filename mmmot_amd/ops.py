@@ -359,7 +359,9 @@ class HipOps:
         a.dW, a.db = _ptr(dW), _ptr(db)
         if self.tn_f16:
             # fp16 matrix cores (3-term split), dY scaled by a power of two taken from its maximum on the device
-            amax = self._scratch('tn_amax', 1, dY.device)
+            # one scalar per (device, stream): two backward passes issued on different streams through one HipOps
+            # must not land their maxima in each other's scale
+            amax = self._scratch(('tn_amax', int(self._stream() or 0)), 1, dY.device)
             _lib.check(self.lib.mmmot_absmax(_ptr(dY), _ld(dY), tiles.R, N, _ptr(amax), self._stream()), 'mmmot_absmax')
             _lib.check(self.lib.mmmot_gemm_tn_f16(ctypes.byref(a), _ptr(amax), self._stream()), 'mmmot_gemm_tn_f16')
             return

@@ -264,6 +264,12 @@ class TrackingLoss(nn.Module):
 
     def forward(self, det_split, gt_det, gt_link, gt_new, gt_end, det_score, link_score, new_score, end_score, trans=None):
         split = [int(d.item()) if torch.is_tensor(d) else int(d) for d in det_split]
+        if min(split) <= 0:
+            # cost.py:166 slices gt_end[:-det_split[-1]] (EMPTY for a last frame without detections, where the slice
+            # below would be the full vector) and a link term over N * M == 0 pairs has no mean: the reference's
+            # training samples are built from frames that have detections (dataset/patchwise_dataset.py:205-216
+            # keeps frames present in sequence_det), so such a sample is refused instead of guessed at
+            raise ValueError('TrackingLoss: every frame of a sample needs at least one detection (det_split = %r)' % (split,))
         scores = [det_score, new_score, end_score] + list(link_score)
         terms = self._det_terms(0, det_score, gt_det, self.detloss_type, self.det_ratio)
         terms += self._det_terms(1, new_score, gt_new[split[0]:], self.endloss_type, 0.4)

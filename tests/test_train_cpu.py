@@ -165,7 +165,10 @@ def test_one_sgd_step_matches_the_oracle(name):
 def test_three_sgd_steps_match_the_oracle():
     """Several steps in a row: the folded PointNet weights are fresh tensors every step, freed after the
     backward, and the allocator hands their addresses to the next step's fold - a transposed-weight cache keyed by
-    address alone then serves the PREVIOUS step's weights to the input-gradient GEMM from step 2 on (1e-2 off)."""
+    address alone then serves the PREVIOUS step's weights to the input-gradient GEMM from step 2 on (1e-2 off).
+    Every step is compared with the oracle's step FROM THE MODEL'S OWN STATE: on this 9-detection fixture the
+    normalisations amplify a 6e-7 difference of the parameters into 20 % of some gradients after one step of this size, so
+    two trajectories cannot be compared - one step at a time can."""
     name = 's2_C_multiply_none'
     c, base = get_case(name)
     m = build_model(c, base, ops=TorchOps())
@@ -175,44 +178,27 @@ def test_three_sgd_steps_match_the_oracle():
     kw = dict(detloss_type='bce', linkloss_type='l2', det_ratio=1.5, trans_ratio=0.001)
     cfg = dict(fusion=c['fusion'], affinity_op=c['aff'], softmax_mode=c['sm'])
     lr, steps = 0.05, 3
-    # the oracle's three steps (float64; frozen eval-mode image features: the trunk does not change)
-    with torch.no_grad():
-        img = R.appearance(dets, {k: v.detach().clone() for k, v in m.state_dict().items()}).double()
-    sd = oracle_sd(m)
-    for it in range(steps):
-        gts = make_gts(counts, 20 + it)
-        det, links, new, end, trans = R.tracking_forward_train(sd, cfg, img, info['points'].double(), info['points_split'], ds)
-        loss = R.tracking_loss(counts, gts[0].double(), [g.double() for g in gts[1]], gts[2].double(), gts[3].double(),
-                               det, links, new, end, trans, **kw)
-        loss.backward()
-        nxt = {}
-        for k, v in sd.items():
-            if v.dtype.is_floating_point and v.grad is not None:
-                nxt[k] = (v.detach() - lr * v.grad).requires_grad_(True)
-            else:
-                nxt[k] = v.detach().clone().requires_grad_(v.requires_grad) if v.dtype.is_floating_point else v
-        sd = nxt
     m.train()
     m.freeze_appearance = True
     crit = TrackingLoss(**kw)
     crit.ops = TorchOps()
     opt = torch.optim.SGD(m.parameters(), lr=lr)
+    worst = 0.0
     for it in range(steps):
         gts = make_gts(counts, 20 + it)
+        _, ref_params, _ = sgd_step_reference(m, cfg, kw, dets, info, ds, gts, lr)
         det, links, new, end, trans = m(dets, info, ds)
         loss = crit(ds, gts[0], gts[1], gts[2], gts[3], det, links, new, end, trans)
         opt.zero_grad()
         loss.backward()
         opt.step()
-    worst, n = 0.0, 0
-    for k, p in m.named_parameters():
-        if k.startswith(HEADS) and p.grad is not None:
-            ref = sd[k].detach()
-            err = (p.detach().double() - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
-            worst, n = max(worst, err), n + 1
-            assert err < 5e-5, (k, err)
-    assert n >= 76
-    print('three SGD steps, worst relative parameter difference: %.2e over %d tensors' % (worst, n))
+        for k, p in m.named_parameters():
+            if k in ref_params:
+                ref = ref_params[k]
+                err = (p.detach().double() - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
+                worst = max(worst, err)
+                assert err < 3e-5, (it, k, err)
+    print('three SGD steps, worst relative parameter difference of a step: %.2e' % worst)
 
 
 @pytest.mark.parametrize('what', ['one_step', 'encoder_only'])
@@ -248,3 +234,29 @@ def test_eval_after_training_repacks(what):
     assert (after[1][0] - before[1][0]).abs().max().item() > 1e-4, 'the eval forward still runs on the old weights'
     for a, f in zip((after[0], after[1][0], after[2], after[3]), (fresh[0], fresh[1][0], fresh[2], fresh[3])):
         assert torch.equal(a, f)
+
+
+def test_transposed_weight_cache_survives_address_reuse():
+    """dgrad_gemm caches W^T per (address, version, shape).  A freed weight's address is handed to the next tensor of the
+    same size (version 0 again): the cache must not serve the old transpose for it.  An entry therefore pins
+    its weight - the address cannot come back while the entry lives."""
+    from mmmot_amd.backward import dgrad_gemm
+    from mmmot_amd.plan import RowTiles
+    c, base = get_case('s2_C_multiply_none')
+    eng = build_model(c, base, ops=TorchOps()).engine()
+    tiles = RowTiles([8], 'cpu')
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn(8, 16, generator=g)
+    for attempt in range(40):
+        W1 = torch.randn(16, 24, generator=g)
+        ptr = W1.data_ptr()
+        Y1 = torch.empty(8, 24)
+        dgrad_gemm(eng, W1, tiles, X, Y1)
+        assert torch.allclose(Y1, X @ W1, atol=1e-5)
+        del W1
+        W2 = torch.randn(16, 24, generator=g)   # without the pin: usually the address W1 just gave back
+        Y2 = torch.empty(8, 24)
+        dgrad_gemm(eng, W2, tiles, X, Y2)
+        assert torch.allclose(Y2, X @ W2, atol=1e-5), 'stale transposed weight served for a new tensor at a reused address'
+        assert W2.data_ptr() != ptr
+    assert len(eng._wt_cache) <= 32
