@@ -29,10 +29,27 @@ def _gn(x, sd, key, groups):
     return F.group_norm(x, groups, sd[key + '.weight'], sd[key + '.bias'], EPS)
 
 
-def vgg_stage(x, sd, stage, training=False):
+def _bn_buffers_after(x, sd, prefix, bn_stats, momentum=0.1):
+    """What a training-mode nn.BatchNorm{1,2}d forward leaves in its buffers (torch.nn.modules.batchnorm, the module the
+    reference builds at modules/vgg.py:75 / tracking_net.py:93,96 with the default momentum 0.1):
+    running <- (1 - m) running + m * (batch mean | UNBIASED batch variance), num_batches_tracked + 1."""
+    if bn_stats is None:
+        return
+    dims = [d for d in range(x.dim()) if d != 1]
+    n = x.numel() // x.shape[1]
+    with torch.no_grad():
+        mean = x.mean(dim=dims)
+        var = x.var(dim=dims, unbiased=False) * (n / max(n - 1, 1))
+        bn_stats[prefix + 'running_mean'] = (1 - momentum) * sd[prefix + 'running_mean'] + momentum * mean
+        bn_stats[prefix + 'running_var'] = (1 - momentum) * sd[prefix + 'running_var'] + momentum * var
+        bn_stats[prefix + 'num_batches_tracked'] = sd[prefix + 'num_batches_tracked'] + 1
+
+
+def vgg_stage(x, sd, stage, training=False, bn_stats=None):
     """One regrouped VGG16-BN stage: reference modules/appear_net.py:130-157 (regrouping),
     modules/vgg.py:67-80 (conv3x3 pad1 -> BatchNorm2d -> ReLU, 'M' = MaxPool 2x2).  ``training``: BatchNorm2d on the
-    statistics of the batch (the module under .train(), tracking_model.py:41-48) instead of the running buffers."""
+    statistics of the batch (the module under .train(), tracking_model.py:41-48) instead of the running buffers;
+    ``bn_stats`` (a dict) then receives the buffers the layer holds AFTER the forward."""
     layout = {0: [64, 64, 'M', 128, 128, 'M'], 1: [256, 256, 256, 'M'], 2: [512, 512, 512, 'M'],
               3: [512, 512, 512, 'M']}[stage]
     p = 'appearance.layers.%d.' % stage
@@ -45,6 +62,7 @@ def vgg_stage(x, sd, stage, training=False):
             x = F.conv2d(x, sd[p + '%d.weight' % idx], sd[p + '%d.bias' % idx], padding=1)
             b = p + '%d.' % (idx + 1)
             if training:
+                _bn_buffers_after(x, sd, b, bn_stats)
                 x = F.batch_norm(x, None, None, sd[b + 'weight'], sd[b + 'bias'], True, 0.0, EPS)
             else:
                 x = F.batch_norm(x, sd[b + 'running_mean'], sd[b + 'running_var'], sd[b + 'weight'], sd[b + 'bias'],
@@ -66,12 +84,12 @@ def skippool(x, sd, stage):
     return o.flatten(1)
 
 
-def appearance(crops, sd, keep=None, training=False):
+def appearance(crops, sd, keep=None, training=False, bn_stats=None):
     """reference modules/appear_net.py:166-190 (vgg + skippool path): L x 3 x S x S -> L x 512."""
     outs = []
     x = crops
     for s in range(4):
-        x = vgg_stage(x, sd, s, training)
+        x = vgg_stage(x, sd, s, training, bn_stats)
         if keep is not None:
             keep['vgg_stage%d' % s] = x
         outs.append(skippool(x, sd, s))
@@ -242,28 +260,31 @@ def tracking_forward(sd, cfg, dets, points, points_split, dets_split, keep=None,
 # Training step (reference tracking_model.py:50-66): training-mode forward + TrackingLoss.  Checker for
 # mmmot_amd/train.py / backward.py: torch.autograd through THESE functions (in float64) is the gradient reference.
 # ======================================================================================================================
-def det_head_train(feats, sd):
+def det_head_train(feats, sd, bn_stats=None):
     """reference modules/tracking_net.py:91-100 + 149-151 with ``self.training``: BatchNorm1d on the statistics of the
     batch (the 3 modality rows x L positions of the one sample), raw scores (no sigmoid, no threshold mask)."""
     x = feats
     for i, bn in ((0, 1), (3, 4)):
         x = F.conv1d(x, sd['w_det.%d.weight' % i], sd['w_det.%d.bias' % i])
+        _bn_buffers_after(x, sd, 'w_det.%d.' % bn, bn_stats)
         x = F.relu(F.batch_norm(x, None, None, sd['w_det.%d.weight' % bn], sd['w_det.%d.bias' % bn], True, 0.0, EPS))
     return F.conv1d(x, sd['w_det.6.weight'], sd['w_det.6.bias']).squeeze(1)
 
 
-def tracking_forward_train(sd, cfg, img_feats, points, points_split, dets_split, crops=None):
+def tracking_forward_train(sd, cfg, img_feats, points, points_split, dets_split, crops=None, bn_stats=None):
     """Training-mode ``TrackingNet.forward`` (reference modules/tracking_net.py:165-193 with ``self.training``): image
     encoder in training mode on ``crops`` (batch-statistics BatchNorm2d), or - ``crops`` None - GIVEN image features
     ``img_feats`` L x 512 (the product's frozen-image-branch mode); PointNet (GroupNorm only: identical in both modes),
-    fusion, training-mode w_det, the pairwise block; new / end scores are NOT padded in training mode (:190-192)."""
+    fusion, training-mode w_det, the pairwise block; new / end scores are NOT padded in training mode (:190-192).
+    ``bn_stats`` (a dict): receives the BatchNorm buffers (trunk and w_det) as the modules hold them after this forward.
+    Pinned to the imported reference's training step by oracle/gen_golden_train.py (tests/golden/train_*.npz)."""
     if crops is not None:
-        img_feats = appearance(crops, sd, training=True)
+        img_feats = appearance(crops, sd, training=True, bn_stats=bn_stats)
     split = points_split.reshape(-1).long()
     pts, trans = pointnet(points.transpose(-1, -2), split, sd)
     cat = torch.cat([img_feats, pts], dim=-1).t().unsqueeze(0)
     F3 = fusion(cat, sd, cfg['fusion'])
-    det = det_head_train(F3, sd)
+    det = det_head_train(F3, sd, bn_stats)
     counts = [int(c) for c in dets_split]
     links, news, ends = [], [], []
     start = 0

@@ -85,3 +85,73 @@ def compare_outputs(out, g, tol=TOL, rows=(0, 1, 2)):
     bad = {k: float(v) for k, v in errs.items() if not (v <= tol)}
     assert not bad, 'outputs differ from the reference golden by more than %.0e: %r (all: %r)' % (tol, bad, errs)
     return errs
+
+
+# ---- training-step fixtures of the IMPORTED reference (oracle/gen_golden_train.py) ----
+def train_case_names():
+    import glob
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, 'train_*.npz')))
+
+
+def load_train_case(name):
+    """-> (case dict, loss kwargs, fixture npz, inputs (dets, info, dets_split), gts (det, [link], new, end))"""
+    import ast
+    g = np.load(os.path.join(GOLD, name + '.npz'))
+    c = dict(ast.literal_eval(str(g['case'])))
+    kw = dict(ast.literal_eval(str(g['loss_kwargs'])))
+    if 'counts' in c:
+        dets, info, _ = make_pair(c['counts'][0], sum(c['counts'][1:]), c['S'], c['pts'], c['seed'], ragged=True)
+        ds = [torch.tensor([x]) for x in c['counts']]
+    else:
+        dets, info, ds = make_pair(c['N'], c['M'], c['S'], c['pts'], c['seed'], True)
+    n = len(ds) - 1
+    t = lambda k: torch.from_numpy(g[k])
+    gts = (t('gt_det'), [t('gt_link%d' % i) for i in range(n)], t('gt_new'), t('gt_end'))
+    return c, kw, g, (dets, info, ds), gts
+
+
+def compare_train_step(g, outs, loss, grad_of, buffers, out_tol, loss_tol, grad_tol, norm_tol, bn_tol, what):
+    """One training step against a reference fixture.  outs = (det, [links], new, end, trans); grad_of(key) -> gradient
+    tensor (or None = zero); buffers: key -> tensor for the 'bn:' entries.  Gradients are compared relative to the
+    largest entry of the REFERENCE's gradient tensor (grad_norms[:, 2]); tensors whose reference gradient is rounding
+    residue (< 1e-5: biases in front of a normalisation, the STN layers behind the one-value-per-group GroupNorm) must
+    stay below 1e-4 absolutely.  Returns a dict of the worst differences."""
+    det, links, new, end, trans = outs
+    f = lambda x: x.detach().cpu().double().numpy()
+    worst = dict(det=np.abs(f(det) - g['det']).max(), new=np.abs(f(new) - g['new']).max(), end=np.abs(f(end) - g['end']).max(),
+                 link=max(np.abs(f(l) - g['link%d' % i]).max() for i, l in enumerate(links)),
+                 trans=max(np.abs(f(trans[0]) - g['trans1']).max(), np.abs(f(trans[1]) - g['trans2']).max()),
+                 loss=abs(float(loss) - float(g['loss'])))
+    assert max(worst[k] for k in ('det', 'new', 'end', 'link', 'trans')) < out_tol, (what, worst)
+    assert worst['loss'] < loss_tol * max(1.0, abs(float(g['loss']))), (what, worst)
+    keys = [str(k) for k in g['grad_keys']]
+    norms = {k: g['grad_norms'][i] for i, k in enumerate(keys)}
+    sl, nm, res = 0.0, 0.0, 0.0
+    for name in g.files:
+        if not name.startswith('g:'):
+            continue
+        k = name[2:]
+        want = g[name]
+        got = grad_of(k)
+        got = np.zeros_like(want) if got is None else f(got)[:want.shape[0]]
+        sl = max(sl, np.abs(got - want).max() / norms[k][2])
+    for k in keys:
+        got = grad_of(k)
+        got = None if got is None else f(got)
+        s1, s2, amax = norms[k]
+        if amax < 1e-5:
+            if got is not None:
+                res = max(res, np.abs(got).max())
+            continue
+        assert got is not None, (what, k, 'no gradient')
+        nm = max(nm, abs(np.sqrt((got ** 2).sum()) - np.sqrt(s2)) / np.sqrt(s2), abs(np.abs(got).max() - amax) / amax)
+    worst.update(grad_slices=sl, grad_norms=nm, grad_residue=res)
+    assert sl < grad_tol and nm < norm_tol and res < 1e-4, (what, worst)
+    bn = 0.0
+    for name in g.files:
+        if name.startswith('bn:'):
+            got = buffers[name[3:]].detach().cpu().double().numpy()
+            bn = max(bn, np.abs(got - g[name]).max())
+    worst['bn_buffers'] = bn
+    assert bn < bn_tol, (what, worst)
+    return worst

@@ -45,3 +45,38 @@ def test_oracle_loss_matches_the_reference_fixture(name):
             list(zip(trans, ref['trans'])):
         g = got.grad if got.grad is not None else torch.zeros_like(got)
         assert (g - want).abs().max().item() < 1e-7
+
+
+# ---- the training-mode forward and its gradients against the IMPORTED reference's training step ----
+from common import compare_train_step, load_train_case, train_case_names  # noqa: E402
+from mmmot_amd.weights import generate_state_dict  # noqa: E402
+from common import build_model  # noqa: E402
+
+
+def test_train_fixtures_exist():
+    names = train_case_names()
+    assert len(names) >= 3 and any('3frames' in n for n in names) and any(n.endswith('_C') for n in names)
+
+
+@pytest.mark.parametrize('name', train_case_names())
+def test_oracle_training_step_matches_the_reference_fixture(name):
+    """tracking_forward_train (batch-statistics BatchNorm in the trunk and w_det, unpadded new / end) + tracking_loss,
+    differentiated by autograd, on the fixture's sample: outputs, loss, every gradient's norm, element-wise slices, and the
+    BatchNorm buffers after the forward - all from the reference's own training step (tracking_model.py:50-66)."""
+    c, kw, g, (dets, info, ds), gts = load_train_case(name)
+    counts = [int(d) for d in ds]
+    base = dict(c, fusion=c['fusion'], aff=c['aff'], sm=c['sm'])
+    from common import manifest
+    m = build_model(base, manifest()['base_kwargs'])  # the mirror module: only its state_dict (generated weights) is used
+    sd = {k: (v.detach().clone().requires_grad_(True) if v.dtype.is_floating_point and not k.endswith('idt')
+              and 'running_' not in k else v.detach().clone()) for k, v in m.state_dict().items()}
+    cfg = dict(fusion=c['fusion'], affinity_op=c['aff'], softmax_mode=c['sm'])
+    stats = {}
+    det, links, new, end, trans = R.tracking_forward_train(sd, cfg, None, info['points'], info['points_split'], counts,
+                                                           crops=dets, bn_stats=stats)
+    loss = R.tracking_loss(counts, gts[0], gts[1], gts[2], gts[3], det, links, new, end, trans, **kw)
+    loss.backward()
+    worst = compare_train_step(g, (det, links, new, end, trans), loss.item(),
+                               lambda k: sd[k].grad if sd[k].requires_grad else None, stats,
+                               out_tol=5e-5, loss_tol=2e-6, grad_tol=1e-3, norm_tol=1e-3, bn_tol=1e-5, what=name)
+    print('%s: oracle vs the reference training step: %s' % (name, ' '.join('%s=%.1e' % kv for kv in worst.items())))
