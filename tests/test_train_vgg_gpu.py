@@ -187,3 +187,20 @@ def test_eval_after_training_uses_the_updated_weights():
               (out[2].cpu() - ref[2]).abs().max().item(), (out[3].cpu() - ref[3]).abs().max().item())
     assert err < 1e-3, err
     assert (out[1][0] - before).abs().max().item() > 1e-4   # and it is not the forward of the initial weights
+
+
+# ---- the device's training step against the IMPORTED reference's (fixtures of oracle/gen_golden_train.py) ----
+from common import compare_train_step, train_case_names  # noqa: E402
+from test_train_vgg_cpu import product_train_step  # noqa: E402
+
+
+@pytest.mark.parametrize('name', train_case_names())
+def test_device_training_step_matches_the_reference_fixture(name):
+    """scores, loss, gradients (norm of every tensor + element-wise slices) and the BatchNorm buffers of one training step
+    on the device against what the imported reference produced for the same sample (tracking_model.py:50-66,
+    cost.py:134-185).  Gradient tolerance: the reference's own fp32 noise on the first trunk layers is 0.4 - 0.7 %
+    (tests/test_train_vgg_cpu.py); scores within the north-star 1e-3."""
+    g, outs, loss, grad_of, buffers = product_train_step(name, device=DEV)
+    worst = compare_train_step(g, outs, loss, grad_of, buffers, out_tol=3e-4, loss_tol=1e-4, grad_tol=3e-2, norm_tol=2e-2,
+                               bn_tol=5e-5, what=name)
+    print('%s: device vs the reference training step: %s' % (name, ' '.join('%s=%.1e' % kv for kv in worst.items())))
