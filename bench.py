@@ -551,11 +551,22 @@ def main():
         mdl.set_trunk(trunk)
         eng = mdl.engine()
 
-        def step():
-            res = mdl.forward_batch(plan_, crops_, points_)
-            if not args.no_gather:
-                res = gather_results(res, same_layout=True, force=args.force_dist)  # trivial for one process
+        gather_ev = []  # HIP events around the result gather of every timed step (N-rank runs: where the time goes)
+
+        def gathered(res):
+            if args.no_gather:
+                return res
+            if not dist_on:
+                return gather_results(res, same_layout=True)  # trivial for one process
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            res = gather_results(res, same_layout=True, force=args.force_dist)
+            e1.record()
+            gather_ev.append((e0, e1))
             return res
+
+        def step():
+            return gathered(mdl.forward_batch(plan_, crops_, points_))
 
         for _ in range(warmup):
             step()
@@ -564,14 +575,13 @@ def main():
             graphed = mdl.capture(plan_, crops_, points_)
 
             def step():  # noqa: F811
-                res = graphed(crops_, points_)
-                if not args.no_gather:
-                    res = gather_results(res, same_layout=True, force=args.force_dist)
-                return res
+                return gathered(graphed(crops_, points_))
             step()
         eng.conv_events = []
+        del gather_ev[:]
         dt, res = time_steps(step, steps, barrier)
         events, eng.conv_events = eng.conv_events, None
+        dt_own = dt
         dt = max_over_ranks(dt, world, dev)
         roof, layers = roofline_of(trunk, events, eng, wl['B'], wl['name'], dt, wl['rows'])
         N_, M_, S_, pts_, fusion_ = wl['shape']
@@ -582,6 +592,15 @@ def main():
                'exec_tflops_equiv_per_gpu': round(fexec * value / 1e12 / world, 2)}
         if trunk == 'f16x3':
             leg['whole_step_frac_of_f16x3_peak'] = round(fexec * value / 1e12 / world / (PEAK_F16_MFMA_TFLOPS / 3.0), 4)
+        if dist_on:
+            # every rank's own wall time per step and the device time of its result gather (pack + RCCL all_gather +
+            # unpack, HIP events): `value` uses the MAX over ranks; this shows which rank and which part set it
+            import torch.distributed as dist
+            gus = (sum(e0.elapsed_time(e1) for e0, e1 in gather_ev) / max(len(gather_ev), 1)) * 1e3 if gather_ev else 0.0
+            mine = [round(dt_own / steps * 1e3, 3), round(gus, 1)]
+            allr = [None] * world
+            dist.all_gather_object(allr, mine)
+            leg['per_rank'] = {'ms_per_step': [x[0] for x in allr], 'gather_us_per_step': [x[1] for x in allr]}
         if rank == 0 and wl['gold'] is not None:
             leg['linf_vs_reference_golden'] = golden_linf(res[0], wl['gold'], wl['rows'])
         return leg, res, layers
@@ -611,6 +630,8 @@ def main():
                      'whole-step fraction = F_exec x pairs/s / GPU / (2500/3) - north_star target >= 0.50'},
         'parity': {'tolerance': 1e-3},
     }
+    if 'per_rank' in head:
+        out['per_rank'] = head['per_rank']
     if head.get('linf_vs_reference_golden') is not None:
         out['parity']['linf_vs_reference_golden'] = head['linf_vs_reference_golden']
         out['parity']['golden'] = ('tests/golden/%s.npz (output of the imported reference on the first pair of the batch)'

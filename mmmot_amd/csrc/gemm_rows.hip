@@ -240,16 +240,19 @@ __global__ __launch_bounds__(MM_THREADS, 2) void gemm_rows_kernel(mmmot_gemm_arg
   //   part[t][1][n] = M2 = sum_r (v[r][n] - S/nrows)^2
   // mmmot_gn_finalize merges the tiles with the parallel-variance formula of Chan et al. in fp64.
   const float oscale = F16 ? a.oscale : 1.f;
-  float* red = smem;                 // [WM][BN] per-wave column partials (LDS reuse: all waves are past the last stage)
-  float* colmean = smem + WM * BN;   // [BN]
+  // Order of the sums (shared with gemm_wide.hip, which must reproduce part[] bit for bit): per 32-row block of the tile the
+  // lane's 16 values in register order, then its two lane halves; per tile (s0 + s1) + (s2 + s3) over the four blocks.
+  float* red = smem;                 // [4 row blocks][BN] column partials (LDS reuse: all waves are past the last stage)
+  float* colmean = smem + 4 * BN;    // [BN]
+  static_assert(WM * TM == 4, "four 32-row blocks per tile");
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int cl = wn * TN * 32 + tn * 32 + (lane & 31);  // column inside the tile
     const int n = n0 + cl;
     const float bv = a.bias ? a.bias[n] : 0.f;
-    float s1 = 0.f;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
+      float s1 = 0.f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int r = wm * TM * 32 + tm * 32 + mm_acc_row(e, lane);
@@ -263,18 +266,16 @@ __global__ __launch_bounds__(MM_THREADS, 2) void gemm_rows_kernel(mmmot_gemm_arg
           }
         }
       }
-    }
-    if (a.part) {
-      s1 = mm_xor32_sum(s1);
-      if (lane < 32) red[wm * BN + cl] = s1;
+      if (a.part) {
+        s1 = mm_xor32_sum(s1);
+        if (lane < 32) red[(wm * TM + tm) * BN + cl] = s1;
+      }
     }
   }
   if (a.part) {
     __syncthreads();
     for (int cl = tid; cl < BN; cl += MM_THREADS) {
-      float s = 0.f;
-#pragma unroll
-      for (int w = 0; w < WM; ++w) s += red[w * BN + cl];
+      const float s = (red[cl] + red[BN + cl]) + (red[2 * BN + cl] + red[3 * BN + cl]);
       a.part[((long)t * 2 + 0) * a.N + n0 + cl] = s;
       colmean[cl] = s / (float)nrows;
     }
@@ -283,26 +284,24 @@ __global__ __launch_bounds__(MM_THREADS, 2) void gemm_rows_kernel(mmmot_gemm_arg
     for (int tn = 0; tn < TN; ++tn) {
       const int cl = wn * TN * 32 + tn * 32 + (lane & 31);
       const float mu = colmean[cl];
-      float s2 = 0.f;
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) {
+        float s2 = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int r = wm * TM * 32 + tm * 32 + mm_acc_row(e, lane);
           if (r < nrows) {
             const float d = acc[tm][tn][e] - mu;
-            s2 += d * d;
+            s2 = fmaf(d, d, s2);
           }
         }
+        s2 = mm_xor32_sum(s2);
+        if (lane < 32) red[(wm * TM + tm) * BN + cl] = s2;  // red[] was consumed before the barrier above
       }
-      s2 = mm_xor32_sum(s2);
-      if (lane < 32) red[wm * BN + cl] = s2;  // red[] was consumed before the barrier above
     }
     __syncthreads();
     for (int cl = tid; cl < BN; cl += MM_THREADS) {
-      float s = 0.f;
-#pragma unroll
-      for (int w = 0; w < WM; ++w) s += red[w * BN + cl];
+      const float s = (red[cl] + red[BN + cl]) + (red[2 * BN + cl] + red[3 * BN + cl]);
       a.part[((long)t * 2 + 1) * a.N + n0 + cl] = s;
     }
   }
@@ -386,6 +385,9 @@ static int dispatch_gemm(const mmmot_gemm_args* a, hipStream_t s) {
   return MMMOT_EINVAL;
 }
 
+// gemm_wide.hip: the K >= 256 layers of the pairwise block on a batch that fills the chip
+int mmmot_gemm_wide_try(const mmmot_gemm_args* a, hipStream_t s, int* status);
+
 extern "C" int mmmot_gemm_rows(const mmmot_gemm_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!a || !a->W || a->T <= 0 || !a->tile_row0 || !a->tile_nrows) return MMMOT_EINVAL;
@@ -405,6 +407,8 @@ extern "C" int mmmot_gemm_rows(const mmmot_gemm_args* a, void* stream) {
   if (a->dbias && !a->rowidx) return MMMOT_EINVAL;
   if (a->colsum && (!a->osc || !a->osh)) return MMMOT_EINVAL;
   if (a->w_hl16 && a->Y && (a->ldy % 4 != 0 || !mm_al16(a->Y))) return MMMOT_EINVAL;
+  int status = MMMOT_OK;
+  if (mmmot_gemm_wide_try(a, s, &status)) return status;
   return a->w_hl16 ? dispatch_gemm<true>(a, s) : dispatch_gemm<false>(a, s);
 }
 

@@ -62,6 +62,21 @@ __global__ __launch_bounds__(GR_THREADS) void gram_rows_kernel(const float* __re
       for (int e = 0; e < 16; ++e) gs[a][b][e] = gc[a][b][e] = 0.f;
   float ss = 0.f, scc = 0.f;  // compensated column sum of channel `tid` (threads < K)
 
+  // The raw rows of sub-tile r0 + 128 are requested while sub-tile r0 is split, summed and multiplied: one workgroup per
+  // CU (the compensated Gram accumulators take 128 registers per lane), so nothing else would hide the load latency -
+  // round 3 measured 2.1 TB/s, a quarter of the HBM rate, with the latency exposed once per 128 rows.
+  f32x4 xr[CPT / 4][4];
+  auto load_rows = [&](int r0) {
+    const int nr = min(GR_ROWS, nrows - r0);
+#pragma unroll
+    for (int c4 = 0; c4 < CPT; c4 += 4)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const bool rv = sr4 + rr < nr;  // rows past the end read row 0 of the sub-tile (mapped) and are zeroed below
+        xr[c4 / 4][rr] = *reinterpret_cast<const f32x4*>(X + (long)(row0 + r0 + (rv ? sr4 + rr : 0)) * ldx + sq * CPT + c4);
+      }
+  };
+  load_rows(0);
   for (int r0 = 0; r0 < nrows; r0 += GR_ROWS) {
     const int nr = min(GR_ROWS, nrows - r0);
     // ---- stage: normalise + ReLU + hi/lo split, transposed into LDS ([channel][row]) ----
@@ -73,19 +88,12 @@ __global__ __launch_bounds__(GR_THREADS) void gram_rows_kernel(const float* __re
       for (int c4 = 0; c4 < CPT; c4 += 4) {
         const f32x4 s4 = *reinterpret_cast<const f32x4*>(ps + c4);
         const f32x4 h4 = *reinterpret_cast<const f32x4*>(ph + c4);
-        f32x4 x[4];
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const bool rv = sr4 + rr < nr;
-          x[rr] = *reinterpret_cast<const f32x4*>(X + (long)(row0 + r0 + (rv ? sr4 + rr : 0)) * ldx + sq * CPT + c4);
-          if (!rv) x[rr] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           f16x4 hi, lo;
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
-            float y = fminf(fmaxf(fmaf(x[rr][e], s4[e], h4[e]), 0.f), 65000.f);
+            float y = fminf(fmaxf(fmaf(xr[c4 / 4][rr][e], s4[e], h4[e]), 0.f), 65000.f);
             if (sr4 + rr >= nr) y = 0.f;  // rows past the end of the super-tile contribute nothing
             hi[rr] = (_Float16)y;
             lo[rr] = (_Float16)(y - (float)hi[rr]);
@@ -96,6 +104,7 @@ __global__ __launch_bounds__(GR_THREADS) void gram_rows_kernel(const float* __re
         }
       }
     }
+    if (r0 + GR_ROWS < nrows) load_rows(r0 + GR_ROWS);
     __syncthreads();
     // ---- column sums (deterministic order): thread c adds its channel's 128 rows, hi and lo ----
     if (tid < K) {

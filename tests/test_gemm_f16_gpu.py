@@ -76,3 +76,107 @@ def test_gemm_f16_pair(hip, pairop):
              part=pg, w_hl16=True, oscale=osc)
     close(Yg, Y, 3e-6, 'gemm f16x3 pair')
     close(pg[:, 0], part[:, 0], 1e-5, 'pair f16x3 tile sums')
+
+
+# ---- the wide kernel (csrc/gemm_wide.hip): A fragments generated in registers, 32 rows x 512 columns per wave ----
+@pytest.fixture
+def variants(hip):
+    from mmmot_amd import _lib
+    lib = _lib.load()
+    yield lib.mmmot_set_gemm_rows_variant
+    assert lib.mmmot_set_gemm_rows_variant(0) == 0
+
+
+def _pair_tables(tl, NM, aoff, boff, dev):
+    return dict(row0=torch.tensor(tl.cpu.h_g_row0).to(dev), M=torch.tensor([m for _, m in NM], dtype=torch.int32).to(dev),
+                aoff=torch.tensor(aoff, dtype=torch.int32).to(dev), boff=torch.tensor(boff, dtype=torch.int32).to(dev))
+
+
+@pytest.mark.parametrize('pairop', [0, 1, 2])
+@pytest.mark.parametrize('N,K,NM', [(1024, 512, [(5, 7), (130, 3), (64, 64)]), (512, 512, [(20, 33)]), (128, 512, [(9, 50)]),
+                                    (512, 64, [(40, 40), (1, 1)]), (1024, 128, [(128, 97)])])
+def test_gemm_wide_pair(hip, variants, pairop, N, K, NM):
+    """stacked pairwise layer (reference modules/gcn.py:59-82, new_end.py:48-52) on the wide kernel: fp64 statement, and
+    the tile kernel's Y bit for bit (same operand values, same accumulation order)"""
+    emu = TorchOps(torch.float64)
+    counts = [n * m for n, m in NM]
+    tl = DevTiles(counts)
+    nf = sum(n + m for n, m in NM)
+    Fm = rnd(nf + 3, 512, seed=240)
+    aoff, boff, o = [], [], 1
+    for n, m in NM:
+        aoff.append(o)
+        boff.append(o + n)
+        o += n + m
+    W = rnd(N, K, seed=241, scale=K ** -0.5)
+    bias = rnd(N, seed=242)
+    R = sum(counts)
+    Y, part = torch.zeros(R, N), torch.zeros(tl.cpu.T, 2, N)
+    emu.gemm(W, tl.cpu, N, K, FA=Fm, FB=Fm, pair=_pair_tables(tl, NM, aoff, boff, 'cpu'), amode=2, pairop=pairop, bias=bias,
+             Y=Y, part=part)
+    W16, osc = split_w(W)
+    Fg, Wg, bg, pt = Fm.cuda(), W16.cuda(), bias.cuda(), _pair_tables(tl, NM, aoff, boff, 'cuda')
+    outs = {}
+    for v in (2, 1):
+        assert variants(v) == 0
+        Yg, pg = torch.full((R + 1, N), float('nan')).cuda(), torch.full((tl.cpu.T, 2, N), float('nan')).cuda()
+        hip.gemm(Wg, tl.gpu, N, K, FA=Fg, FB=Fg, pair=pt, amode=2, pairop=pairop, bias=bg, Y=Yg, part=pg, w_hl16=True,
+                 oscale=osc)
+        assert torch.isnan(Yg[R]).all(), 'row beyond the last tile written'
+        outs[v] = (Yg[:R].cpu(), pg.cpu())
+    close(outs[2][0], Y, 3e-6, 'wide gemm pair Y')
+    close(outs[2][1][:, 0], part[:, 0], 1e-5, 'wide gemm pair tile sums')
+    close(outs[2][1][:, 1], part[:, 1], 1e-4, 'wide gemm pair tile M2')
+    assert torch.equal(outs[2][0], outs[1][0]), 'wide and tile kernels differ in Y'
+
+
+@pytest.mark.parametrize('N,K,ldx,counts', [(512, 512, 1024, [300, 5, 128, 1000]), (128, 512, 512, [77, 260]),
+                                            (1024, 256, 256, [129])])
+def test_gemm_wide_norm_relu(hip, variants, N, K, ldx, counts):
+    """the GroupNorm-fed layers behind it (w_link.conv1.3 / conv1.6, reference modules/gcn.py:61-65): strided input rows
+    (the conv1.0 half of the stacked layer's output), per-group scale / shift"""
+    emu = TorchOps(torch.float64)
+    tl = DevTiles(counts)
+    R, G = sum(counts), len(counts)
+    buf = rnd(R, ldx, seed=250)
+    X = buf[:, ldx - K:]
+    W = rnd(N, K, seed=251, scale=K ** -0.5)
+    bias = rnd(N, seed=252, scale=0.2)
+    sc, sh = rnd(G, K, seed=253).abs() + 0.5, rnd(G, K, seed=254)
+    Y, part = torch.zeros(R, N), torch.zeros(tl.cpu.T, 2, N)
+    emu.gemm(W, tl.cpu, N, K, X=X, bias=bias, Y=Y, part=part, sc=sc, sh=sh, amode=1)
+    W16, osc = split_w(W)
+    bufg = buf.cuda()
+    outs = {}
+    for v in (2, 1):
+        assert variants(v) == 0
+        Yg, pg = torch.full((R, N), float('nan')).cuda(), torch.full((tl.cpu.T, 2, N), float('nan')).cuda()
+        hip.gemm(W16.cuda(), tl.gpu, N, K, X=bufg[:, ldx - K:], bias=bias.cuda(), Y=Yg, part=pg, sc=sc.cuda(), sh=sh.cuda(),
+                 amode=1, w_hl16=True, oscale=osc)
+        outs[v] = (Yg.cpu(), pg.cpu())
+    close(outs[2][0], Y, 3e-6, 'wide gemm norm_relu Y')
+    close(outs[2][1][:, 0], part[:, 0], 1e-5, 'wide gemm norm_relu tile sums')
+    close(outs[2][1][:, 1], part[:, 1], 1e-4, 'wide gemm norm_relu tile M2')
+    assert torch.equal(outs[2][0], outs[1][0]), 'wide and tile kernels differ in Y'
+
+
+def test_gemm_wide_long_chains_are_deterministic(hip, variants):
+    """more items than workgroups (each persistent workgroup walks a chain of tiles, the successor's first weight stage and
+    source rows requested during the last stage): 40 000 pair rows x 1024 columns = 626 items on 256 CUs, repeated"""
+    NM = [(200, 200)]
+    tl = DevTiles([40000])
+    N, K = 1024, 512
+    Fm = rnd(400, K, seed=260).cuda()
+    W = rnd(N, K, seed=261, scale=K ** -0.5)
+    W16, osc = split_w(W)
+    pt = _pair_tables(tl, NM, [0], [200], 'cuda')
+    outs = []
+    for v in (1, 2, 2, 2):
+        assert variants(v) == 0
+        Yg, pg = torch.full((40000, N), float('nan')).cuda(), torch.full((tl.cpu.T, 2, N), float('nan')).cuda()
+        hip.gemm(W16.cuda(), tl.gpu, N, K, FA=Fm, FB=Fm, pair=pt, amode=2, pairop=0, Y=Yg, part=pg, w_hl16=True, oscale=osc)
+        outs.append((Yg, pg))
+    for Yg, pg in outs[1:]:
+        assert torch.equal(Yg, outs[0][0]), 'wide kernel (chained tiles) differs from the tile kernel'
+    assert torch.equal(outs[1][1], outs[2][1]) and torch.equal(outs[1][1], outs[3][1])
+    close(outs[1][1][:, 0].cpu(), outs[0][1][:, 0].cpu(), 1e-5, 'tile sums wide vs tile kernel')
