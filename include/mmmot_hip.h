@@ -186,6 +186,17 @@ int mmmot_conv3x3_first_hl16(const float* in, const float* wp, const float* bias
                              int L, int H, int W, int Cout, void* stream);
 int mmmot_hl16_pack(const float* x, void* y, long n, void* stream);
 int mmmot_hl16_unpack(const void* x, float* y, long n, void* stream);
+/* ABI 7, training step: y = hl16(x * 2^(target - ex)) with max |x| = amax[0] = f * 2^ex, f in [0.5, 1) - a DEVICE scalar
+ * (mmmot_absmax), NULL = unscaled; and the vector out[0..C) = 2^-(shift_a + shift_b) that undoes two such scales in the
+ * consumer's epilogue.  No host round trip: gradients (1e-4 .. 1e-7) and freshly stepped weights are scaled where they are. */
+int mmmot_hl16_pack_pow2(const float* x, void* y, long n, const float* amax, int target, void* stream);
+int mmmot_pow2_oscale(float* out, int C, const float* amax_a, int target_a, const float* amax_b, int target_b, void* stream);
+/* ABI 7, training step: the plain 3x3 convolution out[p][n] = oscale[n] * sum_taps in[p + off] . wp[tap][n] + bias[n] as
+ * fp32 rows [L*H*W][Cout] (no BatchNorm, no ReLU: the training-mode forward of /root/reference/modules/vgg.py:74-76 keeps
+ * the pre-BatchNorm tensor, and the input gradient is the same convolution of dZ with the flipped, transposed weights) on
+ * the fp16 matrix cores (f16x3): in = hl16 rows [L*H*W][Cin], wp = hl16 [9][Cout][Cin].  Cin % 32 == 0, Cout % 64 == 0. */
+int mmmot_conv3x3_raw_hl16(const void* in, const void* wp, const float* bias, float* out, int L, int H, int W, int Cin,
+                           int Cout, const float* oscale, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Row GEMM with fused operand generation and statistics epilogue:
@@ -547,6 +558,11 @@ int mmmot_maxpool_bwd(const float* Z, int C, const float* sc, const float* sh, c
  * (zero padding); nsplit shares, the caller adds them.  Cin % 64 == 0, Cout % 64 == 0. */
 int mmmot_conv3x3_wgrad(const float* dZ, const float* A, int L, int H, int W, int Cin, int Cout, int nsplit, float* dW,
                         void* stream);
+/* ABI 7.  The same weight gradient on the fp16 matrix cores (3-term hi/lo split, the pixel axis as the K of the MFMA like
+ * mmmot_gemm_tn_f16): dZ is scaled by the power of two that puts dzamax[0] = max |dZ| (device scalar, mmmot_absmax; NULL =
+ * no scaling) at 2^10 and the result scaled back exactly.  Same output layout; fp32-class (products exact to 2^-22). */
+int mmmot_conv3x3_wgrad_f16(const float* dZ, const float* A, int L, int H, int W, int Cin, int Cout, int nsplit, float* dW,
+                            const float* dzamax, void* stream);
 /* first layer (NCHW crops X [L][3][H][W], Cout = 64): PW[b][co][28] partial sums over block b's pixels of
  * (dW1[co][k = tap * 3 + colour], k < 27 | db1[co]); the caller adds the nblocks partials. */
 int mmmot_conv3x3_first_wgrad(const float* dZ, const float* X, int L, int H, int W, float* PW, int nblocks, void* stream);

@@ -103,6 +103,9 @@ SIGNATURES = {
     'mmmot_trunk_range_bind': [c_f],
     'mmmot_hl16_pack': [c_f, c_f, ctypes.c_long, c_f],
     'mmmot_hl16_unpack': [c_f, c_f, ctypes.c_long, c_f],
+    'mmmot_hl16_pack_pow2': [c_f, c_f, ctypes.c_long, c_f, c_i, c_f],
+    'mmmot_pow2_oscale': [c_f, c_i, c_f, c_i, c_f, c_i, c_f],
+    'mmmot_conv3x3_raw_hl16': [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f],
     'mmmot_hq8_pack': [c_f, c_f, ctypes.c_long, c_f],
     'mmmot_hq8_unpack': [c_f, c_f, ctypes.c_long, c_f],
     'mmmot_rowdot': [c_f, c_i, c_i, c_f, ctypes.c_float, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i,
@@ -140,6 +143,7 @@ SIGNATURES = {
     'mmmot_bn_relu_pool': [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f],
     'mmmot_maxpool_bwd': [c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f],
     'mmmot_conv3x3_wgrad': [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f],
+    'mmmot_conv3x3_wgrad_f16': [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     'mmmot_conv3x3_first_wgrad': [c_f, c_f, c_i, c_i, c_i, c_f, c_i, c_f],
     'mmmot_rows_gather_scale': [c_f, c_i, c_f, c_f, c_f, c_i, ctypes.c_long, c_i, c_f],
     'mmmot_pointnet_layer1_bwd': [c_f, c_f, c_i, c_f, c_f, c_i, c_f, c_f],

@@ -212,12 +212,15 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 #define Q8_SCALE_A 124   // E8M0 exponent of the block scale 2^-3 = 2^-11 (lo) * 2^2 (activation copies) * 2^6 (weight copies)
 #define Q8_SCALE_B 127
 
-template <int BN, int BS, bool POOL, int EXP, bool FUSE1 = false, bool Q8 = false>
+// RAW (training, mmmot_conv3x3_raw_hl16): the output is the plain convolution  acc * oscale + bias  as fp32 rows (8 floats
+// where an inference launch writes one [hi8 | lo8] unit: the same bytes at the same place) - no ReLU, no clamp, no split.
+template <int BN, int BS, bool POOL, int EXP, bool FUSE1 = false, bool Q8 = false, bool RAW = false>
 __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
     const u32x4* __restrict__ in, const u32x4* __restrict__ wp, const float* __restrict__ bias,
     u32x4* __restrict__ out, int L, int H, int W, int Cin, int Cout, int nby, int nbx, int nblk, int ntm, int ntn,
     const float* __restrict__ oscv, Fuse1Args fz, unsigned int* __restrict__ rng) {
   static_assert(!FUSE1 || (BN == 64 && BS == 16), "the fused first layer exists for 64-channel 16x16 tiles");
+  static_assert(!RAW || (!POOL && !FUSE1 && !Q8), "raw fp32 output: plain unpooled f16x3 layers");
   using G = PatchGeom<BS>;
   constexpr int WN = (BN == 128) ? 2 : 1;  // waves along channels
   constexpr int WM = 8 / WN;               // waves along pixels
@@ -1319,16 +1322,23 @@ __global__ __launch_bounds__(512) void conv3x3_hl16_patch_kernel(
       PT_BLK_PIXEL(blk, y, x)
       if (crop >= 0 && gy < H && gx < W) {
         f32x8 v = *reinterpret_cast<const f32x8*>(&Cs[rl * CLD + eu * 8]);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], sv[e], bv[e]), 0.f);
-        {
-          float vg[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) vg[e] = v[e];
-          pt_range_guard<8>(vg, false, rng);
-        }
         u32x4 hi, lo;
-        pt_split8(v, hi, lo);
+        if constexpr (RAW) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], sv[e], bv[e]);
+          hi = __builtin_bit_cast(u32x4, f32x4{v[0], v[1], v[2], v[3]});
+          lo = __builtin_bit_cast(u32x4, f32x4{v[4], v[5], v[6], v[7]});
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], sv[e], bv[e]), 0.f);
+          {
+            float vg[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vg[e] = v[e];
+            pt_range_guard<8>(vg, false, rng);
+          }
+          pt_split8(v, hi, lo);
+        }
         const long pix = ((long)crop * H + gy) * W + gx;
         u32x4* o = out + (pix * cout8 + (n0 >> 3) + eu) * 2;
         if constexpr (EXP == 16) {
@@ -1486,7 +1496,7 @@ static bool pt_use_bn64(int L, int H, int W, int Cout) {
   return 0.85 * eff(i64) > eff(i128);  // a 64-channel tile does half the work of a 128-channel one in ~0.59 of the time
 }
 
-template <int BN, int BS, bool POOL, int EXP, bool FUSE1 = false, bool Q8 = false>
+template <int BN, int BS, bool POOL, int EXP, bool FUSE1 = false, bool Q8 = false, bool RAW = false>
 static int launch_patch_e(const void* in, const void* wp, const float* bias, void* out, int L, int H, int W, int Cin,
                         int Cout, const float* oscale, hipStream_t s, Fuse1Args fz = Fuse1Args{nullptr, nullptr, nullptr, 1.f, nullptr, {0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}}) {
   const int nby = (H + BS - 1) / BS, nbx = (W + BS - 1) / BS;
@@ -1503,7 +1513,7 @@ static int launch_patch_e(const void* in, const void* wp, const float* bias, voi
   if (grid > ((nitems + 7) / 8) * 8) grid = ((nitems + 7) / 8) * 8;
   unsigned int* rng = pt_range_block();
   if (!rng) return MMMOT_EINVAL;
-  hipLaunchKernelGGL((conv3x3_hl16_patch_kernel<BN, BS, POOL, EXP, FUSE1, Q8>), dim3(grid), dim3(512), 0, s,
+  hipLaunchKernelGGL((conv3x3_hl16_patch_kernel<BN, BS, POOL, EXP, FUSE1, Q8, RAW>), dim3(grid), dim3(512), 0, s,
                      (const u32x4*)in, (const u32x4*)wp, bias, (u32x4*)out, L, H, W, Cin, Cout, nby, nbx, nblk, ntm, ntn,
                      oscale, fz, rng);
   return mm_check(hipGetLastError());
@@ -1557,6 +1567,24 @@ extern "C" int mmmot_conv3x3_bn_relu_hl16_patch(const void* in, const void* wp, 
   return bs == 16 ? launch_patch_p<64, 16>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s)
          : bs == 8 ? launch_patch_p<64, 8>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s)
                    : launch_patch_p<64, 4>(pool, in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
+}
+
+// Training (mmmot_amd/train_vgg.py): the plain convolution out[p][n] = oscale[n] * sum in * wp + bias[n] as fp32 rows
+// [L * H * W][Cout] - the f16x3 counterpart of mmmot_conv3x3_raw for the training-mode forward (in = hl16 activations)
+// and for the input gradient (in = hl16 of the scaled dZ, wp = flipped / transposed weights, oscale carrying both
+// power-of-two scales back).  Same geometry dispatch and accumulation order as the inference launch.
+extern "C" int mmmot_conv3x3_raw_hl16(const void* in, const void* wp, const float* bias, float* out, int L, int H, int W,
+                                      int Cin, int Cout, const float* oscale, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!in || !wp || !bias || !out || !oscale || L <= 0 || H <= 0 || W <= 0) return MMMOT_EINVAL;
+  if (Cin % 32 != 0 || Cout % 64 != 0) return MMMOT_EINVAL;
+  if (!mm_al16(in) || !mm_al16(wp) || !mm_al16(out)) return MMMOT_EINVAL;
+  if ((long)L * H * W * (Cin / 4) >= (1L << 31) - 64) return MMMOT_EINVAL;
+  const int bs = pt_block_edge(H, W);
+#define PT_RAW(BNV, BSV) launch_patch_e<BNV, BSV, false, 0, false, false, true>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s)
+  if (!pt_use_bn64(L, H, W, Cout)) return bs == 16 ? PT_RAW(128, 16) : bs == 8 ? PT_RAW(128, 8) : PT_RAW(128, 4);
+  return bs == 16 ? PT_RAW(64, 16) : bs == 8 ? PT_RAW(64, 8) : PT_RAW(64, 4);
+#undef PT_RAW
 }
 
 // conv1_1 (3 -> 64) + conv1_2 (64 -> 64) + 2x2 max-pool in one kernel: see FUSE1 above.

@@ -67,3 +67,55 @@ extern "C" int mmmot_hl16_unpack(const void* x, float* y, long n, void* stream) 
                      (const u32x4*)x, y, nu);
   return mm_check(hipGetLastError());
 }
+
+// ---------------------------------------------------------------------------
+// Device-side power-of-two scaling for the training step (no host round trip): a tensor whose magnitude is only known
+// on the device (a gradient: 1e-4 .. 1e-7; freshly updated weights) is multiplied by 2^(target - ex), amax = f * 2^ex
+// with f in [0.5, 1), before the split, so that its lo halves stay normal fp16 numbers; mmmot_pow2_oscale builds the
+// per-output-channel vector the consuming kernel multiplies its accumulators with to undo the scale(s) exactly.
+__device__ __forceinline__ int hl_pow2_shift(const float* amax, int target) {
+  const float a = amax ? *amax : 0.f;
+  int ex = 0;
+  if (a > 0.f) (void)frexpf(a, &ex);
+  return a > 0.f ? target - ex : 0;
+}
+
+__global__ void hl16_pack_pow2_kernel(const float* __restrict__ x, u32x4* __restrict__ y, long nunits,
+                                      const float* __restrict__ amax, int target) {
+  const float sd = ldexpf(1.f, hl_pow2_shift(amax, target));
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nunits; i += (long)gridDim.x * blockDim.x) {
+    f32x8 v = *reinterpret_cast<const f32x8*>(x + i * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= sd;
+    u32x4 hi, lo;
+    hl_split8(v, hi, lo);
+    y[i * 2] = hi;
+    y[i * 2 + 1] = lo;
+  }
+}
+
+// y = hl16(x * 2^(target - ex(amax[0]))); amax: device scalar (mmmot_absmax), NULL = no scaling.  n % 8 == 0.
+extern "C" int mmmot_hl16_pack_pow2(const float* x, void* y, long n, const float* amax, int target, void* stream) {
+  if (!x || !y || n <= 0 || n % 8 != 0 || !mm_al16(x) || !mm_al16(y) || target < -60 || target > 15) return MMMOT_EINVAL;
+  const long nu = n / 8;
+  const long nb = (nu + 255) / 256;
+  hipLaunchKernelGGL(hl16_pack_pow2_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, (hipStream_t)stream, x,
+                     (u32x4*)y, nu, amax, target);
+  return mm_check(hipGetLastError());
+}
+
+__global__ void pow2_oscale_kernel(float* __restrict__ out, int C, const float* __restrict__ amax_a, int target_a,
+                                   const float* __restrict__ amax_b, int target_b) {
+  const float v = ldexpf(1.f, -(hl_pow2_shift(amax_a, target_a) + hl_pow2_shift(amax_b, target_b)));
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) out[c] = v;
+}
+
+// out[0..C) = 2^-(shift_a + shift_b): the inverse of the scales mmmot_hl16_pack_pow2 applied with the same (amax, target)
+// pairs (either may be NULL = unscaled operand)
+extern "C" int mmmot_pow2_oscale(float* out, int C, const float* amax_a, int target_a, const float* amax_b, int target_b,
+                                 void* stream) {
+  if (!out || C <= 0) return MMMOT_EINVAL;
+  hipLaunchKernelGGL(pow2_oscale_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, C, amax_a, target_a,
+                     amax_b, target_b);
+  return mm_check(hipGetLastError());
+}

@@ -200,6 +200,184 @@ extern "C" int mmmot_conv3x3_wgrad(const float* dZ, const float* A, int L, int H
   return mm_check(hipGetLastError());
 }
 
+// ---- the same weight gradient on the fp16 matrix cores (3-term hi/lo split), round 4 ----
+// The fp32 kernel above feeds v_mfma_f32_32x32x2_f32 two pixels per instruction from two scalar global loads per lane and
+// re-reads dZ / A once per (channel tile, tap): it is load-latency-bound and was most of the 63 ms of the whole-network
+// backward (round 3).  Here, like gemm_tn_f16.hip: a chunk of 128 pixels of dZ (TN output channels, scaled by the power of
+// two that puts max |dZ| at 2^10 - gradients sit in fp16's subnormals otherwise) and of the tap-shifted, image-masked A
+// (TK input channels) is staged TRANSPOSED into LDS as hi / lo fp16 planes ([channel][pixel]), the pixel axis is the
+// K = 16 of v_mfma_f32_32x32x16_f16, 4 waves own 2 x 2 quadrants of the TN x TK tile.  grid = (Cout / TN, Cin / TK,
+// 9 * nsplit); partial dW per pixel share like the fp32 kernel (same layout: [share][tap][Cout][Cin]).
+typedef _Float16 wg_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 wg_f16x4 __attribute__((ext_vector_type(4)));
+#define WG_ROWS 128
+#define WG_LD 136
+
+template <int TN, int TK>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_f16_kernel(const float* __restrict__ dZ, const float* __restrict__ A,
+                                                                int L, int H, int W, int Cin, int Cout, int nsplit,
+                                                                float* __restrict__ dW, const float* __restrict__ dzamax) {
+  constexpr int WN = TN / 64, WK = TK / 64;
+  __shared__ __attribute__((aligned(16))) _Float16 Dh[TN * WG_LD];
+  __shared__ __attribute__((aligned(16))) _Float16 Dl[TN * WG_LD];
+  __shared__ __attribute__((aligned(16))) _Float16 Ah[TK * WG_LD];
+  __shared__ __attribute__((aligned(16))) _Float16 Al[TK * WG_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1;
+  const int lr = lane & 31, kh = (lane >> 5) * 8;
+  const int n0 = blockIdx.x * TN, k0 = blockIdx.y * TK;
+  const int tap = blockIdx.z / nsplit, share = blockIdx.z - tap * nsplit;
+  const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+  const float amax = dzamax ? *dzamax : 0.f;
+  int ex = 0;
+  if (amax > 0.f) (void)frexpf(amax, &ex);
+  const int shift = amax > 0.f ? 11 - ex : 0;
+  const float sd = ldexpf(1.f, shift), inv_sd = ldexpf(1.f, -shift);
+  const long P = (long)L * H * W;
+  const long nchunk = (P + WG_ROWS - 1) / WG_ROWS;
+  const long c_lo = nchunk * share / nsplit, c_hi = nchunk * (share + 1) / nsplit;
+  const int HW = H * W;
+
+  f32x16 tot[WN][WK];
+#pragma unroll
+  for (int x = 0; x < WN; ++x)
+#pragma unroll
+    for (int y = 0; y < WK; ++y)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) tot[x][y][e] = 0.f;
+  const int sr4 = (tid >> 3) * 4, sq = tid & 7;
+  constexpr int CPN = TN / 8, CPK = TK / 8;
+
+  for (long c = c_lo; c < c_hi; ++c) {
+    const long p0 = c * WG_ROWS;
+    long prow[4], arow[4];
+    bool pv[4], av[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const long p = p0 + sr4 + rr;
+      pv[rr] = p < P;
+      prow[rr] = pv[rr] ? p : p0;
+      const int rem = (int)(prow[rr] % HW);
+      const int y = rem / W, x = rem - y * W;
+      av[rr] = pv[rr] && (unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W;
+      arow[rr] = av[rr] ? prow[rr] + (long)dy * W + dx : prow[rr];
+    }
+#pragma unroll
+    for (int c4 = 0; c4 < CPN; c4 += 4) {
+      f32x4 x[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        x[rr] = *reinterpret_cast<const f32x4*>(dZ + prow[rr] * Cout + n0 + sq * CPN + c4);
+        if (!pv[rr]) x[rr] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        wg_f16x4 hi, lo;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const float yv = x[rr][e] * sd;
+          hi[rr] = (_Float16)yv;
+          lo[rr] = (_Float16)(yv - (float)hi[rr]);
+        }
+        const int ch = sq * CPN + c4 + e;
+        *reinterpret_cast<wg_f16x4*>(&Dh[ch * WG_LD + sr4]) = hi;
+        *reinterpret_cast<wg_f16x4*>(&Dl[ch * WG_LD + sr4]) = lo;
+      }
+    }
+#pragma unroll
+    for (int c4 = 0; c4 < CPK; c4 += 4) {
+      f32x4 x[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        x[rr] = *reinterpret_cast<const f32x4*>(A + arow[rr] * Cin + k0 + sq * CPK + c4);
+        if (!av[rr]) x[rr] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        wg_f16x4 hi, lo;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const float yv = fminf(fmaxf(x[rr][e], -65000.f), 65000.f);
+          hi[rr] = (_Float16)yv;
+          lo[rr] = (_Float16)(yv - (float)hi[rr]);
+        }
+        const int ch = sq * CPK + c4 + e;
+        *reinterpret_cast<wg_f16x4*>(&Ah[ch * WG_LD + sr4]) = hi;
+        *reinterpret_cast<wg_f16x4*>(&Al[ch * WG_LD + sr4]) = lo;
+      }
+    }
+    __syncthreads();
+    f32x16 acc[WN][WK];
+#pragma unroll
+    for (int x = 0; x < WN; ++x)
+#pragma unroll
+      for (int y = 0; y < WK; ++y)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[x][y][e] = 0.f;
+#pragma unroll
+    for (int k16 = 0; k16 < WG_ROWS / 16; ++k16) {
+      wg_f16x8 dh[WN], dl[WN], ah[WK], al[WK];
+#pragma unroll
+      for (int x = 0; x < WN; ++x) {
+        const int off = ((wi * WN + x) * 32 + lr) * WG_LD + k16 * 16 + kh;
+        dh[x] = *reinterpret_cast<const wg_f16x8*>(&Dh[off]);
+        dl[x] = *reinterpret_cast<const wg_f16x8*>(&Dl[off]);
+      }
+#pragma unroll
+      for (int y = 0; y < WK; ++y) {
+        const int off = ((wj * WK + y) * 32 + lr) * WG_LD + k16 * 16 + kh;
+        ah[y] = *reinterpret_cast<const wg_f16x8*>(&Ah[off]);
+        al[y] = *reinterpret_cast<const wg_f16x8*>(&Al[off]);
+      }
+#pragma unroll
+      for (int x = 0; x < WN; ++x)
+#pragma unroll
+        for (int y = 0; y < WK; ++y) {
+          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dl[x], ah[y], acc[x][y], 0, 0, 0);
+          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh[x], al[y], acc[x][y], 0, 0, 0);
+          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh[x], ah[y], acc[x][y], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int x = 0; x < WN; ++x)
+#pragma unroll
+      for (int y = 0; y < WK; ++y)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tot[x][y][e] += acc[x][y][e];
+    __syncthreads();
+  }
+  float* out = dW + ((long)share * 9 + tap) * Cout * Cin;
+#pragma unroll
+  for (int x = 0; x < WN; ++x)
+#pragma unroll
+    for (int y = 0; y < WK; ++y)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = n0 + (wi * WN + x) * 32 + mm_acc_row(e, lane);
+        const int k = k0 + (wj * WK + y) * 32 + lr;
+        out[(long)n * Cin + k] = tot[x][y][e] * inv_sd;
+      }
+}
+
+// dzamax: device pointer to max |dZ| (mmmot_absmax), NULL = no scaling.  Same layout and contract as mmmot_conv3x3_wgrad.
+extern "C" int mmmot_conv3x3_wgrad_f16(const float* dZ, const float* A, int L, int H, int W, int Cin, int Cout, int nsplit,
+                                       float* dW, const float* dzamax, void* stream) {
+  if (!dZ || !A || !dW || L <= 0 || H <= 0 || W <= 0 || Cin % 64 != 0 || Cout % 64 != 0 || Cin <= 0 || Cout <= 0)
+    return MMMOT_EINVAL;
+  if (nsplit < 1 || nsplit > 256 || !mm_al16(dZ) || !mm_al16(A)) return MMMOT_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const bool n128 = Cout % 128 == 0, k128 = Cin % 128 == 0;
+#define WG_LAUNCH(TNV, TKV)                                                                                              \
+  hipLaunchKernelGGL((conv3x3_wgrad_f16_kernel<TNV, TKV>), dim3(Cout / TNV, Cin / TKV, 9 * nsplit), dim3(256), 0, s, dZ, A, \
+                     L, H, W, Cin, Cout, nsplit, dW, dzamax)
+  if (n128 && k128) WG_LAUNCH(128, 128);
+  else if (n128) WG_LAUNCH(128, 64);
+  else if (k128) WG_LAUNCH(64, 128);
+  else WG_LAUNCH(64, 64);
+#undef WG_LAUNCH
+  return mm_check(hipGetLastError());
+}
+
 // First layer (3 input channels, NCHW crops as delivered): PW[b][co][k] partial sums of dW1[co][k = tap * 3 + colour]
 // = sum_p dZ[p][co] * X[crop][colour][p + off(tap)] over block b's pixels (28 columns: 27 + the bias gradient sum_p dZ).
 // VALU, like the forward's K = 27 case is not matrix-core shaped; float64 accumulation (the sums cancel: BatchNorm

@@ -524,6 +524,7 @@ class TrackingNet(nn.Module):
     def invalidate(self):
         self._engine = None
         self._plans = {}
+        self.__dict__.pop('_train_plans', None)  # training-mode plans (mmmot_amd/train.py::forward_train)
         self._pack_version += 1
 
     def refresh_head(self):

@@ -196,6 +196,25 @@ class HipOps:
     def hl16_unpack(self, x, y):
         _lib.check(self.lib.mmmot_hl16_unpack(_ptr(x), _ptr(y), y.numel(), self._stream()), 'mmmot_hl16_unpack')
 
+    # ---- training step on the fp16 matrix cores: device-side power-of-two scales, raw-output trunk convolution ----
+    def absmax(self, X, out):
+        """out[0] = max |X| over a contiguous [R][C] tensor (device scalar, no host round trip)"""
+        R, C = X.numel() // X.shape[-1], X.shape[-1]
+        _lib.check(self.lib.mmmot_absmax(_ptr(X), C, R, C, _ptr(out), self._stream()), 'mmmot_absmax')
+
+    def hl16_pack_pow2(self, x, y, amax, target):
+        _lib.check(self.lib.mmmot_hl16_pack_pow2(_ptr(x), _ptr(y), x.numel(), _ptr(amax), int(target), self._stream()),
+                   'mmmot_hl16_pack_pow2')
+
+    def pow2_oscale(self, out, amax_a, target_a, amax_b=None, target_b=0):
+        _lib.check(self.lib.mmmot_pow2_oscale(_ptr(out), out.numel(), _ptr(amax_a), int(target_a), _ptr(amax_b), int(target_b),
+                                              self._stream()), 'mmmot_pow2_oscale')
+
+    def conv3x3_raw_hl16(self, x16, w16, bias, out, L, H, W, Cin, Cout, oscale):
+        st = self.lib.mmmot_conv3x3_raw_hl16(_ptr(x16), _ptr(w16), _ptr(bias), _ptr(out), L, H, W, Cin, Cout, _ptr(oscale),
+                                             self._stream())
+        _lib.check(st, 'mmmot_conv3x3_raw_hl16')
+
     def gemm(self, W, tiles, N, K, X=None, bias=None, dbias=None, rowidx=None, Y=None, part=None,
              sc=None, sh=None, FA=None, FB=None, pair=None, amode=A_PLAIN, pairop=0, act=ACT_NONE,
              w_hl16=False, oscale=1.0, osc=None, osh=None, colsum=None):
@@ -442,7 +461,17 @@ class HipOps:
         st = self.lib.mmmot_maxpool_bwd(_ptr(Z), C, _ptr(sc), _ptr(sh), _ptr(dP), L, H, W, _ptr(dA), self._stream())
         _lib.check(st, 'mmmot_maxpool_bwd')
 
-    def conv3x3_wgrad(self, dZ, A, L, H, W, Cin, Cout, nsplit, dW):
+    def conv3x3_wgrad(self, dZ, A, L, H, W, Cin, Cout, nsplit, dW, amax=None):
+        if self.tn_f16:
+            # fp16 matrix cores (3-term split), dZ scaled by a power of two taken from its maximum on the device
+            # (`amax`: that maximum when the caller has it already - the input-gradient convolution uses the same one)
+            if amax is None:
+                amax = self._scratch(('tn_amax', int(self._stream() or 0)), 1, dZ.device)
+                _lib.check(self.lib.mmmot_absmax(_ptr(dZ), Cout, L * H * W, Cout, _ptr(amax), self._stream()), 'mmmot_absmax')
+            st = self.lib.mmmot_conv3x3_wgrad_f16(_ptr(dZ), _ptr(A), L, H, W, Cin, Cout, nsplit, _ptr(dW), _ptr(amax),
+                                                  self._stream())
+            _lib.check(st, 'mmmot_conv3x3_wgrad_f16')
+            return
         st = self.lib.mmmot_conv3x3_wgrad(_ptr(dZ), _ptr(A), L, H, W, Cin, Cout, nsplit, _ptr(dW), self._stream())
         _lib.check(st, 'mmmot_conv3x3_wgrad')
 

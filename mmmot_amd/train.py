@@ -308,7 +308,16 @@ def forward_train(model, dets, det_info, dets_split):
     points = det_info['points']
     points = points.reshape(-1, points.shape[-1]).contiguous()
     S = int(dets.shape[-1])
-    plan = BatchPlan([(fc, ps)], S, points.device, rows=(0, 1, 2), use_points=True)
+    # the plan (integer tile tables, uploaded once) and everything the backward caches on it (row tilings of the trunk's
+    # layers, segment tables) are kept per sample layout: a training loop revisits the same layouts epoch after epoch,
+    # and rebuilding them cost ~250 small host-to-device copies per step (rocprof, round 4)
+    cache = model.__dict__.setdefault('_train_plans', {})
+    key = (tuple(fc), ps.tobytes(), S, str(points.device))
+    plan = cache.get(key)
+    if plan is None:
+        if len(cache) >= 32:
+            cache.pop(next(iter(cache)))
+        plan = cache[key] = BatchPlan([(fc, ps)], S, points.device, rows=(0, 1, 2), use_points=True)
     eng = _current_engine(model)
     if not getattr(model, 'freeze_appearance', False):
         from .train_vgg import appearance_autograd

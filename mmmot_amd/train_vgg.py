@@ -42,12 +42,25 @@ def _colsum_big(eng, X):
     if R <= 4096:
         return _colsum(eng, X)
     n = (R + 2047) // 2048
-    start = np.arange(n) * 2048
-    count = np.minimum(2048, R - start)
-    seg = Segments(start, count, np.ones(n), np.zeros(n), X.device, div=np.ones(n))
+    cache = eng.__dict__.setdefault('_colsum_big_segs', {})  # chunk table per row count (uploaded once)
+    key = (R, str(X.device))
+    seg = cache.get(key)
+    if seg is None:
+        if len(cache) > 64:
+            cache.clear()
+        start = np.arange(n) * 2048
+        count = np.minimum(2048, R - start)
+        seg = cache[key] = Segments(start, count, np.ones(n), np.zeros(n), X.device, div=np.ones(n))
     part = torch.empty(n, C, dtype=torch.float32, device=X.device)
     eng.ops.segment_mean(X, C, seg, part, use_group=False)
     return _colsum(eng, part)
+
+
+def _f16_convs(ops):
+    """training-mode trunk convolutions (forward and input gradient) on the fp16 matrix cores: the product backend in its
+    default arithmetic (MMMOT_GEMM_TN=f32 keeps the exact fp32 MFMA everywhere; the torch emulation of the tests has no such
+    entry point and runs the fp32 statement)"""
+    return bool(getattr(ops, 'tn_f16', False)) and hasattr(ops, 'conv3x3_raw_hl16')
 
 
 def _conv_params(model):
@@ -79,6 +92,7 @@ def appearance_forward_train(eng, model, plan, crops, P):
     if getattr(model.appearance, 'dropblock', 0):
         raise NotImplementedError('DropBlock (appearance dropblock > 0) is not built; the shipped configs set dropblock: 0')
     cache = plan.__dict__.setdefault('_vgg_train_tiles', {})
+    f16 = _f16_convs(ops)
     feats = new(L, 512)
     tape = dict(layers=[], heads=[])
     x, H, W = crops.contiguous(), S, S
@@ -94,7 +108,19 @@ def appearance_forward_train(eng, model, plan, crops, P):
             wp = w.permute(2, 3, 0, 1).reshape(9, cout, cin).contiguous()
         rows = L * H * W
         Z = new(rows, cout)
-        ops.conv3x3_raw(x, wp, b, Z, L, H, W, cin, cout, first)
+        amw = None
+        if f16 and not first:
+            # f16x3 (round 4): activations split once (hl16), weights scaled by a device-side power of two (max |w| ->
+            # [2^13, 2^14): their lo halves stay normal fp16 numbers) and split, the trunk kernel of the inference path with
+            # a raw fp32 output.  Nothing crosses the host: the step's weights are whatever the optimizer left on the device.
+            x16, w16, amw, osc = new(x.shape[0], cin), torch.empty_like(wp), new(1), new(cout)
+            ops.hl16_pack(x, x16)
+            ops.absmax(wp, amw)
+            ops.hl16_pack_pow2(wp, w16, amw, 14)
+            ops.pow2_oscale(osc, amw, 14)
+            ops.conv3x3_raw_hl16(x16, w16, b, Z, L, H, W, cin, cout, osc)
+        else:
+            ops.conv3x3_raw(x, wp, b, Z, L, H, W, cin, cout, first)
         T = _tiles(cache, rows, dev)
         part = new(T.T, 2, cout)
         ops.rows_stats(Z, cout, T, part)
@@ -103,7 +129,7 @@ def appearance_forward_train(eng, model, plan, crops, P):
         A = new(L * Ho * Wo, cout)
         ops.bn_relu_pool(Z, cout, Lyr.sc, Lyr.sh, L, H, W, pool, A)
         tape['layers'].append(dict(L=Lyr, x=x, wp=wp, H=H, W=W, cin=cin, cout=cout, pool=pool, first=first, stage=s,
-                                   last=last, cidx=cidx, bn=bn, rows=rows))
+                                   last=last, cidx=cidx, bn=bn, rows=rows, amw=amw))
         x, H, W, first = A, Ho, Wo, False
         if last:
             tape['heads'].append(_head_forward(eng, plan, cache, s, x, H * W, cout, P, feats))
@@ -117,7 +143,10 @@ def _head_forward(eng, plan, cache, s, x, hw, C, P, feats):
     new = lambda *s_: torch.empty(*s_, dtype=torch.float32, device=dev)
     pre = 'global_pool.%d.fc.' % s
     T1 = _tiles(cache, L, dev, each=1)
-    seg = Segments(np.arange(L) * hw, np.full(L, hw), np.ones(L), np.zeros(L), dev)
+    key = ('pool', L, hw)  # cached with the plan: a Segments table is five small host-to-device copies (4.5 ms per step
+    if key not in cache:   # over the four heads, cProfile round 4)
+        cache[key] = Segments(np.arange(L) * hw, np.full(L, hw), np.ones(L), np.zeros(L), dev)
+    seg = cache[key]
     Pm = new(L, C)
     ops.segment_mean(x, C, seg, Pm, use_group=False)           # AdaptiveAvgPool2d(1)
     part = new(T1.T, 2, C)
@@ -205,14 +234,30 @@ def appearance_backward(eng, model, plan, crops, tape, dF):
             tiles_w = (cout // 64) * (cin // 64) * 9
             ns = int(max(1, min(64, -(-1024 // tiles_w), rows // 256)))
             dWp = new(ns, 9 * cout * cin)
-            ops.conv3x3_wgrad(dZ, ly['x'], L, H, W, cin, cout, ns, dWp)
+            f16 = _f16_convs(ops) and ly['amw'] is not None
+            if f16:
+                amz = new(1)
+                ops.absmax(dZ, amz)  # one maximum for both uses of dZ
+                ops.conv3x3_wgrad(dZ, ly['x'], L, H, W, cin, cout, ns, dWp, amax=amz)
+            else:
+                ops.conv3x3_wgrad(dZ, ly['x'], L, H, W, cin, cout, ns, dWp)
             dW = _colsum(eng, dWp) if ns > 1 else dWp[0]
             g[pre + '%d.weight' % cidx] = dW.view(3, 3, cout, cin).permute(2, 3, 0, 1)
             # input gradient: the same convolution kernel on dZ with the taps flipped and Cin / Cout swapped
             wflip = ly['wp'].flip(0).permute(0, 2, 1).contiguous()  # [tap][Cin][Cout]
             zero = torch.zeros(cin, dtype=torch.float32, device=dev)
             dA = new(L * H * W, cin)
-            ops.conv3x3_raw(dZ, wflip, zero, dA, L, H, W, cout, cin, False)
+            if f16:
+                # f16x3: dZ scaled by the power of two that puts its maximum at 2^10 (gradients of 1e-6 sit in fp16's
+                # subnormals otherwise - what broke the SGD-step parity of the unscaled attempt of round 3), the weights
+                # by theirs; the epilogue's per-channel vector undoes both exactly
+                dz16, wf16, osc = new(rows, cout), torch.empty_like(wflip), new(cin)
+                ops.hl16_pack_pow2(dZ, dz16, amz, 11)
+                ops.hl16_pack_pow2(wflip, wf16, ly['amw'], 14)
+                ops.pow2_oscale(osc, amz, 11, ly['amw'], 14)
+                ops.conv3x3_raw_hl16(dz16, wf16, zero, dA, L, H, W, cout, cin, osc)
+            else:
+                ops.conv3x3_raw(dZ, wflip, zero, dA, L, H, W, cout, cin, False)
     return g
 
 

@@ -63,6 +63,16 @@ def test_two_rank_gather_gloo():
     assert dict(ret) == {0: True, 1: True}
 
 
+def test_uneven_shards_cover_the_batch_exactly():
+    """B = 250 over 8 ranks (cfg4's 256 minus a few): contiguous, balanced, no pair lost or doubled"""
+    for B, world in ((250, 8), (7, 8), (256, 8), (1, 2), (33, 4)):
+        bounds = [shard_range(B, r, world) for r in range(world)]
+        assert bounds[0][0] == 0 and bounds[-1][1] == B
+        assert all(bounds[r][1] == bounds[r + 1][0] for r in range(world - 1))
+        sizes = [hi - lo for lo, hi in bounds]
+        assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
 def test_bench_single_command_launcher_dry_run():
     """`python bench.py --gpus 2` must become two ranks by itself (the driver launches it exactly so): the --dry
     mode runs bench.py's own launcher, shard_range split, gather_results(same_layout=True) loop, barrier /

@@ -36,6 +36,34 @@ def test_conv3x3_raw(hip, first, L, H, W, Cin, Cout):
     assert (out < 0).any()  # no ReLU
 
 
+@pytest.mark.parametrize('L,H,W,Cin,Cout,scale', [(3, 10, 12, 64, 128, 1.0), (2, 7, 9, 128, 64, 3e-6), (5, 4, 4, 512, 512, 1e-4),
+                                                  (2, 16, 16, 256, 256, 1.0), (37, 4, 4, 128, 128, 2e-7), (1, 30, 20, 64, 64, 1.0)])
+def test_conv3x3_raw_hl16_with_device_side_scales(hip, L, H, W, Cin, Cout, scale):
+    """the training-mode trunk convolution on the fp16 matrix cores (forward: activations / dgrad: a gradient of magnitude
+    `scale`): input and weights scaled by device-side powers of two, split, convolved by the trunk kernel with raw fp32
+    output, unscaled by the per-channel vector - fp32-class RELATIVE accuracy against the fp64 convolution, also for
+    gradients far below fp16's normal range"""
+    emu = TorchOps(torch.float64)
+    x = rnd(L * H * W, Cin, seed=30) * scale
+    wp = rnd(9, Cout, Cin, seed=31, scale=(2.0 / (9 * Cin)) ** 0.5)
+    bias = rnd(Cout, seed=32, scale=0.1) * scale
+    ref = torch.zeros(L * H * W, Cout, dtype=torch.float64)
+    emu.conv3x3_raw(x, wp, bias, ref, L, H, W, Cin, Cout, False)
+    xg, wg = x.cuda(), wp.cuda()
+    new = lambda *s_: torch.empty(*s_, dtype=torch.float32, device=DEV)
+    amx, amw, x16, w16, osc = new(1), new(1), new(L * H * W, Cin), new(9, Cout, Cin), new(Cout)
+    hip.absmax(xg, amx)
+    hip.absmax(wg, amw)
+    assert abs(amx.item() - x.abs().max().item()) == 0.0 and abs(amw.item() - wp.abs().max().item()) == 0.0
+    hip.hl16_pack_pow2(xg, x16, amx, 11)
+    hip.hl16_pack_pow2(wg, w16, amw, 14)
+    hip.pow2_oscale(osc, amx, 11, amw, 14)
+    out = torch.full((L * H * W, Cout), float('nan')).cuda()
+    hip.conv3x3_raw_hl16(x16, w16, bias.cuda(), out, L, H, W, Cin, Cout, osc)
+    close(out / scale, ref.float() / scale, 3e-6, 'conv3x3 raw hl16 (device-side power-of-two scales)')
+    assert (out < 0).any()  # no ReLU
+
+
 def test_rows_stats_and_bn_relu_pool(hip):
     emu = TorchOps(torch.float64)
     L, H, W, C = 3, 9, 7, 64
@@ -63,15 +91,25 @@ def test_rows_stats_and_bn_relu_pool(hip):
     close(dg, dr.float(), 1e-6, 'maxpool backward (odd map: last row / column zero)')
 
 
-@pytest.mark.parametrize('L,H,W,Cin,Cout,ns', [(2, 6, 5, 64, 64, 1), (3, 8, 8, 128, 64, 3), (1, 4, 4, 64, 256, 2)])
-def test_conv3x3_wgrad(hip, L, H, W, Cin, Cout, ns):
+@pytest.mark.parametrize('f16', [True, False])
+@pytest.mark.parametrize('L,H,W,Cin,Cout,ns,scale', [(2, 6, 5, 64, 64, 1, 1.0), (3, 8, 8, 128, 64, 3, 1.0), (1, 4, 4, 64, 256, 2, 1.0),
+                                                     (5, 14, 14, 128, 128, 4, 1e-6), (2, 28, 20, 256, 128, 7, 3e-5),
+                                                     (3, 7, 9, 64, 128, 2, 1.0)])
+def test_conv3x3_wgrad(hip, f16, L, H, W, Cin, Cout, ns, scale):
+    """both arithmetics of the trunk's weight gradient (MMMOT_GEMM_TN: f16x3 = 3-term split on the fp16 matrix cores with a
+    device-side power-of-two scale of dZ, f32 = exact fp32 MFMA): gradients of 1e-6 keep fp32-class RELATIVE accuracy"""
     emu = TorchOps(torch.float64)
-    dZ, A = rnd(L * H * W, Cout, seed=10), rnd(L * H * W, Cin, seed=11)
+    dZ, A = rnd(L * H * W, Cout, seed=10) * scale, torch.relu(rnd(L * H * W, Cin, seed=11)) * 2.0
     ref = torch.zeros(ns, 9 * Cout * Cin, dtype=torch.float64)
     emu.conv3x3_wgrad(dZ, A, L, H, W, Cin, Cout, ns, ref)
     got = torch.full((ns, 9 * Cout * Cin), float('nan')).cuda()
-    hip.conv3x3_wgrad(dZ.cuda(), A.cuda(), L, H, W, Cin, Cout, ns, got)
-    close(got.sum(0), ref.sum(0).float(), 3e-6, 'conv3x3 weight gradient')
+    was = hip.tn_f16
+    hip.tn_f16 = f16
+    try:
+        hip.conv3x3_wgrad(dZ.cuda(), A.cuda(), L, H, W, Cin, Cout, ns, got)
+    finally:
+        hip.tn_f16 = was
+    close(got.sum(0) / scale, ref.sum(0).float() / scale, 3e-6, 'conv3x3 weight gradient (%s)' % ('f16x3' if f16 else 'f32'))
 
 
 def test_conv3x3_first_wgrad(hip):

@@ -6,7 +6,7 @@ from mmmot_amd.synth import make_pair
 from mmmot_amd.weights import init_module
 dev = torch.device('cuda', 0)
 model = TrackingNet(**dict(bench.BASE_KW, score_fusion_arch='C', affinity_op='multiply', softmax_mode='none'))
-init_module(model, seed=0); model.to(dev).train(); model.freeze_appearance = True
+init_module(model, seed=0); model.to(dev).train(); model.freeze_appearance = ('--whole' not in sys.argv)
 crit = TrackingLoss(detloss_type='bce', linkloss_type='l2', det_ratio=1.5, trans_ratio=0.001)
 opt = torch.optim.SGD(model.parameters(), lr=1e-4)
 N, M = 10, 12
@@ -20,5 +20,6 @@ def step():
     loss = crit(ds, gt[0], gt[1], gt[2], gt[3], det, links, new, end, trans)
     opt.zero_grad(); loss.backward(); opt.step(); torch.cuda.synchronize()
 step(); step()
+t0 = time.perf_counter(); step(); step(); print('wall per step: %.1f ms' % ((time.perf_counter() - t0) / 2 * 1e3))
 pr = cProfile.Profile(); pr.enable(); step(); step(); pr.disable()
-pstats.Stats(pr).sort_stats('cumulative').print_stats(28)
+pstats.Stats(pr).sort_stats('cumulative').print_stats(45)
