@@ -276,6 +276,11 @@ typedef struct mmmot_gemm_ares_args {
   float oscale;
 } mmmot_gemm_ares_args;
 int mmmot_gemm_ares(const mmmot_gemm_ares_args* a, void* stream);
+/* ABI 7.  tests: which kernel serves the K = 128 consumer pass (colsum only) of mmmot_gemm_ares - 0 = automatic (the
+ * weights-in-registers kernel of csrc/gemm_wreg.hip when N % 512 == 0 and the launch fills the chip), 1 = the streaming
+ * kernel only (the kernel before ABI 7), 2 = the register kernel whenever the layer is eligible.  Results do not depend on
+ * it, bit for bit. */
+int mmmot_set_gemm_ares_variant(int v);
 
 /* ---------------------------------------------------------------------------
  * GroupNorm statistics of a 1x1-conv output from the second moments of its INPUT (v2):

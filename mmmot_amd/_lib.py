@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.environ.get('MMMOT_LIB_PATH', os.path.join(_HERE, 'libmmmot_hip.so'))  # override: tools' timing-experiment builds
 SOURCES = ['conv3x3.hip', 'hl16_format.hip', 'conv3x3_hl16_patch.hip', 'gemm_rows.hip', 'gemm_wide.hip',
-           'gemm_ares.hip', 'gemm_wres.hip', 'pn_mlp64.hip', 'gram.hip', 'points_gather.hip', 'crop_resize.hip', 'small_kernels.hip', 'backward.hip', 'train.hip', 'train_vgg.hip', 'gemm_tn_f16.hip']
+           'gemm_ares.hip', 'gemm_wres.hip', 'gemm_wreg.hip', 'pn_mlp64.hip', 'gram.hip', 'points_gather.hip', 'crop_resize.hip', 'small_kernels.hip', 'backward.hip', 'train.hip', 'train_vgg.hip', 'gemm_tn_f16.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 HIPFLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
 
@@ -85,6 +85,7 @@ SIGNATURES = {
     'mmmot_gemm_rows': [ctypes.POINTER(GemmArgs), c_f],
     'mmmot_set_gemm_rows_variant': [c_i],
     'mmmot_gemm_ares': [ctypes.POINTER(GemmAresArgs), c_f],
+    'mmmot_set_gemm_ares_variant': [c_i],
     'mmmot_gram_rows': [c_f, c_i, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_f, c_f, c_f],
     'mmmot_gn_finalize_gram': [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_i, c_f, c_f, ctypes.c_float, c_f, c_f, c_f, c_f],
     'mmmot_gn_finalize': [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, ctypes.c_float, c_f, c_f, c_f],

@@ -419,6 +419,7 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
 }
 
 int mmmot_gemm_wres64_launch(const mmmot_gemm_ares_args* a, int mode, int n_cu, hipStream_t s);  // gemm_wres.hip
+int mmmot_gemm_wreg128_try(const mmmot_gemm_ares_args* a, int mode, int n_cu, hipStream_t s, int* status);  // gemm_wreg.hip
 
 extern "C" int mmmot_gemm_ares(const mmmot_gemm_ares_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -440,6 +441,9 @@ extern "C" int mmmot_gemm_ares(const mmmot_gemm_ares_args* a, void* stream) {
     return !(e && e[0] == '0');
   }();
   if (use_wres && a->K == 64 && a->N <= 512) return mmmot_gemm_wres64_launch(a, mode, n_cu, s);
+  // K = 128 consumer pass on a launch that fills the chip: the wave's weights live in registers (gemm_wreg.hip)
+  int wst = MMMOT_OK;
+  if (mmmot_gemm_wreg128_try(a, mode, n_cu, s, &wst)) return wst;
   if (a->N % AR_BN != 0) return MMMOT_EINVAL;  // the streaming kernel walks 256-channel tiles
   const int grid = a->T < n_cu ? a->T : n_cu;  // persistent: one workgroup per CU
 #define AR_LAUNCH(KSV, MODEV) \

@@ -540,6 +540,57 @@ def test_gemm_ares_statistics_and_colsum(hip, K, N):
     close(h_g, h_r, 2e-5, 'shift from half-tile statistics')
 
 
+@pytest.mark.parametrize('N,dets,with_dbias', [
+    (1024, [[130, 1, 40, 257, 64], [5, 128, 300, 65]], True),           # ragged detection-aligned tiles, per-tile bias row
+    (1024, [[2048] * 9, [2048] * 7, [100]], False),                      # conv5's shape: full tiles, several per sequence
+    (512, [[64] * 40], False),                                           # one channel half; every second half tile empty
+    (1536, [[700, 33], [128]], True),                                    # three channel halves
+])
+def test_gemm_ares_weights_in_registers_kernel(hip, N, dets, with_dbias):
+    """the K = 128 consumer pass on the weights-in-registers kernel (csrc/gemm_wreg.hip): fp64 emulation, and the streaming
+    kernel's column sums bit for bit (same operand values, accumulation order and summation order)"""
+    from mmmot_amd import _lib
+    from mmmot_amd.pack import hl16_weight_shift, to_hl16
+    from mmmot_amd.plan import HalfTiles
+    lib = _lib.load()
+    emu = TorchOps(torch.float64)
+    K = 128
+    counts = [sum(d) for d in dets]
+    G = len(dets)
+    cpu = RowTiles(counts, 'cpu', sub_counts=dets)
+    gpu = RowTiles(counts, 'cuda', sub_counts=dets)
+    hc = HalfTiles(cpu, 'cpu')
+    flat = [c for d in dets for c in d]
+    ndet, R = len(flat), sum(counts)
+    X = rnd(R, K, seed=90) + 0.5
+    W = rnd(N, K, seed=91, scale=K ** -0.5)
+    bias = rnd(N, seed=92)
+    sc, sh = rnd(G, K, seed=93).abs() + 0.5, rnd(G, K, seed=94)
+    dbias = rnd(ndet, N, seed=95) if with_dbias else None
+    tile_det = torch.repeat_interleave(torch.arange(ndet), torch.tensor(cpu.h_sub_ntiles).long()).int()
+    osc, osh = rnd(G, N, seed=96).abs() + 0.5, rnd(G, N, seed=97)
+    shift = hl16_weight_shift(W)
+    W16 = to_hl16(W.double() * 2.0 ** shift)
+    osv = 2.0 ** -shift
+    cs = torch.zeros(hc.T, N, dtype=torch.float64)
+    emu.gemm_ares(W16, osv, cpu, N, K, X, sc, sh, bias=bias, dbias=dbias, tile_dbrow=tile_det if with_dbias else None,
+                  osc=osc, osh=osh, colsum=cs)
+    outs = {}
+    try:
+        for v in (2, 1):
+            assert lib.mmmot_set_gemm_ares_variant(v) == 0
+            cg = torch.full((hc.T, N), float('nan')).cuda()
+            hip.gemm_ares(W16.cuda(), osv, gpu, N, K, X.cuda(), sc.cuda(), sh.cuda(), bias=bias.cuda(),
+                          dbias=dbias.cuda() if with_dbias else None, tile_dbrow=tile_det.cuda() if with_dbias else None,
+                          osc=osc.cuda(), osh=osh.cuda(), colsum=cg)
+            outs[v] = cg.cpu()
+    finally:
+        assert lib.mmmot_set_gemm_ares_variant(0) == 0
+    close(outs[2], cs.float(), 1e-5, 'weights-in-registers kernel: column sums')
+    if N % 256 == 0:  # the streaming kernel walks 256-channel tiles
+        assert torch.equal(outs[2], outs[1]), 'register-resident and streaming kernels differ'
+
+
 @pytest.mark.parametrize('K,N', [(128, 1024), (64, 192)])
 def test_gram_statistics_match_direct_statistics(hip, K, N):
     """GroupNorm(N, N) scale/shift of v = W relu(X*sc+sh) + b from the Gram matrix of the input (gram_rows +

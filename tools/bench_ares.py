@@ -20,6 +20,7 @@ def main():
     ap.add_argument('--rows', type=int, default=1 << 20)
     ap.add_argument('--k', type=int, default=128)
     ap.add_argument('--n', type=int, nargs='*', default=[128, 256, 512, 1024])
+    ap.add_argument('--variants', type=int, nargs='*', default=[0], help='mmmot_set_gemm_ares_variant values to time (1 = streaming kernel, 2 = weights in registers)')
     a = ap.parse_args()
     ops = HipOps()
     R, K = a.rows, a.k
@@ -36,7 +37,8 @@ def main():
         part = torch.empty(half.T, 2, N).cuda()
         cs = torch.empty(half.T, N).cuda()
         osc, osh = torch.ones(1, N).cuda(), torch.zeros(1, N).cuda()
-        for mode in ('stats', 'colsum'):
+        for mode, var in [(m, v) for m in ('stats', 'colsum') for v in a.variants]:
+            ops.lib.mmmot_set_gemm_ares_variant(var)
             kw = dict(part=part) if mode == 'stats' else dict(osc=osc, osh=osh, colsum=cs)
             ts = []
             for r in range(6):
@@ -49,7 +51,8 @@ def main():
                     ts.append(e0.elapsed_time(e1))
             ts.sort()
             ms = ts[len(ts) // 2]
-            print('K=%d N=%4d %-6s %.3f ms  %.0f TFLOP/s-equivalent' % (K, N, mode, ms, 2.0 * R * N * K / ms / 1e9))
+            print('K=%d N=%4d %-6s variant %d  %.3f ms  %.0f TFLOP/s-equivalent' % (K, N, mode, var, ms, 2.0 * R * N * K / ms / 1e9))
+        ops.lib.mmmot_set_gemm_ares_variant(0)
 
 
 if __name__ == '__main__':
