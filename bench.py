@@ -198,9 +198,19 @@ def roofline_of(trunk, events, eng, B, workload, dt, rows=(0, 1, 2)):
         f16 = trunk != 'f32'
         peak = PEAK_F16_MFMA_TFLOPS / 3.0 if f16 else PEAK_F32_MFMA_TFLOPS
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        roof = {'bound': 'mfma', 'kernel': 'gemm_ares_kernel<K=128> (PointNet conv5 128->1024 + GroupNorm + ReLU + '
-                'per-detection mean, second pass; 1 launch/step)', 'achieved': round(ach, 2), 'peak': round(peak, 1),
-                'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': None,
+        traffic, traffic_src = None, None
+        try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command (profiles/traffic.json)
+            with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
+                tr = json.load(f).get('%s_lidar/%s' % (workload, trunk))
+            if tr:
+                traffic = round((tr['fetch_bytes_per_pair'] + tr['write_bytes_per_pair']) * B / tr['launches_per_step'])
+                traffic_src = tr['source']
+        except (OSError, ValueError, KeyError):
+            pass
+        roof = {'bound': 'mfma', 'kernel': 'gemm_wreg128_kernel (PointNet conv5 128->1024 + GroupNorm + ReLU + per-detection mean, '
+                'consumer pass with the weights in registers; 1 launch/step)', 'achieved': round(ach, 2), 'peak': round(peak, 1),
+                'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_unit': 'bytes/launch (mean)',
+                'traffic_source': traffic_src,
                 'algorithmic_bytes_per_launch': round(sum(r * k * 4.0 for _, r, k, _, _, _ in tagged) / max(len(tagged), 1)),
                 'avg_launch_ms': round(ms / max(len(tagged), 1), 4), 'share_of_step': round(ms / (dt * 1e3), 4),
                 'flops_basis': 'algorithmic 2*K*N per point', 'peak_basis': '2500/3 (f16x3 row GEMMs)' if f16 else 'fp32 MFMA'}
