@@ -243,6 +243,10 @@ typedef struct mmmot_gemm_args {
    * rows per segment) finishes the mean. */
   const float* osc; const float* osh; int ldosc;   /* [G][ldosc] or NULL                */
   float* colsum;                        /* [T][N] or NULL                     */
+  /* ABI 7 (appended).  PAIR: nonzero = the caller guarantees grp_M[g] % 32 == 0 for every group, i.e. the 32 rows of
+   * every 32-row block of a tile share their a_i row; the wide kernel (csrc/gemm_wide.hip) then stages that row in LDS
+   * once per wave instead of requesting it per lane (it serves PAIR launches only with this guarantee). */
+  int pair_uniform32;
 } mmmot_gemm_args;
 int mmmot_gemm_rows(const mmmot_gemm_args* a, void* stream);
 /* ABI 7.  tests: which kernel serves mmmot_gemm_rows - 0 = automatic (the wide kernel of csrc/gemm_wide.hip for the

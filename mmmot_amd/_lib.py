@@ -43,6 +43,7 @@ class GemmArgs(ctypes.Structure):
         ('w_hl16', c_i), ('oscale', ctypes.c_float),
         ('osc', c_f), ('osh', c_f), ('ldosc', c_i),
         ('colsum', c_f),
+        ('pair_uniform32', c_i),
     ]
 
 

@@ -13,6 +13,11 @@
 //     in the MFMA operand layout (lane = row, 8 consecutive k), from 32-byte global loads of the fp32 source rows issued
 //     two 16-k steps ahead - no LDS traffic for A at all, and every generated fragment feeds 3 TN MFMAs: VALU work per
 //     MFMA drops 4x against the tile kernel and the 256 rows share one copy of the weight stage;
+//   * what is the same for all 32 rows of a wave - the a_i row of a pair tile (the caller guarantees M % 32 == 0, so a
+//     32-row block never straddles two i), the per-group scale / shift rows of the GroupNorm prologue - is staged in LDS
+//     once per item and read as broadcast fragments: the kernel is bound by the RATE of vector-memory instructions a CU
+//     gets through (~90 cycles each with eight requesting waves), and those redundant per-lane requests were a third
+//     (PAIR) / half (NORM_RELU) of them;
 //   * weights stream through a 3-slot LDS ring of (BN rows x 128 B) stages (32 k = 4 hl16 units per row) by LDS-DMA
 //     (global_load_lds, no VGPR staging), two stages ahead, XOR-swizzled on the source side like the trunk kernel's
 //     weight ring (piece ^ ((row >> 1) & 7): conflict-free ds_read_b128 fragments); one s_barrier per stage with a
@@ -46,8 +51,8 @@ __device__ __forceinline__ void gw_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-struct GwRaw {  // source values of one 16-k step of this lane's row: 8 consecutive k
-  f32x4 x[2], u[2], w[2];  // PAIR: a_i, b_j | NORM_RELU: X, sc, sh
+struct GwRaw {  // source values of one 16-k step of this lane's row: 8 consecutive k of b_j (PAIR) / X (NORM_RELU)
+  f32x4 x[2];
 };
 
 template <int TN, int AMODE, int PAIROP>
@@ -56,12 +61,17 @@ __global__ __launch_bounds__(512, 1) void gemm_wide_kernel(mmmot_gemm_args a, in
   constexpr int SLOT = BN * GW_ROWB;            // 32 KB (TN = 8) / 16 KB (TN = 4)
   constexpr int NG = TN / 4;                    // column groups of 4 MFMA tiles: 2 / 1
   constexpr int NDMA = BN / 8 / 8;              // weight DMA instructions per wave and stage: 4 / 2
-  constexpr int NRAW = (AMODE == MMMOT_A_PAIR) ? 4 : 6;  // source-row load instructions per wave and 16-k step
-  constexpr int CLD = 32 + 4;                   // output staging: 32 columns at a time, floats per staged row
+  constexpr int NRAW = 2;                       // source-row load instructions per wave and 16-k step (b_j / X: 32 B per lane)
+  constexpr int SCOLS = 16;                     // output staging: 16 columns at a time
+  constexpr int CLD = SCOLS + 4;                // floats per staged row
   constexpr int STG_WAVE = 32 * CLD * 4;        // bytes per wave
   constexpr int RED_OFF = GW_NSLOT * SLOT;      // [8][BN] per-wave column partials, [2][BN] column means
   constexpr int STG_OFF = RED_OFF + 10 * BN * 4;
-  constexpr int SMEM = STG_OFF + 8 * STG_WAVE;
+  // wave-uniform source vectors, double-buffered by item parity: PAIR [2][8 waves][512] (a_i of the wave's rows),
+  // NORM_RELU [2][2 halves][2][512] (scale, shift of the half's group)
+  constexpr int UNI_OFF = STG_OFF + 8 * STG_WAVE;
+  constexpr int UNI_BUF = (AMODE == MMMOT_A_PAIR) ? 8 * 2048 : 2 * 2 * 2048;
+  constexpr int SMEM = UNI_OFF + 2 * UNI_BUF;
   static_assert(SMEM <= 160 * 1024, "LDS budget");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
 
@@ -86,9 +96,14 @@ __global__ __launch_bounds__(512, 1) void gemm_wide_kernel(mmmot_gemm_args a, in
   struct Item {  // this WAVE's plan tile of the item (the two halves of a workgroup may belong to different groups)
     int t, nt, row0, nrows, grp;
   };
+  // item -> (pair of row tiles u, column tile nt): the ntn column tiles of a row-tile pair are items it, it + 8, ... of one
+  // group of 8 ntn - with a grid that is a multiple of 8 ntn they run at the same time on workgroups b, b + 8, ... = on the
+  // SAME XCD, so the source rows (NORM_RELU: X from HBM; PAIR: a_i / b_j) are fetched once into that XCD's L2 and the
+  // other column tiles hit it.  Row-tile pairs beyond the last one (the item count is padded to whole groups) are empty.
+  auto item_u = [&](int it) { return (it & 7) + 8 * (it / (8 * ntn)); };
   auto decode = [&](int it, Item& I) {
-    const int u = it / ntn;
-    I.nt = it - u * ntn;
+    const int u = item_u(it);
+    I.nt = (it >> 3) % ntn;
     const int t = 2 * u + half;
     const bool ok = t < a.T;
     I.t = ok ? t : a.T - 1;
@@ -98,7 +113,9 @@ __global__ __launch_bounds__(512, 1) void gemm_wide_kernel(mmmot_gemm_args a, in
   };
   // per-lane source rows of the A operand (row 32 wq + lr of the tile; rows beyond the tile read row 0 and are zeroed)
   struct Src {
-    const float *p0, *p1, *p2;
+    const float* p0;   // per lane: b_j (PAIR) / X row (NORM_RELU), + 8 h
+    const float* u0;   // wave-uniform rows for the LDS staging: a_i (PAIR) / scale (NORM_RELU)
+    const float* u1;   //                                        shift (NORM_RELU)
     float top;
   };
   auto sources = [&](const Item& I, Src& S) {
@@ -110,38 +127,67 @@ __global__ __launch_bounds__(512, 1) void gemm_wide_kernel(mmmot_gemm_args a, in
       const int q = I.row0 + rr - a.grp_row0[I.grp];
       const int M = a.grp_M[I.grp];
       const int ii = q / M, jj = q - ii * M;
-      S.p0 = a.FA + (long)(a.grp_aoff[I.grp] + ii) * a.ldf + 8 * h;
-      S.p1 = a.FB + (long)(a.grp_boff[I.grp] + jj) * a.ldf + 8 * h;
-      S.p2 = nullptr;
+      S.p0 = a.FB + (long)(a.grp_boff[I.grp] + jj) * a.ldf + 8 * h;
+      // M % 32 == 0 (pair_uniform32) and tiles start at multiples of 128 rows of their group: the wave's rows share ii;
+      // rows beyond the tile stand in for the wave's first row (or, in a wave without valid rows, the tile's first row:
+      // it contributes zeros whatever it reads)
+      const int iw = __builtin_amdgcn_readfirstlane(ii);
+      S.u0 = a.FA + (long)(a.grp_aoff[I.grp] + iw) * a.ldf;
+      S.u1 = nullptr;
     } else {
       S.p0 = a.X + (long)(I.row0 + rr) * a.ldx + 8 * h;
-      S.p1 = a.sc + (long)I.grp * a.ldsc + 8 * h;
-      S.p2 = a.sh + (long)I.grp * a.ldsc + 8 * h;
+      S.u0 = a.sc + (long)I.grp * a.ldsc;
+      S.u1 = a.sh + (long)I.grp * a.ldsc;
     }
   };
   auto load_raw = [&](const Src& S, int s, int j, GwRaw& R) {  // k = 32 s + 16 j + 8 h .. + 7
     const int k = s * GW_BK + 16 * j;
     R.x[0] = *reinterpret_cast<const f32x4*>(S.p0 + k);
     R.x[1] = *reinterpret_cast<const f32x4*>(S.p0 + k + 4);
-    R.u[0] = *reinterpret_cast<const f32x4*>(S.p1 + k);
-    R.u[1] = *reinterpret_cast<const f32x4*>(S.p1 + k + 4);
-    if constexpr (AMODE == MMMOT_A_NORM_RELU) {
-      R.w[0] = *reinterpret_cast<const f32x4*>(S.p2 + k);
-      R.w[1] = *reinterpret_cast<const f32x4*>(S.p2 + k + 4);
+  };
+  // the wave-uniform vectors of an item -> LDS buffer `ub` (lane-linear 1 KB pieces: 256 floats per instruction)
+  auto dma_uniform = [&](const Src& S, int ub) {
+    if constexpr (AMODE == MMMOT_A_PAIR) {
+      unsigned char* dst = smem + UNI_OFF + ub * UNI_BUF + wave * 2048;
+      gw_dma16(reinterpret_cast<const u32x4*>(S.u0) + lane, dst);
+      if (a.K > 256) gw_dma16(reinterpret_cast<const u32x4*>(S.u0) + 64 + lane, dst + 1024);
+    } else {
+      // wave 1 of each half fetches its group's shift row, the other waves the scale row (the same bytes into the same
+      // place): every wave issues the same NUMBER of requests - the counted waits assume it
+      const int v = (wq == 1) ? 1 : 0;
+      unsigned char* dst = smem + UNI_OFF + ub * UNI_BUF + (half * 2 + v) * 2048;
+      const float* src = v ? S.u1 : S.u0;
+      gw_dma16(reinterpret_cast<const u32x4*>(src) + lane, dst);
+      if (a.K > 256) gw_dma16(reinterpret_cast<const u32x4*>(src) + 64 + lane, dst + 1024);
     }
   };
   // the A fragment of one k-step: op / normalise, fp16 range clamp (rows beyond the tile: bound 0), hi/lo split
-  auto generate = [&](const GwRaw& R, float top, f16x8& ah, f16x8& al) {
+  // step: 16-k step inside the item (k = 16 step + 8 h); ub: LDS buffer of the item's uniform vectors
+  auto generate = [&](const GwRaw& R, float top, int step, int ub, f16x8& ah, f16x8& al) {
+    const int k = 16 * step + 8 * h;
+    f32x4 u4[2], w4[2];
+    if constexpr (AMODE == MMMOT_A_PAIR) {
+      const float* U = reinterpret_cast<const float*>(smem + UNI_OFF + ub * UNI_BUF + wave * 2048) + k;
+      u4[0] = *reinterpret_cast<const f32x4*>(U);
+      u4[1] = *reinterpret_cast<const f32x4*>(U + 4);
+    } else {
+      const float* U = reinterpret_cast<const float*>(smem + UNI_OFF + ub * UNI_BUF + half * 2 * 2048) + k;
+      u4[0] = *reinterpret_cast<const f32x4*>(U);
+      u4[1] = *reinterpret_cast<const f32x4*>(U + 4);
+      w4[0] = *reinterpret_cast<const f32x4*>(U + 512);
+      w4[1] = *reinterpret_cast<const f32x4*>(U + 516);
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float x = R.x[e >> 2][e & 3], u = R.u[e >> 2][e & 3];
+      // PAIR: x = b_j (per lane), u = a_i (the wave's row): a_i op b_j with the operand order of the tile kernel
+      const float x = R.x[e >> 2][e & 3], u = u4[e >> 2][e & 3];
       float y;
       if constexpr (AMODE == MMMOT_A_PAIR) {
-        if constexpr (PAIROP == MMMOT_PAIR_MULTIPLY) y = x * u;
-        else if constexpr (PAIROP == MMMOT_PAIR_MINUS_ABS) y = fabsf((x - u) * 0.5f);
-        else y = (x - u) * 0.5f;
+        if constexpr (PAIROP == MMMOT_PAIR_MULTIPLY) y = u * x;
+        else if constexpr (PAIROP == MMMOT_PAIR_MINUS_ABS) y = fabsf((u - x) * 0.5f);
+        else y = (u - x) * 0.5f;
       } else {
-        y = fmaxf(fmaf(x, u, R.w[e >> 2][e & 3]), 0.f);
+        y = fmaxf(fmaf(x, u, w4[e >> 2][e & 3]), 0.f);
       }
       y = __builtin_amdgcn_fmed3f(y, -top, top);
       ah[e] = (_Float16)y;
@@ -201,18 +247,18 @@ __global__ __launch_bounds__(512, 1) void gemm_wide_kernel(mmmot_gemm_args a, in
     const int ml = nx ? m - 2 * nst : m;
     Src sn;
     sn.p0 = nx ? snxt.p0 : scur.p0;
-    sn.p1 = nx ? snxt.p1 : scur.p1;
-    sn.p2 = nx ? snxt.p2 : scur.p2;
     load_raw(sn, ml >> 1, ml & 1, R);
   };
+  int ub = 0;  // LDS buffer of the current item's uniform vectors
   {  // first item of this workgroup: load prologue (K >= 64: two stages exist)
+    dma_uniform(scur, 0);
     dma_stage(wcur, 0, 0);
     load_raw(scur, 0, 0, raw[0]);
     load_raw(scur, 0, 1, raw[1]);
     dma_stage(wcur, 1, 1);
     gw_wait_vm<NDMA>();  // stage 0 and the first source values landed; stage 1 may be in flight
     __builtin_amdgcn_s_barrier();
-    generate(raw[0], scur.top, fh[0], fl[0]);
+    generate(raw[0], scur.top, 0, 0, fh[0], fl[0]);
     load_raw(scur, 1, 0, raw[0]);
     read_b(0, boff, 0, 0);
   }
@@ -225,6 +271,7 @@ __global__ __launch_bounds__(512, 1) void gemm_wide_kernel(mmmot_gemm_args a, in
     decode(has_next ? item_n : item, nxt);
     sources(nxt, snxt);
     const u32x4* wnxt = Wp + (long)(nxt.nt * BN) * wrow;
+    dma_uniform(snxt, ub ^ 1);  // read from the last step of this item on: many stage barriers away
     f32x16 acc[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
@@ -262,8 +309,8 @@ __global__ __launch_bounds__(512, 1) void gemm_wide_kernel(mmmot_gemm_args a, in
           }
           if (j == 0 && g == 0) dma_stage(wb2, s2, slot2);
           if (g == 0) {  // the A fragment of step n + 1 (the successor's first step behind the last one)
-            const float top2 = (last && j == 1) ? snxt.top : scur.top;
-            generate(raw[j ^ 1], top2, fh[j ^ 1], fl[j ^ 1]);
+            const bool nx = last && j == 1;
+            generate(raw[j ^ 1], nx ? snxt.top : scur.top, nx ? 0 : n + 1, nx ? (ub ^ 1) : ub, fh[j ^ 1], fl[j ^ 1]);
             load_stream(n + 3, raw[j ^ 1]);
           }
           // ---- 12 MFMAs, term-major: consecutive ones hit different accumulators (per accumulator the order of
@@ -295,16 +342,18 @@ __global__ __launch_bounds__(512, 1) void gemm_wide_kernel(mmmot_gemm_args a, in
     if (a.Y) {
       float* stg = reinterpret_cast<float*>(smem + STG_OFF + wave * STG_WAVE);  // wave-private
 #pragma unroll
-      for (int c = 0; c < TN; ++c) {
+      for (int c = 0; c < 2 * TN; ++c) {  // 16 columns at a time: the column halves of the lanes lr < 16 / lr >= 16
+        if ((lr >> 4) == (c & 1)) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) stg[mm_acc_row(e, lane) * CLD + lr] = fmaf(acc[c][e], oscale, bv[c]);
+          for (int e = 0; e < 16; ++e) stg[mm_acc_row(e, lane) * CLD + (lr & 15)] = fmaf(acc[c >> 1][e], oscale, bv[c >> 1]);
+        }
         // same wave writes and reads: LDS operations of a wave execute in order
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {  // 8 lanes per row (128 B), 8 rows per instruction
-          const int r = it * 8 + (lane >> 3), p = lane & 7;
+        for (int it = 0; it < 2; ++it) {  // 4 lanes per row (64 B), 16 rows per instruction
+          const int r = it * 16 + (lane >> 2), p = lane & 3;
           const f32x4 v = *reinterpret_cast<const f32x4*>(&stg[r * CLD + 4 * p]);
           if (rbase + r < nrows)
-            *reinterpret_cast<f32x4*>(&a.Y[(long)(cur.row0 + rbase + r) * a.ldy + n0 + c * 32 + 4 * p]) = v;
+            *reinterpret_cast<f32x4*>(&a.Y[(long)(cur.row0 + rbase + r) * a.ldy + n0 + c * SCOLS + 4 * p]) = v;
         }
       }
     }
@@ -327,7 +376,7 @@ __global__ __launch_bounds__(512, 1) void gemm_wide_kernel(mmmot_gemm_args a, in
         const int hf = x / BN, cl = x - hf * BN;
         const float* rp = red + hf * 4 * BN + cl;
         const float sum = (rp[0] + rp[BN]) + (rp[2 * BN] + rp[3 * BN]);
-        const int t2 = 2 * (item / ntn) + hf;
+        const int t2 = 2 * item_u(item) + hf;
         if (t2 < a.T) {
           a.part[((long)t2 * 2 + 0) * a.N + n0 + cl] = sum;
           colmean[x] = sum / (float)a.tile_nrows[t2];
@@ -352,7 +401,7 @@ __global__ __launch_bounds__(512, 1) void gemm_wide_kernel(mmmot_gemm_args a, in
         const int hf = x / BN, cl = x - hf * BN;
         const float* rp = red + hf * 4 * BN + cl;
         const float sum = (rp[0] + rp[BN]) + (rp[2 * BN] + rp[3 * BN]);
-        const int t2 = 2 * (item / ntn) + hf;
+        const int t2 = 2 * item_u(item) + hf;
         if (t2 < a.T) a.part[((long)t2 * 2 + 1) * a.N + n0 + cl] = sum;
       }
       gw_lds_barrier();  // the partials and means are rewritten by the next item's epilogue
@@ -360,6 +409,7 @@ __global__ __launch_bounds__(512, 1) void gemm_wide_kernel(mmmot_gemm_args a, in
     cur = nxt;
     scur = snxt;
     wcur = wnxt;
+    ub ^= 1;
   }
 }
 
@@ -375,8 +425,11 @@ extern "C" int mmmot_set_gemm_rows_variant(int v) {
 template <int TN, int AMODE, int PAIROP>
 static int gw_launch(const mmmot_gemm_args* a, hipStream_t s, int n_cu) {
   const int ntn = a->N / (32 * TN);
-  const int nitems = ((a->T + 1) / 2) * ntn;
-  const int grid = nitems < n_cu ? nitems : n_cu;
+  const int nu = (a->T + 1) / 2;                     // pairs of row tiles
+  const int nitems = ((nu + 7) / 8) * 8 * ntn;       // padded to whole groups of 8 row-tile pairs x ntn column tiles
+  int grid = (n_cu / (8 * ntn)) * (8 * ntn);         // whole groups: column tiles of a row-tile pair on one XCD
+  if (grid < 8 * ntn) grid = 8 * ntn;
+  if (grid > nitems) grid = nitems;
   hipLaunchKernelGGL((gemm_wide_kernel<TN, AMODE, PAIROP>), dim3(grid), dim3(512), 0, s, *a, ntn, nitems);
   return mm_check(hipGetLastError());
 }
@@ -396,10 +449,11 @@ static int gw_dispatch(const mmmot_gemm_args* a, hipStream_t s, int n_cu) {
 int mmmot_gemm_wide_try(const mmmot_gemm_args* a, hipStream_t s, int* status) {
   const int variant = g_gemm_variant.load();
   if (variant == 1) return 0;
-  if (!a->w_hl16 || a->K % GW_BK != 0 || a->K < 2 * GW_BK || a->N % 128 != 0) return 0;
+  if (!a->w_hl16 || (a->K != 256 && a->K != 512) || a->N % 128 != 0) return 0;  // (whole 256-value pieces of the uniform rows)
   if (a->amode != MMMOT_A_PAIR && a->amode != MMMOT_A_NORM_RELU) return 0;
   if (a->dbias || a->colsum || a->act != MMMOT_ACT_NONE) return 0;
-  if (a->amode == MMMOT_A_PAIR && (a->ldf % 4 != 0 || a->K > a->ldf)) return 0;
+  if (a->amode == MMMOT_A_PAIR && (a->ldf % 4 != 0 || a->K > a->ldf || !a->pair_uniform32)) return 0;
+  if (a->amode == MMMOT_A_NORM_RELU && a->ldsc < a->K) return 0;
   if (a->Y && (a->ldy % 4 != 0)) return 0;
   const int n_cu = mm_num_cu();
   if (n_cu <= 0) return 0;

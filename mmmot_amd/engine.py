@@ -16,6 +16,7 @@ import os
 import threading
 import warnings
 
+import numpy as np
 import torch
 
 from .ops import (ACT_NONE, ACT_RELU, ACT_SIGMOID, A_NORM_RELU, A_PAIR, A_PLAIN, FUSION_MODES, PAIR_OPS,
@@ -548,7 +549,8 @@ class Engine:
         ops, lk, PT, VT = self.ops, self.P['w_link'], plan.pair_tiles, plan.v_tiles
         nR, Lt, R = plan.nR, plan.Lt, plan.pair_tiles.R
         Ff = F.view(nR * Lt, 512)
-        pair = dict(row0=PT.g_row0, M=plan.pg_M, aoff=plan.pg_aoff, boff=plan.pg_boff)
+        pair = dict(row0=PT.g_row0, M=plan.pg_M, aoff=plan.pg_aoff, boff=plan.pg_boff,
+                    uniform32=bool(len(plan.h_pg_M)) and bool((np.asarray(plan.h_pg_M) % 32 == 0).all()))
         # stacked [new_end.conv0 ; conv1.0] over the on-the-fly pairwise tensor
         ya = self.buf('aff_ya', R, 1024)
         part = self._part(PT, 1024)

@@ -233,6 +233,7 @@ class HipOps:
         if pair is not None:
             a.grp_row0, a.grp_M = _iptr(pair['row0']), _iptr(pair['M'])
             a.grp_aoff, a.grp_boff = _iptr(pair['aoff']), _iptr(pair['boff'])
+            a.pair_uniform32 = int(bool(pair.get('uniform32', False)))  # every M a multiple of 32 (the caller's plan knows)
         a.T, a.N, a.K = tiles.T, N, K
         a.amode, a.pairop, a.act = amode, pairop, act
         a.w_hl16, a.oscale = int(w_hl16), float(oscale)

@@ -89,15 +89,17 @@ def variants(hip):
 
 def _pair_tables(tl, NM, aoff, boff, dev):
     return dict(row0=torch.tensor(tl.cpu.h_g_row0).to(dev), M=torch.tensor([m for _, m in NM], dtype=torch.int32).to(dev),
-                aoff=torch.tensor(aoff, dtype=torch.int32).to(dev), boff=torch.tensor(boff, dtype=torch.int32).to(dev))
+                aoff=torch.tensor(aoff, dtype=torch.int32).to(dev), boff=torch.tensor(boff, dtype=torch.int32).to(dev),
+                uniform32=all(m % 32 == 0 for _, m in NM))
 
 
 @pytest.mark.parametrize('pairop', [0, 1, 2])
-@pytest.mark.parametrize('N,K,NM', [(1024, 512, [(5, 7), (130, 3), (64, 64)]), (512, 512, [(20, 33)]), (128, 512, [(9, 50)]),
-                                    (512, 64, [(40, 40), (1, 1)]), (1024, 128, [(128, 97)])])
+@pytest.mark.parametrize('N,K,NM', [(1024, 512, [(5, 64), (130, 32), (64, 64)]), (512, 512, [(20, 96)]), (128, 512, [(9, 32)]),
+                                    (512, 256, [(40, 32), (1, 32)]), (1024, 512, [(128, 128), (3, 160)]),
+                                    (1024, 512, [(5, 7), (130, 3)])])   # last: M % 32 != 0 - the tile kernel serves it
 def test_gemm_wide_pair(hip, variants, pairop, N, K, NM):
     """stacked pairwise layer (reference modules/gcn.py:59-82, new_end.py:48-52) on the wide kernel: fp64 statement, and
-    the tile kernel's Y bit for bit (same operand values, same accumulation order)"""
+    the tile kernel's Y and statistics bit for bit (same operand values, same accumulation and summation order)"""
     emu = TorchOps(torch.float64)
     counts = [n * m for n, m in NM]
     tl = DevTiles(counts)
@@ -112,8 +114,8 @@ def test_gemm_wide_pair(hip, variants, pairop, N, K, NM):
     bias = rnd(N, seed=242)
     R = sum(counts)
     Y, part = torch.zeros(R, N), torch.zeros(tl.cpu.T, 2, N)
-    emu.gemm(W, tl.cpu, N, K, FA=Fm, FB=Fm, pair=_pair_tables(tl, NM, aoff, boff, 'cpu'), amode=2, pairop=pairop, bias=bias,
-             Y=Y, part=part)
+    cp = _pair_tables(tl, NM, aoff, boff, 'cpu')
+    emu.gemm(W, tl.cpu, N, K, FA=Fm, FB=Fm, pair=cp, amode=2, pairop=pairop, bias=bias, Y=Y, part=part)
     W16, osc = split_w(W)
     Fg, Wg, bg, pt = Fm.cuda(), W16.cuda(), bias.cuda(), _pair_tables(tl, NM, aoff, boff, 'cuda')
     outs = {}
@@ -128,10 +130,11 @@ def test_gemm_wide_pair(hip, variants, pairop, N, K, NM):
     close(outs[2][1][:, 0], part[:, 0], 1e-5, 'wide gemm pair tile sums')
     close(outs[2][1][:, 1], part[:, 1], 1e-4, 'wide gemm pair tile M2')
     assert torch.equal(outs[2][0], outs[1][0]), 'wide and tile kernels differ in Y'
+    assert torch.equal(outs[2][1], outs[1][1]), 'wide and tile kernels differ in the per-tile statistics'
 
 
 @pytest.mark.parametrize('N,K,ldx,counts', [(512, 512, 1024, [300, 5, 128, 1000]), (128, 512, 512, [77, 260]),
-                                            (1024, 256, 256, [129])])
+                                            (1024, 256, 256, [129]), (256, 512, 512, [128] * 37)])
 def test_gemm_wide_norm_relu(hip, variants, N, K, ldx, counts):
     """the GroupNorm-fed layers behind it (w_link.conv1.3 / conv1.6, reference modules/gcn.py:61-65): strided input rows
     (the conv1.0 half of the stacked layer's output), per-group scale / shift"""
@@ -158,18 +161,19 @@ def test_gemm_wide_norm_relu(hip, variants, N, K, ldx, counts):
     close(outs[2][1][:, 0], part[:, 0], 1e-5, 'wide gemm norm_relu tile sums')
     close(outs[2][1][:, 1], part[:, 1], 1e-4, 'wide gemm norm_relu tile M2')
     assert torch.equal(outs[2][0], outs[1][0]), 'wide and tile kernels differ in Y'
+    assert torch.equal(outs[2][1], outs[1][1]), 'wide and tile kernels differ in the per-tile statistics'
 
 
 def test_gemm_wide_long_chains_are_deterministic(hip, variants):
     """more items than workgroups (each persistent workgroup walks a chain of tiles, the successor's first weight stage and
     source rows requested during the last stage): 40 000 pair rows x 1024 columns = 626 items on 256 CUs, repeated"""
-    NM = [(200, 200)]
+    NM = [(250, 160)]
     tl = DevTiles([40000])
     N, K = 1024, 512
-    Fm = rnd(400, K, seed=260).cuda()
+    Fm = rnd(410, K, seed=260).cuda()
     W = rnd(N, K, seed=261, scale=K ** -0.5)
     W16, osc = split_w(W)
-    pt = _pair_tables(tl, NM, [0], [200], 'cuda')
+    pt = _pair_tables(tl, NM, [0], [250], 'cuda')
     outs = []
     for v in (1, 2, 2, 2):
         assert variants(v) == 0
