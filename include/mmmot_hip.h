@@ -428,7 +428,9 @@ int mmmot_points_scatter(const float* pts, int P, int F, const double* planes, i
  * of `planes` every emitted point of sweep s must ALSO be inside (the image frustum of remove_outside_points fused
  * into the per-box test: same rows, same order as filtering first, no intermediate array).  Host-built tables:
  * blk_sweep [NBLK] / blk_first [NS] (256-point blocks per sweep), cnt_off [NPOLY] (first counter of each polygon;
- * polygon totals are stored at cnt[cnt_total + j]; cnt holds cnt_total + NPOLY ints).  split [NPOLY+1] as above. */
+ * polygon totals are stored at cnt[cnt_total + j]; behind them, 8-byte aligned, the count pass leaves four 64-bit
+ * membership masks per counter for the scatter pass, so cnt holds ((cnt_total + NPOLY + 1) & ~1) + 8 * cnt_total
+ * ints - since ABI 8).  split [NPOLY+1] as above. */
 int mmmot_points_count_batched(const float* pts, int F, int NS, int NPOLY, int NBLK, int cnt_total,
                                const double* planes, const int* blk_sweep, const int* blk_first,
                                const int* sweep_row0, const int* poly0, const int* filt, const int* cnt_off,

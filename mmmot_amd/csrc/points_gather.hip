@@ -4,7 +4,8 @@
 //
 // Replaces the numba loop _points_in_convex_polygon_3d_jit (reference point_cloud/geometry.py:96-114) and
 // the per-box boolean-index loop of read_and_prep_points (point_cloud/preprocess.py:70-96).  HBM-bound byte
-// shuffling: every point is read twice (count pass, scatter pass), every kept point written once; the
+// shuffling: every point is read once by the count pass (the batched form keeps its membership masks for the scatter
+// pass, which then reads only the kept points; the single-sweep form tests twice), every kept point written once; the
 // membership arithmetic is the reference's - float64, left to right, no FMA contraction - so that the
 // inside/outside decision is bit-identical.
 #include "common.h"
@@ -162,6 +163,8 @@ extern "C" int mmmot_points_scatter(const float* pts, int P, int F, const double
 //   sweep_row0 [NS+1]: first point of every sweep            poly0 [NS+1]   : first polygon of every sweep
 //   filt [NS]        : index (into planes) of the sweep's filter polygon, or -1
 //   cnt_off [NPOLY]  : first counter of every polygon (its sweep's blocks), totals follow at cnt_total
+//   cnt              : cnt_total counters, NPOLY totals, then (8-byte aligned) four 64-bit membership masks per
+//                      counter: ((cnt_total + NPOLY + 1) & ~1) + 8 * cnt_total ints in all
 // A sweep may have at most PG_MAX_POLY polygons.
 struct PgBatch {
   const float* pts;
@@ -175,104 +178,177 @@ struct PgBatch {
   int F, NS, NPOLY, cnt_total;
 };
 
-__global__ __launch_bounds__(PG_THREADS) void pgb_count_kernel(PgBatch a, int* __restrict__ cnt) {
-  __shared__ double lpl[(PG_MAX_POLY + 1) * 24];
-  __shared__ int lcnt[PG_MAX_POLY];
+#define PGB_CHUNK 16  // polygons per pass of a block
+#define PGB_K1 2      // planes of the dense first stage (one slab of a box)
+
+__device__ __forceinline__ bool pg_below(double x, double y, double z, const double* __restrict__ pl) {
+  double s = __dadd_rn(__dmul_rn(x, pl[0]), __dmul_rn(y, pl[1]));
+  s = __dadd_rn(s, __dmul_rn(z, pl[2]));
+  s = __dadd_rn(s, pl[3]);
+  return !(s >= 0.0);
+}
+
+// Membership of one 256-point block in its sweep's polygons, in two stages: every (point, polygon) pair is tested
+// against the first PGB_K1 planes; the few pairs that pass (a slab of a box holds a few percent of a sweep) are
+// queued in LDS and finish the remaining planes on dense waves.  The decision is the AND of the same six
+// comparisons whatever the order, so the masks are the ones the straight loop gives.  Output per (polygon, block):
+// the four 64-bit wave masks (read again by the scatter pass, which therefore repeats no arithmetic) and their
+// population count.
+__global__ __launch_bounds__(PG_THREADS) void pgb_count_kernel(PgBatch a, int* __restrict__ cnt,
+                                                               unsigned long long* __restrict__ msk) {
+  __shared__ double lpl[(PGB_CHUNK + 1) * 24];
+  __shared__ double px[PG_THREADS], py[PG_THREADS], pz[PG_THREADS];
+  __shared__ unsigned long long wmask[PGB_CHUNK][PG_THREADS / 64];
+  __shared__ unsigned short queue[PGB_CHUNK * PG_THREADS];
+  __shared__ int qn;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int s = a.blk_sweep[blockIdx.x];
   const int b = blockIdx.x - a.blk_first[s];
   const int p0 = a.poly0[s], np = a.poly0[s + 1] - p0, fi = a.filt[s];
-  for (int i = threadIdx.x; i < np * 24; i += PG_THREADS) lpl[i] = a.planes[(long)p0 * 24 + i];
-  if (fi >= 0 && threadIdx.x < 24) lpl[PG_MAX_POLY * 24 + threadIdx.x] = a.planes[(long)fi * 24 + threadIdx.x];
-  for (int j = threadIdx.x; j < np; j += PG_THREADS) lcnt[j] = 0;
-  __syncthreads();
-  const int i = a.sweep_row0[s] + b * PG_THREADS + threadIdx.x;
+  if (fi >= 0 && tid < 24) lpl[PGB_CHUNK * 24 + tid] = a.planes[(long)fi * 24 + tid];
+  const int i = a.sweep_row0[s] + b * PG_THREADS + tid;
   bool valid = i < a.sweep_row0[s + 1];
   double x = 0, y = 0, z = 0;
   if (valid) {
     x = (double)a.pts[(long)i * a.F + 0];
     y = (double)a.pts[(long)i * a.F + 1];
     z = (double)a.pts[(long)i * a.F + 2];
-    if (fi >= 0) valid = pg_inside(x, y, z, &lpl[PG_MAX_POLY * 24]);
   }
-  const int lane = threadIdx.x & 63;
-  for (int j = 0; j < np; ++j) {
-    const bool in = valid && pg_inside(x, y, z, &lpl[j * 24]);
-    const unsigned long long m = __ballot(in);
-    if (lane == 0 && m) atomicAdd(&lcnt[j], __popcll(m));
-  }
+  px[tid] = x;
+  py[tid] = y;
+  pz[tid] = z;
   __syncthreads();
-  for (int j = threadIdx.x; j < np; j += PG_THREADS) cnt[a.cnt_off[p0 + j] + b] = lcnt[j];
+  if (valid && fi >= 0) valid = pg_inside(x, y, z, &lpl[PGB_CHUNK * 24]);
+  for (int j0 = 0; j0 < np; j0 += PGB_CHUNK) {
+    const int pc = min(PGB_CHUNK, np - j0);
+    __syncthreads();  // the previous pass has finished with lpl / wmask / queue
+    for (int t = tid; t < pc * 24; t += PG_THREADS) lpl[t] = a.planes[(long)(p0 + j0) * 24 + t];
+    if (tid < PGB_CHUNK * (PG_THREADS / 64)) (&wmask[0][0])[tid] = 0ull;
+    if (tid == 0) qn = 0;
+    __syncthreads();
+    for (int jj = 0; jj < pc; ++jj) {
+      bool in = valid;
+#pragma unroll
+      for (int k = 0; k < PGB_K1; ++k) in = in && pg_below(x, y, z, &lpl[jj * 24 + 4 * k]);
+      const unsigned long long m = __ballot(in);
+      if (m) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&qn, __popcll(m));
+        base = __shfl(base, 0, 64);
+        if (in) queue[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(tid | (jj << 8));
+      }
+    }
+    __syncthreads();
+    const int n = qn;
+    for (int q = tid; q < n; q += PG_THREADS) {
+      const int e = queue[q], pt = e & 255, jj = e >> 8;
+      const double qx = px[pt], qy = py[pt], qz = pz[pt];
+      bool in = true;
+#pragma unroll
+      for (int k = PGB_K1; k < 6; ++k) in = in && pg_below(qx, qy, qz, &lpl[jj * 24 + 4 * k]);
+      if (in) atomicOr(&wmask[jj][pt >> 6], 1ull << (pt & 63));
+    }
+    __syncthreads();
+    if (tid < pc * (PG_THREADS / 64)) {
+      const int jj = tid >> 2, w = tid & 3;
+      msk[((long)a.cnt_off[p0 + j0 + jj] + b) * 4 + w] = wmask[jj][w];
+    }
+    if (tid < pc)
+      cnt[a.cnt_off[p0 + j0 + tid] + b] =
+          __popcll(wmask[tid][0]) + __popcll(wmask[tid][1]) + __popcll(wmask[tid][2]) + __popcll(wmask[tid][3]);
+  }
 }
 
-// per polygon: block counts -> exclusive offsets, total; then the global split over all polygons
-__global__ __launch_bounds__(1024) void pgb_scan_kernel(PgBatch a, int* __restrict__ cnt, int pad_empty,
-                                                        int* __restrict__ split) {
-  for (int j = threadIdx.x; j < a.NPOLY; j += 1024) {
-    int s = 0;  // sweep of polygon j (few sweeps: linear search)
-    while (a.poly0[s + 1] <= j) ++s;
-    const int nblk = (a.sweep_row0[s + 1] - a.sweep_row0[s] + PG_THREADS - 1) / PG_THREADS;
-    int* c = cnt + a.cnt_off[j];
-    int run = 0;
-    for (int b = 0; b < nblk; ++b) {
-      const int v = c[b];
-      c[b] = run;
-      run += v;
-    }
-    cnt[a.cnt_total + j] = run;
+__device__ __forceinline__ int pg_wave_inclusive(int v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int u = __shfl_up(v, d, 64);
+    if (lane >= d) v += u;
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int j = 0; j < a.NPOLY; ++j) {
-      split[j] = run;
-      const int tot = cnt[a.cnt_total + j];
-      run += (tot == 0 && pad_empty) ? 1 : tot;
-    }
-    split[a.NPOLY] = run;
-  }
+  return v;
 }
 
+// one wave per polygon: its block counts -> exclusive offsets, and the polygon's total
+__global__ __launch_bounds__(64) void pgb_scan_kernel(PgBatch a, int* __restrict__ cnt) {
+  const int j = blockIdx.x, lane = threadIdx.x;
+  int s = 0;  // sweep of polygon j (few sweeps: linear search, wave-uniform)
+  while (a.poly0[s + 1] <= j) ++s;
+  const int nblk = (a.sweep_row0[s + 1] - a.sweep_row0[s] + PG_THREADS - 1) / PG_THREADS;
+  int* c = cnt + a.cnt_off[j];
+  int run = 0;
+  for (int b0 = 0; b0 < nblk; b0 += 64) {
+    const int b = b0 + lane;
+    const int v = b < nblk ? c[b] : 0;
+    const int inc = pg_wave_inclusive(v, lane);
+    if (b < nblk) c[b] = run + inc - v;
+    run += __shfl(inc, 63, 64);
+  }
+  if (lane == 0) cnt[a.cnt_total + j] = run;
+}
+
+// one wave: the global split over all polygons (an empty polygon takes one padded row when pad_empty)
+__global__ __launch_bounds__(64) void pgb_split_kernel(const int* __restrict__ tot, int NPOLY, int pad_empty,
+                                                       int* __restrict__ split) {
+  const int lane = threadIdx.x;
+  int run = 0;
+  for (int j0 = 0; j0 < NPOLY; j0 += 64) {
+    const int j = j0 + lane;
+    int v = 0;
+    if (j < NPOLY) {
+      v = tot[j];
+      if (v == 0 && pad_empty) v = 1;
+    }
+    const int inc = pg_wave_inclusive(v, lane);
+    if (j < NPOLY) split[j] = run + inc - v;
+    run += __shfl(inc, 63, 64);
+  }
+  if (lane == 0) split[NPOLY] = run;
+}
+
+// rows of a block to their places: the masks of the count pass say who goes where; a point is read only if some
+// polygon holds it
 __global__ __launch_bounds__(PG_THREADS) void pgb_scatter_kernel(PgBatch a, const int* __restrict__ cnt,
+                                                                 const unsigned long long* __restrict__ msk,
                                                                  const int* __restrict__ split, float* __restrict__ out,
                                                                  int Fo) {
-  __shared__ double lpl[(PG_MAX_POLY + 1) * 24];
-  __shared__ int wcnt[PG_MAX_POLY][PG_THREADS / 64];
+  __shared__ unsigned long long wm[64][PG_THREADS / 64];
+  __shared__ int base[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int s = a.blk_sweep[blockIdx.x];
   const int b = blockIdx.x - a.blk_first[s];
-  const int p0 = a.poly0[s], np = a.poly0[s + 1] - p0, fi = a.filt[s];
-  for (int i = threadIdx.x; i < np * 24; i += PG_THREADS) lpl[i] = a.planes[(long)p0 * 24 + i];
-  if (fi >= 0 && threadIdx.x < 24) lpl[PG_MAX_POLY * 24 + threadIdx.x] = a.planes[(long)fi * 24 + threadIdx.x];
-  __syncthreads();
-  const int i = a.sweep_row0[s] + b * PG_THREADS + threadIdx.x;
-  bool valid = i < a.sweep_row0[s + 1];
+  const int p0 = a.poly0[s], np = a.poly0[s + 1] - p0;
+  const long i = a.sweep_row0[s] + b * PG_THREADS + tid;
   float v[4] = {0.f, 0.f, 0.f, 0.f};
-  if (valid) {
+  bool loaded = false;
+  for (int j0 = 0; j0 < np; j0 += 64) {
+    const int pc = min(64, np - j0);
+    __syncthreads();
+    if (tid < pc * 4) wm[tid >> 2][tid & 3] = msk[((long)a.cnt_off[p0 + j0 + (tid >> 2)] + b) * 4 + (tid & 3)];
+    if (tid < pc) base[tid] = split[p0 + j0 + tid] + cnt[a.cnt_off[p0 + j0 + tid] + b];
+    __syncthreads();
+    for (int jj = 0; jj < pc; ++jj) {
+      const unsigned long long m = wm[jj][wave];
+      if ((m >> lane) & 1ull) {
+        if (!loaded) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-      if (c < a.F) v[c] = a.pts[(long)i * a.F + c];
-  }
-  const double x = (double)v[0], y = (double)v[1], z = (double)v[2];
-  if (valid && fi >= 0) valid = pg_inside(x, y, z, &lpl[PG_MAX_POLY * 24]);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int j = 0; j < np; ++j) {
-    const bool in = valid && pg_inside(x, y, z, &lpl[j * 24]);
-    const unsigned long long m = __ballot(in);
-    if (lane == 0) wcnt[j][wave] = __popcll(m);
-  }
-  __syncthreads();
-  for (int j = 0; j < np; ++j) {
-    const bool in = valid && pg_inside(x, y, z, &lpl[j * 24]);
-    const unsigned long long m = __ballot(in);
-    if (in) {
-      int pos = __popcll(m & ((1ull << lane) - 1ull));
-      for (int w = 0; w < wave; ++w) pos += wcnt[j][w];
-      float* o = out + ((long)split[p0 + j] + cnt[a.cnt_off[p0 + j] + b] + pos) * Fo;
-      o[0] = v[0];
-      o[1] = v[1];
-      o[2] = v[2];
-      if (Fo == 4) o[3] = v[3];
+          for (int c = 0; c < 4; ++c)
+            if (c < a.F) v[c] = a.pts[i * a.F + c];
+          loaded = true;
+        }
+        int pos = __popcll(m & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; ++w) pos += __popcll(wm[jj][w]);
+        float* o = out + ((long)base[jj] + pos) * Fo;
+        o[0] = v[0];
+        o[1] = v[1];
+        o[2] = v[2];
+        if (Fo == 4) o[3] = v[3];
+      }
     }
   }
+}
+
+__device__ __host__ inline long pgb_mask_offset(int cnt_total, int NPOLY) {
+  return ((long)cnt_total + NPOLY + 1) & ~1L;  // the 64-bit masks follow the counters and totals, 8-byte aligned
 }
 
 extern "C" int mmmot_points_count_batched(const float* pts, int F, int NS, int NPOLY, int NBLK, int cnt_total,
@@ -284,8 +360,10 @@ extern "C" int mmmot_points_count_batched(const float* pts, int F, int NS, int N
     return MMMOT_EINVAL;
   if ((F != 3 && F != 4) || NS <= 0 || NPOLY <= 0 || NBLK <= 0) return MMMOT_EINVAL;
   PgBatch a{pts, planes, blk_sweep, blk_first, sweep_row0, poly0, filt, cnt_off, F, NS, NPOLY, cnt_total};
-  hipLaunchKernelGGL(pgb_count_kernel, dim3(NBLK), dim3(PG_THREADS), 0, s, a, cnt);
-  hipLaunchKernelGGL(pgb_scan_kernel, dim3(1), dim3(1024), 0, s, a, cnt, pad_empty, split);
+  hipLaunchKernelGGL(pgb_count_kernel, dim3(NBLK), dim3(PG_THREADS), 0, s, a, cnt,
+                     (unsigned long long*)(cnt + pgb_mask_offset(cnt_total, NPOLY)));
+  hipLaunchKernelGGL(pgb_scan_kernel, dim3(NPOLY), dim3(64), 0, s, a, cnt);
+  hipLaunchKernelGGL(pgb_split_kernel, dim3(1), dim3(64), 0, s, cnt + cnt_total, NPOLY, pad_empty, split);
   return mm_check(hipGetLastError());
 }
 
@@ -299,7 +377,8 @@ extern "C" int mmmot_points_scatter_batched(const float* pts, int F, int NS, int
     return MMMOT_EINVAL;
   if ((F != 3 && F != 4) || (Fo != 3 && Fo != F) || NS <= 0 || NPOLY <= 0 || NBLK <= 0) return MMMOT_EINVAL;
   PgBatch a{pts, planes, blk_sweep, blk_first, sweep_row0, poly0, filt, cnt_off, F, NS, NPOLY, cnt_total};
-  hipLaunchKernelGGL(pgb_scatter_kernel, dim3(NBLK), dim3(PG_THREADS), 0, s, a, cnt, split, out, Fo);
+  hipLaunchKernelGGL(pgb_scatter_kernel, dim3(NBLK), dim3(PG_THREADS), 0, s, a, cnt,
+                     (const unsigned long long*)(cnt + pgb_mask_offset(cnt_total, NPOLY)), split, out, Fo);
   hipLaunchKernelGGL(pg_pad_kernel, dim3((NPOLY + 63) / 64), dim3(64), 0, s, cnt + cnt_total, split, NPOLY, out, Fo);
   return mm_check(hipGetLastError());
 }

@@ -146,6 +146,17 @@ def prep_points(points, info, dets, use_frustum=False, without_reflectivity=Fals
 
 
 # ---- batched: many sweeps per launch, image-frustum filter fused into the per-box test -----------------------
+_STAGE = {}
+
+
+def _staging(nbytes):
+    """pinned host buffer for the per-batch table upload (grown geometrically, one per process)"""
+    t = _STAGE.get('buf')
+    if t is None or t.numel() < nbytes:
+        t = _STAGE['buf'] = torch.empty(max(1 << 16, 2 * nbytes), dtype=torch.uint8).pin_memory()
+    return t
+
+
 def gather_points_batched(points, sweep_rows, planes, poly_counts, filters=None, pad_empty=True,
                           drop_reflectivity=False):
     """points: device fp32 [sum P_s, F] (the sweeps concatenated); sweep_rows: NS + 1 row offsets;
@@ -176,11 +187,28 @@ def gather_points_batched(points, sweep_rows, planes, poly_counts, filters=None,
     cnt_off = np.concatenate([[0], np.cumsum(np.repeat(nblk, poly_counts))])
     cnt_total = int(cnt_off[-1])
     dev = points.device
-    up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
-    d_blk_sweep, d_blk_first, d_rows, d_poly0, d_filt, d_off = (up(blk_sweep), up(blk_first[:-1]), up(sweep_rows),
-                                                                up(poly0), up(filt), up(cnt_off[:-1]))
-    pl = torch.as_tensor(np.ascontiguousarray(planes, dtype=np.float64)).to(dev)
-    cnt = torch.empty(cnt_total + NPOLY, dtype=torch.int32, device=dev)
+    # ONE upload per batch: the six integer tables and the float64 plane table travel in one pinned staging buffer and
+    # one asynchronous copy
+    tabs = [np.ascontiguousarray(t, dtype=np.int32) for t in (blk_sweep, blk_first[:-1], sweep_rows, poly0, filt, cnt_off[:-1])]
+    pl_h = np.ascontiguousarray(planes, dtype=np.float64)
+    offs, o = [], 0
+    for t in tabs:
+        offs.append(o)
+        o += (t.nbytes + 15) // 16 * 16
+    pl_off = o
+    total = pl_off + pl_h.nbytes
+    stage = _staging(total)
+    hb = stage.numpy()
+    for t, off in zip(tabs, offs):
+        hb[off:off + t.nbytes] = t.view(np.uint8).reshape(-1)
+    hb[pl_off:total] = pl_h.view(np.uint8).reshape(-1)
+    dbuf = torch.empty(total, dtype=torch.uint8, device=dev)
+    dbuf.copy_(stage[:total], non_blocking=True)
+    d_blk_sweep, d_blk_first, d_rows, d_poly0, d_filt, d_off = [
+        dbuf[off:off + t.nbytes].view(torch.int32) for t, off in zip(tabs, offs)]
+    pl = dbuf[pl_off:total].view(torch.float64)
+    # counters, totals and (8-byte aligned) the four 64-bit wave masks per counter the scatter pass reads back
+    cnt = torch.empty(((cnt_total + NPOLY + 1) & ~1) + 8 * cnt_total, dtype=torch.int32, device=dev)
     split = torch.empty(NPOLY + 1, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     common = (_ptr(points), F, NS, NPOLY, NBLK, cnt_total, pl.data_ptr(), _iptr(d_blk_sweep), _iptr(d_blk_first),

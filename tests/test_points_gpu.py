@@ -98,3 +98,43 @@ def test_batched_gather_frustum_path_and_many_sweeps():
     for r in res:
         assert r['points_split'] == z['ref_split'].tolist()
         assert np.array_equal(r['points'].cpu().numpy(), z['ref_points'])
+
+
+@pytest.mark.parametrize('filtered', [False, True], ids=['no_filter', 'filter'])
+def test_batched_gather_many_polygons_per_sweep_vs_oracle(filtered):
+    """Sweeps with 1, 16, 17, 70 and 256 polygons (one and many 16-polygon membership passes, more than one
+    64-polygon scatter pass), ragged point counts incl. one point and a block boundary, boxes that hold a large
+    share of a sweep (long LDS queues), F = 3 and 4: rows and split == the oracle's per-box gather, bit for bit."""
+    rng = np.random.default_rng(77 + filtered)
+    for F in (3, 4):
+        npts = [1, 256, 257, 3000, 1500]
+        npoly = [1, 16, 17, 70, 256]
+        sweeps, planes, exp_rows, exp_split = [], [], [], [0]
+        filt_planes = []
+        for P, N in zip(npts, npoly):
+            pts = rng.uniform(-10, 10, (P, F)).astype(np.float32)
+            boxes = np.concatenate([rng.uniform(-8, 8, (N, 3)), rng.uniform(0.5, 6, (N, 3)), rng.uniform(-3, 3, (N, 1))], 1)
+            boxes[0, 3:6] = 30.0  # one box that swallows most of the sweep
+            pl = O.rbbox_planes(boxes)
+            src = pts
+            if filtered:  # the filter polygon: a big box of its own; emitted rows must be inside both
+                fbox = np.array([[1.0, -1.0, 0.0, 14.0, 16.0, 18.0, 0.3]])
+                fpl = O.rbbox_planes(fbox)
+                filt_planes.append(fpl)
+                keep = pts[O.inside_planes(pts, fpl)[:, 0]]
+                src = keep
+            if len(src):
+                rows, split = O.gather_per_box(src, pl)
+            else:  # nothing survives the filter: every polygon owns its one zero row
+                rows, split = np.zeros((N, F), np.float32), np.arange(N + 1)
+            exp_rows.append(rows.astype(np.float32))
+            exp_split.extend((np.asarray(split[1:]) + exp_split[-1]).tolist())
+            sweeps.append(pts)
+            planes.append(pl)
+        rows0 = np.concatenate([[0], np.cumsum(npts)])
+        allpl = np.concatenate(planes + filt_planes)
+        filters = [sum(npoly) + i for i in range(len(npts))] if filtered else None
+        got, gsplit = PT.gather_points_batched(torch.from_numpy(np.concatenate(sweeps)).cuda(), rows0, allpl, npoly,
+                                               filters=filters, pad_empty=True)
+        assert gsplit.tolist() == exp_split
+        assert np.array_equal(got.cpu().numpy(), np.concatenate(exp_rows))
