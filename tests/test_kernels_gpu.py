@@ -545,6 +545,7 @@ def test_gemm_ares_statistics_and_colsum(hip, K, N):
     (1024, [[2048] * 9, [2048] * 7, [100]], False),                      # conv5's shape: full tiles, several per sequence
     (512, [[64] * 40], False),                                           # one channel half; every second half tile empty
     (1536, [[700, 33], [128]], True),                                    # three channel halves
+    (1024, [[2048] * 40, [300] * 30, [31, 95, 129]], True),              # five and more tiles per workgroup, ragged tails mid-sequence
 ])
 def test_gemm_ares_weights_in_registers_kernel(hip, N, dets, with_dbias):
     """the K = 128 consumer pass on the weights-in-registers kernel (csrc/gemm_wreg.hip): fp64 emulation, and the streaming
