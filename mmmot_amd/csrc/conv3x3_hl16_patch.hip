@@ -1523,6 +1523,8 @@ template <int BN, int BS, bool POOL>
 static int launch_patch(const void* in, const void* wp, const float* bias, void* out, int L, int H, int W, int Cin,
                         int Cout, const float* oscale, hipStream_t s) {
 #ifdef MMMOT_DEBUG
+  if constexpr (BN == 128 && BS == 16)  // phase timers: pooled and unpooled (tools/patch_phase_timers_f16x3.py)
+    if (g_patch_exp == 9) return launch_patch_e<BN, BS, POOL, 9>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
   if constexpr (BN == 128 && BS == 16 && !POOL) {  // the experiments exist for one instantiation only
     switch (g_patch_exp) {
       case 1: return launch_patch_e<BN, BS, POOL, 1>(in, wp, bias, out, L, H, W, Cin, Cout, oscale, s);
