@@ -592,6 +592,54 @@ def test_gemm_ares_weights_in_registers_kernel(hip, N, dets, with_dbias):
         assert torch.equal(outs[2], outs[1]), 'register-resident and streaming kernels differ'
 
 
+@pytest.mark.parametrize('seed', [0, 1, 2, 3, 4, 5])
+def test_gemm_ares_register_kernel_random_tilings_bitwise(hip, seed):
+    """the pipelined register-weights kernel against the streaming kernel on random detection sizes (1 .. 3000 points:
+    ragged tiles at every position of a workgroup's tile sequence, empty second halves, one-row tiles), random sample
+    sizes, with and without per-detection bias rows, N = 512 / 1024 / 2048 - bitwise, twice (the kernel's LDS-DMA
+    pipeline has no data-dependent timing in its results)"""
+    from mmmot_amd import _lib
+    from mmmot_amd.pack import hl16_weight_shift, to_hl16
+    from mmmot_amd.plan import HalfTiles
+    lib = _lib.load()
+    rng = np.random.default_rng(1000 + seed)
+    K = 128
+    N = int(rng.choice([512, 1024, 2048]))
+    G = int(rng.integers(1, 4))
+    dets = [[int(v) for v in rng.choice([1, 31, 32, 33, 64, 65, 127, 128, 129, 300, 1000, 2048, 3000],
+                                        size=int(rng.integers(3, 40)))] for _ in range(G)]
+    with_dbias = bool(seed & 1)
+    counts = [sum(d) for d in dets]
+    gpu = RowTiles(counts, 'cuda', sub_counts=dets)
+    hc = HalfTiles(RowTiles(counts, 'cpu', sub_counts=dets), 'cpu')
+    flat = [c for d in dets for c in d]
+    ndet, R = len(flat), sum(counts)
+    X = (rnd(R, K, seed=300 + seed) + 0.5).cuda()
+    W = rnd(N, K, seed=301 + seed, scale=K ** -0.5)
+    bias = rnd(N, seed=302 + seed).cuda()
+    sc, sh = (rnd(G, K, seed=303 + seed).abs() + 0.5).cuda(), rnd(G, K, seed=304 + seed).cuda()
+    dbias = rnd(ndet, N, seed=305 + seed).cuda() if with_dbias else None
+    cpu_tiles = RowTiles(counts, 'cpu', sub_counts=dets)
+    tile_det = torch.repeat_interleave(torch.arange(ndet), torch.tensor(cpu_tiles.h_sub_ntiles).long()).int().cuda()
+    osc, osh = (rnd(G, N, seed=306 + seed).abs() + 0.5).cuda(), rnd(G, N, seed=307 + seed).cuda()
+    shift = hl16_weight_shift(W)
+    W16 = to_hl16(W.double() * 2.0 ** shift).cuda()
+    outs = []
+    try:
+        for v in (1, 2, 2):
+            assert lib.mmmot_set_gemm_ares_variant(v) == 0
+            cg = torch.full((hc.T, N), float('nan')).cuda()
+            hip.gemm_ares(W16, 2.0 ** -shift, gpu, N, K, X, sc, sh, bias=bias, dbias=dbias,
+                          tile_dbrow=tile_det if with_dbias else None, osc=osc, osh=osh, colsum=cg)
+            outs.append(cg.cpu())
+    finally:
+        assert lib.mmmot_set_gemm_ares_variant(0) == 0
+    assert not torch.isnan(outs[1]).any()
+    assert torch.equal(outs[1], outs[2]), 'register kernel: two launches differ'
+    if N % 256 == 0:
+        assert torch.equal(outs[1], outs[0]), 'register-resident and streaming kernels differ'
+
+
 @pytest.mark.parametrize('K,N', [(128, 1024), (64, 192)])
 def test_gram_statistics_match_direct_statistics(hip, K, N):
     """GroupNorm(N, N) scale/shift of v = W relu(X*sc+sh) + b from the Gram matrix of the input (gram_rows +
