@@ -243,17 +243,20 @@ typedef struct mmmot_gemm_args {
    * rows per segment) finishes the mean. */
   const float* osc; const float* osh; int ldosc;   /* [G][ldosc] or NULL                */
   float* colsum;                        /* [T][N] or NULL                     */
-  /* ABI 7 (appended).  PAIR: nonzero = the caller guarantees grp_M[g] % 32 == 0 for every group, i.e. the 32 rows of
-   * every 32-row block of a tile share their a_i row; the wide kernel (csrc/gemm_wide.hip) then stages that row in LDS
-   * once per wave instead of requesting it per lane (it serves PAIR launches only with this guarantee). */
+  /* ABI 7 (appended).  PAIR: nonzero = the caller guarantees BOTH grp_M[g] % 32 == 0 for every group AND
+   * (tile_row0[t] - grp_row0[tile_group[t]]) % 32 == 0 for every tile (tiles cut every 128 rows from the start of their
+   * group satisfy the second condition), i.e. the 32 rows of every 32-row block of a tile share their a_i row; the wide
+   * kernel (csrc/gemm_wide.hip) then stages that row in LDS once per wave instead of requesting it per lane (it serves
+   * PAIR launches only with this guarantee, takes a_i from the block's first row, and returns WRONG Y - silently - for a
+   * caller that sets the flag on ragged or unaligned pair tiles).  0 is always safe: the tile kernel serves the launch. */
   int pair_uniform32;
 } mmmot_gemm_args;
 int mmmot_gemm_rows(const mmmot_gemm_args* a, void* stream);
 /* ABI 7.  tests: which kernel serves mmmot_gemm_rows - 0 = automatic (the wide kernel of csrc/gemm_wide.hip for the
  * K >= 256 layers of the pairwise block, reference modules/gcn.py:59-66 / new_end.py:48-52, when w_hl16 = 1, amode is
- * PAIR or NORM_RELU, N % 512 == 0, no dbias / colsum / activation and the launch fills the chip), 1 = the tile kernel
- * only (the kernel before ABI 7), 2 = the wide kernel whenever the layer is eligible (N % 128 == 0, K >= 64, any
- * size).  Y does not depend on it, bit for bit; part (per-tile statistics) to rounding. */
+ * PAIR or NORM_RELU, N % 256 == 0, no dbias / colsum / activation and the launch fills the chip), 1 = the tile kernel
+ * only (the kernel before ABI 7), 2 = the wide kernel whenever the layer is eligible (N % 128 == 0, K = 256 or 512,
+ * any size).  Y does not depend on it, bit for bit; part (per-tile statistics) to rounding. */
 int mmmot_set_gemm_rows_variant(int v);
 
 /* A-resident row GEMM for layers whose output is only ever reduced (PointNet conv5 128->1024 and

@@ -192,8 +192,14 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restri
   red[(long)g * (KK + K) + idx] = s;
 }
 
-// scale / shift of GroupNorm(N, N) applied to v = W a + b: one workgroup per (group, 16 output channels);
-// Cov(a) lives in LDS as float64 (K = 128: 128 KB).
+// scale / shift of GroupNorm(N, N) applied to v = W a + b: one workgroup per (group, GF_CH output channels);
+// Cov(a) lives in LDS as float64 (K = 128: 128 KB).  A wave takes GF_CH / 4 channels, four at a time: every
+// covariance element it reads from LDS feeds four float64 FMAs (the weights of the four channels are wave-uniform:
+// scalar loads), so the kernel is bound by its 2 G N K^2 float64 FLOPs (~15 us at G = 32) instead of by LDS reads
+// and by the 64 workgroups per group that each rebuilt the covariance (round 4: 222 us at G = 32).  Per channel
+// the sums run in the order of the one-channel loop they replace (j ascending per row, rows lane, lane + 64, then
+// the xor tree): scale / shift are bit for bit the same.
+#define GF_CH 64
 template <int K>
 __global__ __launch_bounds__(256) void gn_finalize_gram_kernel(const double* __restrict__ red,
                                                                const int* __restrict__ grp_count,
@@ -204,37 +210,69 @@ __global__ __launch_bounds__(256) void gn_finalize_gram_kernel(const double* __r
                                                                float* __restrict__ sc, float* __restrict__ sh) {
   __shared__ double C[K * K];
   __shared__ double m[K];
-  const int g = blockIdx.x, n0 = blockIdx.y * 16;
+  constexpr int NR = K / 64;  // rows of C per lane
+  const int g = blockIdx.x, n0 = blockIdx.y * GF_CH;
   const double cnt = (double)grp_count[g];
   const double* R = red + (long)g * (K * K + K);
   for (int k = threadIdx.x; k < K; k += 256) m[k] = R[K * K + k] / cnt;
   __syncthreads();
   for (int idx = threadIdx.x; idx < K * K; idx += 256) C[idx] = R[idx] / cnt - m[idx / K] * m[idx % K];
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int cc = wave; cc < 16; cc += 4) {
-    const int n = n0 + cc;
-    if (n >= N) break;
-    const float* w = Wm + (long)n * K;
-    // y = C w restricted to this lane's rows; var = w . y, mean = w . m + b
-    double var = 0.0, mean = 0.0;
-    for (int i = lane; i < K; i += 64) {
-      double y = 0.0;
-      for (int j = 0; j < K; ++j) y += C[j * K + i] * (double)w[j];  // C is symmetric: lanes read consecutive doubles
-      var += (double)w[i] * y;
-      mean += (double)w[i] * m[i];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int c4 = 0; c4 < GF_CH / 4; c4 += 4) {
+    const int nb = n0 + wave * (GF_CH / 4) + c4;  // wave-uniform: channels nb .. nb + 3
+    if (nb >= N) break;
+    const float* w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[q] = Wm + (long)(nb + q < N ? nb + q : nb) * K;
+    double y[4][NR];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < NR; ++r) y[q][r] = 0.0;
+    for (int j0 = 0; j0 < K; j0 += 8) {  // C is symmetric: lanes read consecutive doubles of row j
+      float wv[4][8];  // wave-uniform: eight weights of each of the four channels (one scalar load per channel)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wv[q][e] = w[q][j0 + e];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        double c[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) c[r] = C[(j0 + e) * K + lane + 64 * r];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double wj = (double)wv[q][e];
+#pragma unroll
+          for (int r = 0; r < NR; ++r) y[q][r] += c[r] * wj;
+        }
+      }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      var += __shfl_xor(var, o);
-      mean += __shfl_xor(mean, o);
-    }
-    if (lane == 0) {
-      mean += bias ? (double)bias[n] : 0.0;
-      var = var > 0.0 ? var : 0.0;
-      const double scv = (double)gamma[n] / sqrt(var + (double)eps);
-      sc[(long)g * N + n] = (float)scv;
-      sh[(long)g * N + n] = (float)((double)beta[n] - mean * scv);
+    for (int q = 0; q < 4; ++q) {
+      const int n = nb + q;
+      // var = w . (C w), mean = w . m + b
+      double var = 0.0, mean = 0.0;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int i = lane + 64 * r;
+        var += (double)w[q][i] * y[q][r];
+        mean += (double)w[q][i] * m[i];
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        var += __shfl_xor(var, o);
+        mean += __shfl_xor(mean, o);
+      }
+      if (lane == 0 && n < N) {
+        mean += bias ? (double)bias[n] : 0.0;
+        var = var > 0.0 ? var : 0.0;
+        const double scv = (double)gamma[n] / sqrt(var + (double)eps);
+        sc[(long)g * N + n] = (float)scv;
+        sh[(long)g * N + n] = (float)((double)beta[n] - mean * scv);
+      }
     }
   }
 }
@@ -266,10 +304,10 @@ extern "C" int mmmot_gn_finalize_gram(const double* Gp, const double* Sp, const 
   hipLaunchKernelGGL(gram_reduce_kernel, dim3((K * K + K + 255) / 256, G), dim3(256), 0, s, Gp, Sp, grp_tile0,
                      grp_ntiles, K, work);
   if (K == 128)
-    hipLaunchKernelGGL(gn_finalize_gram_kernel<128>, dim3(G, (N + 15) / 16), dim3(256), 0, s, work, grp_count, W, bias,
+    hipLaunchKernelGGL(gn_finalize_gram_kernel<128>, dim3(G, (N + GF_CH - 1) / GF_CH), dim3(256), 0, s, work, grp_count, W, bias,
                        N, gamma, beta, eps, sc, sh);
   else
-    hipLaunchKernelGGL(gn_finalize_gram_kernel<64>, dim3(G, (N + 15) / 16), dim3(256), 0, s, work, grp_count, W, bias,
+    hipLaunchKernelGGL(gn_finalize_gram_kernel<64>, dim3(G, (N + GF_CH - 1) / GF_CH), dim3(256), 0, s, work, grp_count, W, bias,
                        N, gamma, beta, eps, sc, sh);
   return mm_check(hipGetLastError());
 }

@@ -48,6 +48,8 @@ class Engine:
         self.last_out_of_range_forward = None  # index of the latest forward whose out-of-range results were already returned
         self._n_forward = 0
         self._range_buf = self._range_host = self._range_pending = None
+        self._range_win0 = 0  # first forward whose trunk launches no inspected / queued read-back covers yet
+        self.out_of_range_window = None  # (first, last) forward indices of the latest asynchronous detection
         self._busy = threading.Lock()  # see forward()
         self._last_stream = None
         self._image_token = None  # image_first(): the image branch of the next forward is already in the workspace
@@ -300,22 +302,31 @@ class Engine:
             return 'f16x3'
         return None
 
-    def _range_event(self, plan, lower, sat, clamp, c11, recomputed):
-        # `affected_forward`: index (count of forwards of this engine, from 0) of the forward whose trunk ran out of
-        # range.  recomputed=True: that forward's results were recomputed in the lowered arithmetic before they were
-        # returned; False (asynchronous read-back): they were ALREADY RETURNED - the caller discards / repeats the
-        # forward with that index (`Engine.forward_index` of a result = the value of `_n_forward - 1` after the call;
-        # `Engine.last_out_of_range_forward` keeps the latest such index, None while there was none) - ADVICE r3
-        affected = self._n_forward if recomputed else self._n_forward - 1
-        ev = dict(forward=self._n_forward, affected_forward=affected, was=self.trunk, now=lower, e4m3_saturated=sat,
-                  fp16_clamped=clamp, conv1_1_hits=c11, trunk_elements=self.trunk_elements(plan), recomputed=recomputed)
+    def _range_event(self, plan, lower, sat, clamp, c11, recomputed, window=None):
+        # `affected_forwards` = (first, last): indices (count of forwards of this engine, from 0) of the forwards whose
+        # trunk launches the counters that tripped cover.  recomputed=True: one forward, the current one, and its results
+        # were recomputed in the lowered arithmetic before they were returned.  False (asynchronous read-back): a read-back
+        # is recorded behind forward k and inspected once its copy has completed - possibly several forwards later, and no
+        # new one is queued meanwhile - so it covers every forward since the previous read-back up to k, NOT "the previous
+        # forward": `window` carries exactly that range, stored with the pending copy when it was recorded.
+        # Those results were ALREADY RETURNED: the caller discards / repeats the forwards first .. last
+        # (`Engine.forward_index` of a result = the value of `_n_forward - 1` after the call; `last_out_of_range_forward`
+        # = last and `out_of_range_window` = (first, last) keep the latest detection, None while there was none).
+        # `affected_forward` (the last index of the range) is kept for callers of the round-3 interface.
+        if recomputed or window is None:
+            window = (self._n_forward, self._n_forward)
+        ev = dict(forward=self._n_forward, affected_forward=window[1], affected_forwards=tuple(window), was=self.trunk,
+                  now=lower, e4m3_saturated=sat, fp16_clamped=clamp, conv1_1_hits=c11,
+                  trunk_elements=self.trunk_elements(plan), recomputed=recomputed)
         self.range_events.append(ev)
         if not recomputed:
-            self.last_out_of_range_forward = affected
+            self.last_out_of_range_forward = window[1]
+            self.out_of_range_window = tuple(window)
         warnings.warn('mmmot_amd range guard: trunk arithmetic %(was)s -> %(now)s (%(e4m3_saturated)d activation '
                       'elements beyond the e4m3 range, %(fp16_clamped)d beyond the fp16 range, of %(trunk_elements)d '
                       'per forward); ' % ev + ('the trunk of this forward is recomputed' if recomputed else
-                                               'detected one step late: the PREVIOUS forward ran out of range'),
+                                               'detected late: forwards %d..%d of this engine ran out of range and were '
+                                               'already returned' % tuple(window)),
                       RuntimeWarning, stacklevel=4)
         self.trunk = lower
 
@@ -340,20 +351,21 @@ class Engine:
         guard = self.trunk != 'f32' and not capturing
         # ---- verdict of the previous forward's asynchronous read-back -------------------------------------------
         if guard and self._range_pending is not None:
-            ev = self._range_pending
+            ev, w0, w1 = self._range_pending
             if ev is True or ev.query():
                 self._range_pending = None
                 v = [int(x) & 0xFFFFFFFF for x in self._range_host.tolist()[:3]]
                 sat, clamp, c11 = [(a - b) & 0xFFFFFFFF for a, b in zip(v, self._range_seen)]
                 self._range_seen = v
-                lower = self._range_verdict(plan, sat, clamp, c11, 1)
+                lower = self._range_verdict(plan, sat, clamp, c11, w1 - w0 + 1)
                 if lower is not None:
-                    self._range_event(plan, lower, sat, clamp, c11, recomputed=False)
+                    self._range_event(plan, lower, sat, clamp, c11, recomputed=False, window=(w0, w1))
                     guard = self.trunk != 'f32'
         sync = guard and (first or (self.range_check_every > 0 and self._n_forward % self.range_check_every == 0))
         if sync:
             self.read_range(reset=True)  # open the window of this forward (drops whatever a skipped read-back left)
             self._range_pending = None
+            self._range_win0 = self._n_forward
         ops.trunk_range_bind(blk)
         try:
             self.appearance(plan, crops, cat)
@@ -369,12 +381,15 @@ class Engine:
         if guard and not sync and self.trunk != 'f32' and self._range_pending is None:
             # stream-ordered: copy the (cumulative) block out and mark the point - inspected by the next forward
             self._range_host.copy_(blk, non_blocking=True)
+            e = True
             if dev.type == 'cuda':
                 e = torch.cuda.Event()
                 e.record()
-                self._range_pending = e
-            else:
-                self._range_pending = True
+            # the counters are cumulative: this copy covers the forwards since the previous read-back up to this one
+            self._range_pending = (e, self._range_win0, self._n_forward)
+            self._range_win0 = self._n_forward + 1
+        elif sync:
+            self._range_win0 = self._n_forward + 1  # checked (and, if need be, recomputed) synchronously
         self._n_forward += 1
 
     def _skippool(self, plan, s, x, hw, C, cat, hl16=False):
@@ -549,8 +564,9 @@ class Engine:
         ops, lk, PT, VT = self.ops, self.P['w_link'], plan.pair_tiles, plan.v_tiles
         nR, Lt, R = plan.nR, plan.Lt, plan.pair_tiles.R
         Ff = F.view(nR * Lt, 512)
-        pair = dict(row0=PT.g_row0, M=plan.pg_M, aoff=plan.pg_aoff, boff=plan.pg_boff,
-                    uniform32=bool(len(plan.h_pg_M)) and bool((np.asarray(plan.h_pg_M) % 32 == 0).all()))
+        # uniform32 (include/mmmot_hip.h: pair_uniform32): every 32-row block of a pair tile lies inside one i - needs
+        # M % 32 == 0 in every group AND tiles that start a multiple of 32 rows into their group
+        pair = dict(row0=PT.g_row0, M=plan.pg_M, aoff=plan.pg_aoff, boff=plan.pg_boff, uniform32=plan.pair_uniform32)
         # stacked [new_end.conv0 ; conv1.0] over the on-the-fly pairwise tensor
         ya = self.buf('aff_ya', R, 1024)
         part = self._part(PT, 1024)

@@ -242,6 +242,12 @@ class BatchPlan:
         self.h_pg_N, self.h_pg_M = np.asarray(g_N), np.asarray(g_M)
         self.h_pg_aoff, self.h_pg_boff = np.asarray(g_aoff), np.asarray(g_boff)
         self.max_nm = int(max(n + m for n, m in zip(g_N, g_M)))
+        # mmmot_gemm_args.pair_uniform32: every 32-row block of every pair tile lies inside one previous-frame index i -
+        # M % 32 == 0 in every group AND every tile starts a multiple of 32 rows into its group (RowTiles cuts a group
+        # every TILE = 128 rows, so the second condition holds by construction; checked, not assumed - ADVICE r4)
+        PT = self.pair_tiles
+        self.pair_uniform32 = bool(len(g_M)) and bool((self.h_pg_M % 32 == 0).all()) and \
+            bool(((PT.h_row0 - PT.h_g_row0[PT.h_group]) % 32 == 0).all())
         self.link_off = [int(self.pair_tiles.h_g_row0[p * nR]) for p in range(len(pairs))]
 
         # ---- new / end vectors ------------------------------------------

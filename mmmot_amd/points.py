@@ -9,6 +9,8 @@ algebra and the plane equations of every box / frustum (float64 numpy, the opera
 point_cloud/box_np_ops.py:147-178,236-254,312-337,442-493,584-618,702-720 and geometry.py:84-93 in the same
 order so that the planes - and therefore every inside/outside decision - agree with the reference).
 """
+import threading
+
 import numpy as np
 import torch
 
@@ -146,14 +148,18 @@ def prep_points(points, info, dets, use_frustum=False, without_reflectivity=Fals
 
 
 # ---- batched: many sweeps per launch, image-frustum filter fused into the per-box test -----------------------
-_STAGE = {}
+_STAGE = threading.local()
 
 
 def _staging(nbytes):
-    """pinned host buffer for the per-batch table upload (grown geometrically, one per process)"""
-    t = _STAGE.get('buf')
+    """Pinned host buffer for the per-batch table upload, grown geometrically, ONE PER THREAD: the buffer is filled on
+    the host and copied with non_blocking=True, and what makes its reuse safe is the ``split.cpu()`` of the same call,
+    which synchronises the CALLING thread's stream behind that copy.  A process-wide buffer (round 4) could be
+    overwritten - or replaced on growth - by a second thread while the first one's copy was still queued behind trunk
+    work (the library supports one model per thread: ``HipOps._tls``)."""
+    t = getattr(_STAGE, 'buf', None)
     if t is None or t.numel() < nbytes:
-        t = _STAGE['buf'] = torch.empty(max(1 << 16, 2 * nbytes), dtype=torch.uint8).pin_memory()
+        t = _STAGE.buf = torch.empty(max(1 << 16, 2 * nbytes), dtype=torch.uint8).pin_memory()
     return t
 
 

@@ -122,3 +122,19 @@ def calibrate_bn(sd, crops, eps=1e-5):
             if pool:
                 x = F.max_pool2d(x, 2, 2)
     return sd
+
+
+def state_dict_for_profile(spec, weights='default:0', S=64):
+    """State dict for the golden-fixture manifest's ``weights`` field: ``'default:<seed>'`` = generate_state_dict (the
+    He-normal law of every round-1..4 fixture, seed 0) or ``'calibrated:<seed>'`` = the trained-like 'calibrated'
+    profile (per-channel folded gains over > 1e4, heavy-tailed weights) with the VGG BatchNorm statistics calibrated on
+    sixteen sample crops of side ``S`` (seed 4100 + <seed>) - the recipe of tests/test_robust_gpu.py."""
+    kind, _, seed = weights.partition(':')
+    seed = int(seed or 0)
+    if kind == 'default':
+        return generate_state_dict(spec, seed)
+    if kind == 'calibrated':
+        from .synth import make_pair
+        sd = generate_state_dict_trained(spec, seed, 'calibrated')
+        return calibrate_bn(sd, make_pair(8, 8, S, 4, seed=4100 + seed)[0])
+    raise ValueError('unknown weights profile %r' % (weights,))

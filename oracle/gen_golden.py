@@ -39,7 +39,7 @@ import torch.nn.functional as F
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from mmmot_amd.synth import make_pair  # noqa: E402
-from mmmot_amd.weights import generate_state_dict  # noqa: E402
+from mmmot_amd.weights import state_dict_for_profile  # noqa: E402
 from oracle import restatement as R  # noqa: E402
 
 REF = '/root/reference'
@@ -62,12 +62,13 @@ def import_reference():
     return ref_modules
 
 
-def build_reference(ref_modules, fusion, affinity_op, softmax_mode, seq_len=2, end_mode='avg', refl=False):
+def build_reference(ref_modules, fusion, affinity_op, softmax_mode, seq_len=2, end_mode='avg', refl=False,
+                    weights='default:0', S=64):
     kw = dict(BASE, score_fusion_arch=fusion, affinity_op=affinity_op, softmax_mode=softmax_mode, seq_len=seq_len,
               end_mode=end_mode, without_reflectivity=not refl)
     with contextlib.redirect_stdout(io.StringIO()):
         m = ref_modules.TrackingNet(**kw)
-    sd = generate_state_dict(m.state_dict(), seed=0)
+    sd = state_dict_for_profile(m.state_dict(), weights, S)
     m.load_state_dict(sd, strict=True)
     m.eval()
     return m, sd
@@ -121,6 +122,13 @@ CASES.append(dict(name='f_cfg3_ragged_C', fusion='C', aff='multiply', sm='none',
                   ragged=True, seed=1006, full=True))
 CASES.append(dict(name='f_cfg4_ragged_B', fusion='B', aff='minus_abs', sm='dual_add', N=128, M=97, S=64, pts=256,
                   ragged=True, seed=1007, full=True))
+# full size on OTHER weight statistics than the seed-0 He-normal law of every case above (`weights`, see
+# mmmot_amd.weights.state_dict_for_profile): trained-like 'calibrated' statistics (per-channel folded gains over > 1e4,
+# Student-t weights, BatchNorm calibrated on sample crops) and a second seed of the default law
+CASES.append(dict(name='f_cfg3_C_calibrated', fusion='C', aff='multiply', sm='none', N=64, M=64, S=128, pts=2048,
+                  ragged=False, seed=1000, full=True, weights='calibrated:0'))
+CASES.append(dict(name='f_cfg3_C_seed1', fusion='C', aff='multiply', sm='none', N=64, M=64, S=128, pts=2048,
+                  ragged=False, seed=1000, full=True, weights='default:1'))
 
 
 def dump_state_dict_manifest(ref_modules):
@@ -159,10 +167,11 @@ def main():
             if c['name'] in old:
                 manifest.append(old[c['name']])
             continue
-        key = (c['fusion'], c['aff'], c['sm'], len(c.get('counts', [0, 0])), c.get('end_mode', 'avg'), bool(c.get('refl')))
+        key = (c['fusion'], c['aff'], c['sm'], len(c.get('counts', [0, 0])), c.get('end_mode', 'avg'), bool(c.get('refl')),
+               c.get('weights', 'default:0'), c['S'] if 'weights' in c else 0)
         if key not in models:
             models[key] = build_reference(ref_modules, c['fusion'], c['aff'], c['sm'], seq_len=key[3], end_mode=key[4],
-                                          refl=key[5])
+                                          refl=key[5], weights=key[6], S=c['S'])
         model, sd = models[key]
         if 'counts' in c:
             dets, info, dsplit = make_multiframe(c['counts'], c['S'], c['pts'], c['seed'])

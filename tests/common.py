@@ -7,7 +7,7 @@ import torch
 
 from mmmot_amd import TrackingNet
 from mmmot_amd.synth import make_pair
-from mmmot_amd.weights import init_module
+from mmmot_amd.weights import init_module, state_dict_for_profile
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 TOL = 1e-3  # BASELINE.json north_star: outputs within 1e-3 (fp32) of the reference CPU path
@@ -56,7 +56,10 @@ def case_kwargs(c, base):
 
 def build_model(c, base, device='cpu', ops=None):
     m = TrackingNet(**case_kwargs(c, base))
-    init_module(m, 0)
+    if 'weights' in c:  # fixtures generated on other weight statistics than the seed-0 default (oracle/gen_golden.py)
+        m.load_state_dict(state_dict_for_profile(m.state_dict(), c['weights'], c['S']), strict=True)
+    else:
+        init_module(m, 0)
     m.eval()
     if device != 'cpu':
         m = m.to(device)

@@ -267,3 +267,54 @@ def test_conv1_weight_shift_keeps_weights_and_bias_inside_fp16():
         assert float(b.abs().max()) * 2.0 ** s <= 32768.0 < 65504.0
         if bscale == 0.0:
             assert s == hl16_weight_shift(w)
+
+
+def test_point_gather_staging_buffer_is_per_thread(monkeypatch):
+    """the pinned table-upload buffer of gather_points_batched is filled on the host and copied
+    asynchronously; only the calling thread's own stream synchronisation makes its reuse safe, so every thread must own
+    its buffer (pin_memory needs a device: replaced by a plain allocation here)."""
+    import threading
+    from mmmot_amd import points as P
+    monkeypatch.setattr(torch.Tensor, 'pin_memory', lambda self: self, raising=False)
+    got = {}
+
+    def grab(name):
+        a = P._staging(100)
+        got[name] = (a, P._staging(50), P._staging(10 * a.numel()))
+
+    ts = [threading.Thread(target=grab, args=(n,)) for n in ('t0', 't1')]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    grab('main')
+    bufs = [got[n][0].data_ptr() for n in ('t0', 't1', 'main')]
+    assert len(set(bufs)) == 3                      # one buffer per thread
+    for a, again, grown in got.values():
+        assert again.data_ptr() == a.data_ptr()     # reused while it is large enough
+        assert grown.numel() >= 10 * a.numel()      # grown (replaced) only for its own thread
+
+
+def test_launch_profiler_classifies_every_forward_launch():
+    """bench.py's extra.kernels: every operator call of a forward lands in a launch class with its algorithmic FLOPs and
+    bytes (cost models of mmmot_amd/profiler.py run over the torch emulation of the C-ABI; timing needs the device)"""
+    from mmmot_amd.profiler import COSTS, LaunchProfiler
+    c, base = get_case('s2_C_minus_abs_dual_add')
+    m = build_model(c, base, ops=TorchOps())
+    ops = m.engine().ops
+    before = dict(ops.__dict__)
+    with torch.no_grad(), LaunchProfiler(ops) as prof:
+        m(*case_inputs(c))
+    assert dict(ops.__dict__).keys() == before.keys()  # the wrappers are gone
+    s = prof.summary(steps=1)
+    labels = {r['class'] for r in s['classes']}
+    assert not labels & set(COSTS), labels  # a bare method name = a cost model that failed to parse its arguments
+    by = {r['class']: r for r in s['classes']}
+    L, S = 12, 64
+    conv2 = by['trunk conv 64->128 @32x32']
+    assert conv2['gflop_per_step'] == round(2.0 * L * 32 * 32 * 9 * 64 * 128 / 1e9, 1)
+    fused = [r for r in s['classes'] if r['class'].startswith('trunk conv1_1+conv1_2')][0]
+    assert fused['gflop_per_step'] == round(2.0 * L * S * S * 9 * (3 * 64 + 64 * 64) / 1e9, 1)
+    assert any(r['class'].startswith('A-resident GEMM 128->1024') for r in s['classes'])
+    assert any('pair prologue' in r['class'] for r in s['classes'])
+    assert sum(r['launches_per_step'] for r in s['classes']) == len(prof.records)

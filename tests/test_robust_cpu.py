@@ -116,7 +116,7 @@ def test_guard_checks_synchronously_on_the_first_forward_and_on_request():
     assert reads == [0, 0, 3, 3, 6, 6]
 
 
-def test_guard_detects_one_step_late_without_synchronising():
+def test_guard_detects_late_without_synchronising():
     """after the first forward the counters are read back asynchronously and inspected by the NEXT forward: a model that
     leaves the range later (here: the weights are swapped under a live engine) is lowered one step late, with an event
     that says the previous forward was affected; each engine counts in its own block"""
@@ -137,12 +137,51 @@ def test_guard_detects_one_step_late_without_synchronising():
         warnings.simplefilter('error')
         m(dets, info, ds)            # out of range, not yet noticed: no synchronous read on this forward
     assert not eng.range_events
-    with torch.no_grad(), pytest.warns(RuntimeWarning, match='PREVIOUS forward'):
+    with torch.no_grad(), pytest.warns(RuntimeWarning, match='forwards 2..2 of this engine ran out of range'):
         m(dets, info, ds)            # the read-back of the previous forward is inspected first
     ev = eng.range_events[0]
     assert ev['recomputed'] is False and ev['was'] == 'f16q8' and ev['e4m3_saturated'] > 0
+    assert ev['affected_forwards'] == (2, 2) and ev['affected_forward'] == 2 and ev['forward'] == 3
+    assert eng.last_out_of_range_forward == 2 and eng.out_of_range_window == (2, 2)
     assert eng.trunk in ('f16x3', 'f32')
     assert not other.engine().range_events and other.engine().trunk == 'f16q8'
+
+
+def test_late_read_back_reports_the_forwards_it_covers():
+    """a read-back recorded behind forward k is inspected only once its copy has completed - maybe several
+    forwards later, and no new one is queued meanwhile.  The event must name the forwards the counters cover (those since
+    the previous read-back up to k), not "the forward before the inspection"; the forwards that ran while the copy was
+    pending belong to the NEXT read-back."""
+    m, sd, (dets, info, ds) = build('calibrated', 0, 1.0)
+    eng = m.engine()
+
+    class Slow:  # stands for a torch.cuda.Event whose copy has not completed yet
+        done = False
+
+        def query(self):
+            return self.done
+
+    with torch.no_grad():
+        m(dets, info, ds)                      # forward 0: synchronous check
+        m(dets, info, ds)                      # forward 1: read-back queued (covers 1..1)
+        m(dets, info, ds)                      # forward 2: inspects it, queues its own (covers 2..2)
+        assert eng._range_pending[1:] == (2, 2)
+        slow = Slow()
+        eng._range_pending = (slow,) + eng._range_pending[1:]
+        cv = eng.P['vgg'][4]
+        good = cv['bias']
+        m(dets, info, ds)                      # forwards 3, 4: the copy is still in flight, nothing new is queued
+        cv['bias'] = good + 3000.0             # forward 4 leaves the range
+        m(dets, info, ds)
+        cv['bias'] = good
+        assert not eng.range_events and eng._range_pending[0] is slow
+        slow.done = True
+        m(dets, info, ds)                      # forward 5: 2..2 was fine; queues a read-back that covers 3..5
+        assert not eng.range_events and eng._range_pending[1:] == (3, 5)
+        with pytest.warns(RuntimeWarning, match='forwards 3..5'):
+            m(dets, info, ds)                  # forward 6 inspects it
+    ev = eng.range_events[0]
+    assert ev['affected_forwards'] == (3, 5) and ev['forward'] == 6 and eng.out_of_range_window == (3, 5)
 
 
 def test_per_channel_shifts_follow_the_folded_gains():

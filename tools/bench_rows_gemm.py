@@ -24,16 +24,34 @@ def main():
     ap.add_argument('--n', type=int, nargs='*', default=[128, 512])
     ap.add_argument('--ldx', type=int, default=0, help='row pitch of the input in floats (default K): the input is the last K columns of a wider buffer, like the conv1.0 half of the stacked layer')
     ap.add_argument('--sustain', type=int, default=200)
+    ap.add_argument('--pair', type=int, default=0, help='A_PAIR prologue instead of A_NORM_RELU: groups of M x M pair rows '
+                    '(M = this value, a multiple of 32) generated from feature rows F [G * 2M][K]; --rows is rounded to whole groups')
+    ap.add_argument('--ldf', type=int, default=0, help='row pitch of F in floats (default K)')
+    ap.add_argument('--wsm', action='store_true', help='also time variant 3: the wide kernel on the stage-major weight copy '
+                    '[K/32][N][32] (experiment: L2 channel spread of the weight stage); checked bitwise against variant 2')
     ap.add_argument('--variants', type=int, nargs='*', default=[1, 2])
     a = ap.parse_args()
     ops = HipOps()
     K, G = a.k, a.groups
     counts = [a.rows // G] * G
+    if a.pair:
+        G = max(a.rows // (a.pair * a.pair), 1)
+        counts = [a.pair * a.pair] * G
     tiles = RowTiles(counts, 'cuda')
     g = torch.Generator().manual_seed(0)
     ldx = max(a.ldx, K)
     X = torch.randn(sum(counts), ldx, generator=g).cuda()[:, ldx - K:]
     sc, sh = torch.ones(G, K).cuda(), torch.zeros(G, K).cuda()
+    kw = dict(X=X, sc=sc, sh=sh, amode=1)
+    if a.pair:
+        import numpy as np
+        m, ldf = a.pair, max(a.ldf, K)
+        F = torch.randn(G * 2 * m, ldf, generator=g).cuda()[:, :K]
+        put = lambda v: torch.from_numpy(np.asarray(v, np.int32)).cuda()
+        pair = dict(row0=tiles.g_row0, M=put([m] * G), aoff=put([2 * m * i for i in range(G)]),
+                    boff=put([2 * m * i + m for i in range(G)]), uniform32=(m % 32 == 0))
+        kw = dict(FA=F, FB=F, pair=pair, amode=2, pairop=0)
+        ldx = ldf
     for N in a.n:
         W = torch.randn(N, K, generator=g) * K ** -0.5
         shift = hl16_weight_shift(W)
@@ -41,14 +59,16 @@ def main():
         bias = torch.zeros(N).cuda()
         Y = torch.empty(sum(counts), N).cuda()
         part = torch.empty(tiles.T, 2, N).cuda()
-        for v in a.variants:
+        W16sm = W16.cpu().view(N, K // 32, 32).permute(1, 0, 2).contiguous().cuda()
+        ref = None
+        for v in list(a.variants) + ([3] if a.wsm else []):
             ops.lib.mmmot_set_gemm_rows_variant(v)
+            Wv = W16sm if v == 3 else W16
             ts = []
             for r in range(6):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                ops.gemm(W16, tiles, N, K, X=X, bias=bias, Y=Y, part=part, sc=sc, sh=sh, amode=1, w_hl16=True,
-                         oscale=2.0 ** -shift)
+                ops.gemm(Wv, tiles, N, K, bias=bias, Y=Y, part=part, w_hl16=True, oscale=2.0 ** -shift, **kw)
                 e1.record()
                 torch.cuda.synchronize()
                 if r:
@@ -58,13 +78,19 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for r in range(a.sustain):
-                ops.gemm(W16, tiles, N, K, X=X, bias=bias, Y=Y, part=part, sc=sc, sh=sh, amode=1, w_hl16=True,
-                         oscale=2.0 ** -shift)
+                ops.gemm(Wv, tiles, N, K, bias=bias, Y=Y, part=part, w_hl16=True, oscale=2.0 ** -shift, **kw)
             e1.record()
             torch.cuda.synchronize()
             sus = e0.elapsed_time(e1) / max(a.sustain, 1)
-            print('K=%d ldx=%d N=%4d rows=%d variant %d  %.3f ms  %.0f TFLOP/s-equivalent; %d calls back to back: %.3f ms each' % (
-                K, ldx, N, sum(counts), v, ms, 2.0 * sum(counts) * N * K / ms / 1e9, a.sustain, sus))
+            same = ''
+            if v in (2, 3):
+                if ref is None:
+                    ref = (Y.clone(), part.clone())
+                else:
+                    same = '; bitwise == variant 2: %s' % (torch.equal(ref[0], Y) and torch.equal(ref[1], part))
+            print('%s K=%d ld=%d N=%4d rows=%d variant %d  %.3f ms  %.0f TFLOP/s-equivalent; %d calls back to back: %.3f ms each%s' % (
+                'PAIR M=%d' % a.pair if a.pair else 'NORM', K, ldx, N, sum(counts), v, ms,
+                2.0 * sum(counts) * N * K / ms / 1e9, a.sustain, sus, same), flush=True)
         ops.lib.mmmot_set_gemm_rows_variant(0)
 
 
