@@ -74,6 +74,7 @@ EXTRA_WORKLOADS = [
     ('cfg5_image_only', 'cfg3', 8, (0,)),
     ('cfg5_lidar_only', 'cfg3', 8, (1,)),
 ]
+PROFILE_STEPS = 2  # untimed steps behind every leg's timed region that run under the launch profiler (extra.kernels)
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide: BF16/F16 MFMA dense peak (AMD's 5 PF figure is 2:1 sparse)
 HEADLINE_TRUNK = 'f16x3'       # fp32-class arithmetic: what `value` is measured in unless --trunk says otherwise
@@ -130,6 +131,15 @@ def parse_args(argv=None):
     ap.add_argument('--no-latency', action='store_true', help='skip the B=1 reference-call latency extra')
     ap.add_argument('--no-workloads', action='store_true',
                     help='skip extra.workloads (the other BASELINE.json configs: cfg2 B=32, cfg4 32 pairs/GPU, cfg5 rows)')
+    ap.add_argument('--input-sets', type=int, default=3,
+                    help='distinct synthetic input sets rotated over the steps (the last timed step runs set 0, the one the '
+                         'parity checks look at): 3 x (100 MB crops + 50 MB points) at the default batch exceeds the 256 MiB '
+                         'Infinity Cache, so no step finds its inputs cached by the step before')
+    ap.add_argument('--no-profile', action='store_true',
+                    help='skip extra.kernels (HIP events around every operator call of a few extra, untimed steps) and '
+                         'extra.prep (point-cloud gather / crop-resize throughput)')
+    ap.add_argument('--no-bind', action='store_true', help='leave the CPU affinity of the rank alone (default: the cores '
+                    'of the NUMA node its GPU hangs off)')
     ap.add_argument('--rows', default='0,1,2', help='modality rows of the headline workload (cfg5: 0 = image-only, 1 = LiDAR-only)')
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise torch.distributed (RCCL) and run the collective path of the N-GPU run even with one GPU')
@@ -154,6 +164,112 @@ def relaunch_under_torchrun(args):
     env.setdefault('OMP_NUM_THREADS', '8')
     sys.stdout.flush()
     os.execvpe(cmd[0], cmd, env)
+
+
+
+# ---- host placement and device telemetry of a rank ---------------------------------------
+def gpu_sysfs_dir(index):
+    """sysfs directory of cuda:<index> (/sys/bus/pci/devices/<domain:bus:dev.fn>), or None."""
+    try:
+        p = torch.cuda.get_device_properties(index)
+        bdf = '%04x:%02x:%02x.0' % (int(getattr(p, 'pci_domain_id', 0)), int(p.pci_bus_id), int(p.pci_device_id))
+        d = os.path.join('/sys/bus/pci/devices', bdf)
+        return d if os.path.isdir(d) else None
+    except Exception:
+        return None
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def _cpulist(text):
+    cpus = set()
+    for part in (text or '').split(','):
+        if '-' in part:
+            a, b = part.split('-')
+            cpus.update(range(int(a), int(b) + 1))
+        elif part.strip():
+            cpus.add(int(part))
+    return cpus
+
+
+def bind_to_gpu_numa_node(index, enable=True):
+    """Pin this rank (and every thread it starts later: the launch thread, torch's intra-op pool) to the cores of the
+    NUMA node its GPU is attached to, so that eight ranks on one node neither share cores nor launch across sockets.
+    Returns what was done: {'numa_node', 'cpus' (count), 'bound'}; a missing sysfs entry or node -1 leaves the
+    affinity alone."""
+    info = {'numa_node': None, 'cpus': len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else None,
+            'bound': False}
+    d = gpu_sysfs_dir(index) if index is not None else None
+    if d is None:
+        return info
+    node = _read(os.path.join(d, 'numa_node'))
+    cpus = _cpulist(_read(os.path.join(d, 'local_cpulist')))
+    info['numa_node'] = int(node) if node not in (None, '') else None
+    if enable and cpus and info['numa_node'] is not None and info['numa_node'] >= 0 and hasattr(os, 'sched_setaffinity'):
+        allowed = cpus & os.sched_getaffinity(0)
+        if allowed:
+            os.sched_setaffinity(0, allowed)
+            info.update(cpus=len(allowed), bound=True)
+    return info
+
+
+class Telemetry:
+    """Sustained shader clock and package power of one GPU while a leg's timed steps run: a host thread samples the
+    device's hwmon files (freq1_input = sclk in Hz, power1_average / power1_input in uW) every `period` seconds."""
+
+    def __init__(self, index, period=0.25):
+        import glob
+        self.period = period
+        d = gpu_sysfs_dir(index)
+        hw = sorted(glob.glob(os.path.join(d, 'hwmon', 'hwmon*'))) if d else []
+        self.f_clk = self.f_pow = None
+        for h in hw:
+            if self.f_clk is None and os.path.exists(os.path.join(h, 'freq1_input')):
+                self.f_clk = os.path.join(h, 'freq1_input')
+            for name in ('power1_average', 'power1_input'):
+                if self.f_pow is None and os.path.exists(os.path.join(h, name)):
+                    self.f_pow = os.path.join(h, name)
+        self.clk, self.pow = [], []
+        self._stop = None
+        self._thr = None
+
+    def _run(self):
+        while not self._stop.is_set():
+            c, w = _read(self.f_clk) if self.f_clk else None, _read(self.f_pow) if self.f_pow else None
+            try:
+                if c:
+                    self.clk.append(float(c) / 1e6)
+                if w:
+                    self.pow.append(float(w) / 1e6)
+            except ValueError:
+                pass
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        import threading
+        self.clk, self.pow = [], []
+        if self.f_clk or self.f_pow:
+            self._stop = threading.Event()
+            self._thr = threading.Thread(target=self._run, daemon=True)
+            self._thr.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._thr is not None:
+            self._stop.set()
+            self._thr.join()
+            self._thr = None
+        return False
+
+    def result(self):
+        mean = lambda v: round(sum(v) / len(v), 1) if v else None
+        return {'sclk_mhz': mean(self.clk), 'power_w': mean(self.pow), 'samples': max(len(self.clk), len(self.pow))}
 
 
 def stub_results(pairs, N, M, seed0):
@@ -410,6 +526,69 @@ def cpu_baseline(model, ins, res, fusion, aff, sm, N, M, n_timed):
     return base, linf
 
 
+
+def prep_leg(dev):
+    """Throughput of the two device steps in front of the forward, synthetic inputs resident:
+    the batched point-cloud gather (64 sweeps x 120 000 points x 4 floats, 16 boxes + the image-frustum-like filter
+    polygon per sweep -> det_info['points'] / points_split) and crop + resize + normalise (32 detections of a
+    1242 x 375 frame -> 224 x 224 crops, fp32 NCHW and the 8-bit form)."""
+    from mmmot_amd import crops as CR
+    from mmmot_amd import points as PT
+    out = {}
+    rng = np.random.default_rng(7)
+    NS, P, NB = 64, 120000, 16
+    eye = np.eye(4, dtype=np.float32)
+    pts, planes, counts = [], [], []
+    for _ in range(NS):
+        pts.append(np.stack([rng.uniform(0, 70, P), rng.uniform(-30, 30, P), rng.uniform(-2.5, 1.0, P),
+                             rng.uniform(0, 1, P)], 1).astype(np.float32))
+        b = np.concatenate([rng.uniform([5, -20, -1.9], [50, 20, -1.2], (NB, 3)),          # centre (bottom face)
+                            rng.uniform([3.2, 1.3, 1.4], [4.8, 1.8, 2.0], (NB, 3)),          # l, h, w
+                            rng.uniform(-3.1, 3.1, (NB, 1))], 1).astype(np.float32)
+        planes.append(PT.rbbox_planes(b, eye, eye))
+        counts.append(NB)
+    view = PT.rbbox_planes(np.array([[33.5, 0.0, -3.0, 56.0, 3.9, 63.0, 0.0]], dtype=np.float32), eye, eye)
+    allpts = torch.from_numpy(np.concatenate(pts)).to(dev)
+    rows_off = np.arange(NS + 1) * P
+    planes_all = np.concatenate(planes + [view] * NS)
+    filt = [NS * NB + i for i in range(NS)]
+
+    def gather():
+        return PT.gather_points_batched(allpts, rows_off, planes_all, counts, filters=filt, pad_empty=True,
+                                        drop_reflectivity=True)
+    rows, split = gather()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 10
+    for _ in range(n):
+        gather()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out['point_gather'] = {'value': round(n * NS / dt, 1), 'unit': 'sweeps/s', 'ms_per_batch': round(dt / n * 1e3, 3),
+                           'workload': '%d sweeps x %d points x 4 floats per batch, %d boxes + 1 filter polygon per sweep; '
+                                       '%d points kept' % (NS, P, NB, int(split[-1])),
+                           'hbm_tbs_algorithmic': round((2 * allpts.numel() * 4 + rows.numel() * 4) / (dt / n) / 1e12, 3),
+                           'includes': 'table upload, count pass, the one split read-back, scatter pass'}
+    H, W, ND, S = 375, 1242, 32, 224
+    frame = torch.from_numpy(rng.integers(0, 256, (H, W, 3), dtype=np.uint8)).to(dev)
+    x1, y1 = rng.uniform(0, W - 200, ND), rng.uniform(0, H - 150, ND)
+    bb = np.stack([x1, y1, x1 + rng.uniform(30, 190, ND), y1 + rng.uniform(30, 140, ND)], 1)
+    for key, fn in (('crop_resize_normalize_fp32', lambda: CR.crop_resize_normalize(frame, bb, S)),
+                    ('crop_resize_u8', lambda: CR.crop_resize_u8(frame, bb, S))):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 50
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[key] = {'value': round(n * ND / dt, 1), 'unit': 'detections/s', 'us_per_frame': round(dt / n * 1e6, 1),
+                    'workload': '%d detections of a %dx%d frame -> %dx%d crops per call (one frame per call, like the '
+                                'reference loop)' % (ND, W, H, S, S)}
+    return out
+
+
 def latency_b1(dev, trunk):
     """What eval_seq.py:143-153 actually calls: ONE frame pair per call through ``model(dets, det_info, dets_split)``
     at the shape of BASELINE.json configs[0] (Fusion A, N=10, M=12, 224x224 crops, ragged ~300 pts/det), inputs on the
@@ -497,17 +676,24 @@ def main():
             res = stub_results(hi - lo, N, M, 1000 + lo)
             return res if args.no_gather else gather_results(res, same_layout=True)
 
+        place = bind_to_gpu_numa_node(None, enable=not args.no_bind)  # no GPU in a dry run: reports the affinity it found
         for _ in range(args.warmup):
             step()
-        dt, res = time_steps(step, args.steps, barrier)
-        dt = max_over_ranks(dt, world, dev)
+        dt_own, res = time_steps(step, args.steps, barrier)
+        dt = max_over_ranks(dt_own, world, dev)
+        mine = dict(ms_per_step=round(dt_own / args.steps * 1e3, 3), sclk_mhz=None, power_w=None, **place)
+        allr = [mine]
+        if world > 1:
+            allr = [None] * world
+            dist.all_gather_object(allr, mine)
+        per_rank = {k: [x[k] for x in allr] for k in mine}
         ok = args.no_gather or (len(res) == world * B and all(
             torch.equal(res[i][1][0], stub_results(1, N, M, 1000 + i)[0][1][0]) for i in range(0, world * B, max(B // 2, 1))))
         if rank == 0:
             print(json.dumps({'metric': METRIC, 'value': None, 'unit': 'frame-pairs/s', 'n_gpus': world, 'steps': args.steps,
                               'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
                               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': None,
-                              'data': 'dry-run stub (no kernel executed)', 'gather_ok': bool(ok),
+                              'data': 'dry-run stub (no kernel executed)', 'gather_ok': bool(ok), 'per_rank': per_rank,
                               'config': {'workload': args.workload, 'pairs_per_step_per_gpu': B,
                                          'parallelism': 'sample-sharded x%d, flat all_gather of scores (gloo, CPU)' % world}}),
                   flush=True)
@@ -521,6 +707,8 @@ def main():
     from mmmot_amd.weights import init_module
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    place = bind_to_gpu_numa_node(local_rank, enable=not args.no_bind)
+    telemetry = Telemetry(local_rank)
     if args.latency_only:
         print(json.dumps(latency_b1(dev, args.trunk)), flush=True)
         return
@@ -544,22 +732,44 @@ def main():
         init_module(mdl, seed=0)
         mdl.eval().to(dev)
         seed0 = SEED0.get(name, 1000)
-        # synthetic batch: distinct seeds per global pair index; inputs resident in HBM before timing
-        ins_ = [make_pair(N_, M_, S_, pts_, seed=seed0 + i) for i in range(first, first + Bw)]
+        # synthetic batch: distinct seeds per global pair index; inputs resident in HBM before timing.  `--input-sets`
+        # batches of the same shape (one plan: the point counts are fixed) with disjoint seeds; set 0 is the batch the
+        # reference goldens / the CPU baseline look at
         need_img, need_pts = (0 in rows) or (2 in rows), (1 in rows) or (2 in rows)
+        sets, ins_ = [], None
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max(1, min(16, len(os.sched_getaffinity(0)))))  # one seeded generator per pair
+        for k in range(max(args.input_sets, 1)):
+            ik = list(pool.map(lambda i: make_pair(N_, M_, S_, pts_, seed=seed0 + 100003 * k + i), range(first, first + Bw)))
+            sets.append((torch.cat([x[0] for x in ik]).to(dev) if need_img else None,
+                         torch.cat([x[1]['points'].reshape(-1, 3) for x in ik]).to(dev) if need_pts else None))
+            if k == 0:
+                ins_ = ik
+            else:
+                assert all(torch.equal(a[1]['points_split'], b[1]['points_split']) for a, b in zip(ik, ins_))
+        pool.shutdown()
         samples = [([N_, M_], x[1]['points_split'].reshape(-1).long().numpy() if need_pts else None) for x in ins_]
         plan_ = mdl.make_plan(samples, S_, rows=rows)
-        crops_ = torch.cat([x[0] for x in ins_]).to(dev) if need_img else None
-        points_ = torch.cat([x[1]['points'].reshape(-1, 3) for x in ins_]).to(dev) if need_pts else None
         torch.cuda.synchronize()
-        return dict(name=name, model=mdl, plan=plan_, crops=crops_, points=points_, ins=ins_, rows=rows, B=Bw,
-                    gold=gold_, shape=(N_, M_, S_, pts_, fusion_))
+        set_bytes = sum(t.numel() * t.element_size() for t in sets[0] if t is not None)
+        return dict(name=name, model=mdl, plan=plan_, sets=sets, ins=ins_, rows=rows, B=Bw, gold=gold_,
+                    shape=(N_, M_, S_, pts_, fusion_), input_mb=round(len(sets) * set_bytes / 2 ** 20, 1))
 
-    def run_leg(wl, trunk, steps, warmup, graph=False):
+    def run_leg(wl, trunk, steps, warmup, graph=False, profile=False):
         """W warm-up steps, then exactly K timed steps between barrier + synchronize brackets, max over ranks."""
-        mdl, plan_, crops_, points_ = wl['model'], wl['plan'], wl['crops'], wl['points']
+        mdl, plan_, sets = wl['model'], wl['plan'], wl['sets']
         mdl.set_trunk(trunk)
         eng = mdl.engine()
+        # input rotation: call c of a phase of `n` calls runs set (n - 1 - c) % len(sets) - the LAST one runs set 0
+        rot = {'n': 0, 'c': 0}
+
+        def next_set():
+            k = (rot['n'] - 1 - rot['c']) % len(sets) if rot['n'] else 0
+            rot['c'] += 1
+            return sets[k]
+
+        def phase(n):
+            rot['n'], rot['c'] = n, 0
 
         gather_ev = []  # HIP events around the result gather of every timed step (N-rank runs: where the time goes)
 
@@ -576,20 +786,27 @@ def main():
             return res
 
         def step():
+            crops_, points_ = next_set()
             return gathered(mdl.forward_batch(plan_, crops_, points_))
 
+        phase(warmup)
         for _ in range(warmup):
             step()
         if graph:
             # the C-ABI entry points only launch (no allocation, no synchronisation): the whole step is capturable
-            graphed = mdl.capture(plan_, crops_, points_)
+            graphed = mdl.capture(plan_, sets[0][0], sets[0][1])
 
             def step():  # noqa: F811
-                return gathered(graphed(crops_, points_))
+                crops_, points_ = next_set()
+                return gathered(graphed(crops_, points_))  # copies the set into the captured input buffers
+            phase(1)
             step()
         eng.conv_events = []
         del gather_ev[:]
-        dt, res = time_steps(step, steps, barrier)
+        phase(steps)
+        with telemetry:
+            dt, res = time_steps(step, steps, barrier)
+        tele = telemetry.result()
         events, eng.conv_events = eng.conv_events, None
         dt_own = dt
         dt = max_over_ranks(dt, world, dev)
@@ -602,15 +819,26 @@ def main():
                'exec_tflops_equiv_per_gpu': round(fexec * value / 1e12 / world, 2)}
         if trunk == 'f16x3':
             leg['whole_step_frac_of_f16x3_peak'] = round(fexec * value / 1e12 / world / (PEAK_F16_MFMA_TFLOPS / 3.0), 4)
+        leg['inputs'] = '%d sets x %d pairs rotated over the steps, %.0f MiB resident' % (len(sets), wl['B'], wl['input_mb'])
+        leg['telemetry'] = tele  # this rank's sustained shader clock / package power over the timed steps (hwmon)
+        if profile and not graph and rank == 0:
+            # per-launch-class device time of PROFILE_STEPS extra (untimed) steps: HIP events around every operator call
+            from mmmot_amd.profiler import LaunchProfiler
+            phase(PROFILE_STEPS)
+            with LaunchProfiler(eng.ops, f32=(trunk == 'f32')) as prof:
+                for _ in range(PROFILE_STEPS):
+                    step()
+            leg['kernels'] = prof.summary(steps=PROFILE_STEPS, top=24)
         if dist_on:
             # every rank's own wall time per step and the device time of its result gather (pack + RCCL all_gather +
             # unpack, HIP events): `value` uses the MAX over ranks; this shows which rank and which part set it
             import torch.distributed as dist
             gus = (sum(e0.elapsed_time(e1) for e0, e1 in gather_ev) / max(len(gather_ev), 1)) * 1e3 if gather_ev else 0.0
-            mine = [round(dt_own / steps * 1e3, 3), round(gus, 1)]
+            mine = dict(ms_per_step=round(dt_own / steps * 1e3, 3), gather_us_per_step=round(gus, 1),
+                        sclk_mhz=tele['sclk_mhz'], power_w=tele['power_w'], **place)
             allr = [None] * world
             dist.all_gather_object(allr, mine)
-            leg['per_rank'] = {'ms_per_step': [x[0] for x in allr], 'gather_us_per_step': [x[1] for x in allr]}
+            leg['per_rank'] = {k: [x[k] for x in allr] for k in mine}
         if rank == 0 and wl['gold'] is not None:
             leg['linf_vs_reference_golden'] = golden_linf(res[0], wl['gold'], wl['rows'])
         return leg, res, layers
@@ -618,7 +846,11 @@ def main():
     rows = tuple(int(r) for r in args.rows.split(',') if r != '')
     head_wl = build_workload(args.workload, B, rows, lo)
     model, ins = head_wl['model'], head_wl['ins']
-    head, res, layers = run_leg(head_wl, args.trunk, args.steps, args.warmup, graph=args.graph)
+    do_prof = not args.no_profile
+    kernels = {}
+    head, res, layers = run_leg(head_wl, args.trunk, args.steps, args.warmup, graph=args.graph, profile=do_prof)
+    if 'kernels' in head:
+        kernels['headline_%s_%s' % (args.workload, args.trunk)] = head.pop('kernels')
     value = head['value']
     fref = reference_flops_per_pair(N, M, S, (N + M) * pts, fusion)
     out = {
@@ -639,6 +871,10 @@ def main():
                      'the 1088->512 broadcast eliminated, second PointNet_v1.conv1 pass and the Gram matrix added); '
                      'whole-step fraction = F_exec x pairs/s / GPU / (2500/3) - north_star target >= 0.50'},
         'parity': {'tolerance': 1e-3},
+        'inputs': head['inputs'],
+        'host': dict(place, telemetry=head['telemetry'],
+                     note='rank 0: NUMA node / cores the rank was bound to (sysfs numa_node / local_cpulist of its GPU), '
+                          'mean shader clock (MHz) and package power (W) over the timed steps (hwmon, 4 samples/s)'),
     }
     if 'per_rank' in head:
         out['per_rank'] = head['per_rank']
@@ -682,7 +918,9 @@ def main():
         wls = {}
         for key, name, Bw, wrows in EXTRA_WORKLOADS:
             wl = build_workload(name, Bw, wrows, rank * Bw)
-            leg, _, _ = run_leg(wl, args.trunk, args.steps, args.warmup)
+            leg, _, _ = run_leg(wl, args.trunk, args.steps, args.warmup, profile=do_prof)
+            if 'kernels' in leg:
+                kernels[key] = leg.pop('kernels')
             N_, M_, S_, pts_, fusion_ = wl['shape']
             leg['config'] = '%s: Fusion %s, N=M=%d, %dx%d crops, %d pts/det, %d pairs/step/GPU, modality rows %s' % (
                 name, fusion_, N_, S_, S_, pts_, Bw, wrows)
@@ -698,6 +936,17 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_latency:
         out['extra']['latency'] = latency_b1(dev, args.trunk)
+
+    if rank == 0 and kernels:
+        out['extra']['kernels'] = dict(
+            kernels, how='HIP events (torch.cuda.Event on the launch stream) around every operator call of %d untimed steps '
+            'behind each leg\'s timed region (mmmot_amd/profiler.py); per launch class: ms per step, the bound - mfma: '
+            'algorithmic FLOPs against %.0f TFLOP/s-equivalent (f16 MFMA dense peak / 3), hbm: algorithmic bytes against '
+            '%.0f TB/s, latency: under 5 us of roofline time per launch - achieved rate and fraction of that peak; '
+            'device_ms_per_step = their sum (compare ms_per_step of the leg)' % (PROFILE_STEPS, PEAK_F16_MFMA_TFLOPS / 3.0,
+                                                                             8.0))
+    if rank == 0 and world == 1 and do_prof and not args.no_workloads:
+        out['extra']['prep'] = prep_leg(dev)
 
     if rank == 0:
         print(json.dumps(out), flush=True)

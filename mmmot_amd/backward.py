@@ -14,6 +14,8 @@ Everything numeric happens in libmmmot_hip.so (csrc/backward.hip + the forward k
 views, transposes of weights (data movement) and the autograd bookkeeping.  Not built yet (next slices): the
 backward of w_det, fusion, PointNet and the VGG trunk (training-mode BatchNorm), the losses of cost.py:134-185.
 """
+import collections
+
 import numpy as np
 import torch
 
@@ -90,12 +92,18 @@ def dgrad_gemm(eng, W, tiles, X, Y):
     fresh tensors every step) would hand its address - at version 0 - to the next step's fold, which would then hit the
     previous step's transpose (tests/test_train_cpu.py runs three steps against the oracle)."""
     Nf, Kf = int(W.shape[0]), int(W.shape[1])
-    cache = eng.__dict__.setdefault('_wt_cache', {})
+    cache = eng.__dict__.get('_wt_cache')
+    if cache is None:
+        cache = eng.__dict__['_wt_cache'] = collections.OrderedDict()
     key = (W.data_ptr(), W._version, Nf, Kf)
     ent = cache.get(key)
-    if ent is None:
-        while len(cache) >= 32:  # oldest first (per-step weights pass through, persistent ones are re-inserted on use)
-            cache.pop(next(iter(cache)))
+    if ent is not None:
+        cache.move_to_end(key)  # least-recently-USED eviction: a persistent weight that is hit every step stays
+    else:
+        # ~30 weights pass through per step (the folded PointNet weights are fresh tensors every step, the head weights
+        # change version with every optimizer step): room for two steps, evict the entry unused for longest
+        while len(cache) >= 64:
+            cache.popitem(last=False)
         ent = cache[key] = (W, W.detach().t().contiguous())  # data movement; W pinned while the entry lives
     wt = ent[1]
     eng.ops.gemm(wt, tiles, Kf, Nf, X=X, Y=Y)

@@ -130,6 +130,19 @@ __device__ __forceinline__ float mm_act(float v, int act) {
 
 __device__ __forceinline__ float mm_sigmoid(float v) { return 1.f / (1.f + expf(-v)); }
 
+// Power-of-two scale exponent that puts amax = f * 2^ex (f in [0.5, 1)) at 2^target: target - ex, for the fp16-split
+// operands of the training step (device-side scales: gradients of 1e-4 .. 1e-7, freshly updated weights).  Guarded
+// (ADVICE r4): a zero, denormal-tiny, infinite or NaN amax must not turn into 2^(+-huge) = inf and 0 * inf = NaN in the
+// products - a non-finite or non-positive amax means "unscaled", and the exponent is clamped to [-100, 100] (2^100 times
+// a denormal is still finite; the inverse scale 2^-shift stays a normal float).
+__device__ __forceinline__ int mm_pow2_shift(float amax, int target) {
+  if (!(amax > 0.f) || !(amax <= 3.4028234e38f)) return 0;
+  int ex = 0;
+  (void)frexpf(amax, &ex);
+  const int s = target - ex;
+  return s < -100 ? -100 : (s > 100 ? 100 : s);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -57,11 +57,7 @@ __global__ __launch_bounds__(256) void gemm_tn_f16_kernel(mmmot_gemm_tn_args a, 
   const int n0 = blockIdx.x * TN, k0 = blockIdx.y * TK;
   // power-of-two scale of dY: max |dY| -> [2^10, 2^11)
   const float amax = dyamax ? *dyamax : 0.f;
-  int ex = 0;
-  if (amax > 0.f) {
-    (void)frexpf(amax, &ex);  // amax = f * 2^ex, f in [0.5, 1)
-  }
-  const int shift = amax > 0.f ? 11 - ex : 0;
+  const int shift = mm_pow2_shift(amax, 11);  // amax = f * 2^ex, f in [0.5, 1): 11 - ex (guarded, common.h)
   const float sd = ldexpf(1.f, shift), inv_sd = ldexpf(1.f, -shift);
 
   const int t_lo = (int)((long)a.T * blockIdx.z / gridDim.z), t_hi = (int)((long)a.T * (blockIdx.z + 1) / gridDim.z);

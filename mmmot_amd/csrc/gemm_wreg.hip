@@ -92,19 +92,30 @@ __global__ __launch_bounds__(512, 1) void gemm_wreg128_kernel(mmmot_gemm_ares_ar
   // (scalar loads written out: the compiler turns these table reads into VECTOR loads - the kernel stores to global
   // memory, so it will not treat them as constant - and then waits vmcnt(0) for them, i.e. for every LDS-DMA request
   // in flight, right after the requests were issued)
-  auto sload = [&](const int* ptr) {
-    int v;
-    asm volatile("s_load_dword %0, %1, 0x0" : "=s"(v) : "s"(ptr));
-    return v;
-  };
+  // The four loads and their wait are ONE asm block with early-clobber outputs: with the wait in a separate statement
+  // the compiler does not know the destination registers are pending and may schedule a scalar move / select on them in
+  // between.  Optional tables read a valid word (the tile's row0) and are replaced by 0 afterwards.
   auto tile_info = [&](int t) {
     Tile w;
     w.t = t;
-    w.row0 = sload(a.tile_row0 + t);
-    w.nrows = sload(a.tile_nrows + t);
-    w.grp = a.tile_group ? sload(a.tile_group + t) : 0;
-    w.dbrow = a.dbias ? sload(a.tile_dbrow + t) : 0;
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w.row0), "+s"(w.nrows), "+s"(w.grp), "+s"(w.dbrow));
+    const int* p0 = a.tile_row0 + t;
+    const int* p1 = a.tile_nrows + t;
+    const int* p2 = a.tile_group ? a.tile_group + t : p0;
+    const int* p3 = a.dbias ? a.tile_dbrow + t : p0;
+    int v0, v1, v2, v3;
+    asm volatile(
+        "s_load_dword %0, %4, 0x0\n\t"
+        "s_load_dword %1, %5, 0x0\n\t"
+        "s_load_dword %2, %6, 0x0\n\t"
+        "s_load_dword %3, %7, 0x0\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(v0), "=&s"(v1), "=&s"(v2), "=&s"(v3)
+        : "s"(p0), "s"(p1), "s"(p2), "s"(p3)
+        : "memory");
+    w.row0 = v0;
+    w.nrows = v1;
+    w.grp = a.tile_group ? v2 : 0;
+    w.dbrow = a.dbias ? v3 : 0;
     return w;
   };
   // raw rows of half h of a tile -> Raw[h]: 4 instructions of 1 KB (2 rows) per wave; rows past the tile read its first row

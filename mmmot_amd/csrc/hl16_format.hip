@@ -74,10 +74,7 @@ extern "C" int mmmot_hl16_unpack(const void* x, float* y, long n, void* stream) 
 // with f in [0.5, 1), before the split, so that its lo halves stay normal fp16 numbers; mmmot_pow2_oscale builds the
 // per-output-channel vector the consuming kernel multiplies its accumulators with to undo the scale(s) exactly.
 __device__ __forceinline__ int hl_pow2_shift(const float* amax, int target) {
-  const float a = amax ? *amax : 0.f;
-  int ex = 0;
-  if (a > 0.f) (void)frexpf(a, &ex);
-  return a > 0.f ? target - ex : 0;
+  return mm_pow2_shift(amax ? *amax : 0.f, target);
 }
 
 __global__ void hl16_pack_pow2_kernel(const float* __restrict__ x, u32x4* __restrict__ y, long nunits,

@@ -20,12 +20,32 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(
   // part[t][0][c] = tile sum S, part[t][1][c] = tile-centred M2 (see gemm_rows.hip epilogue).
   // Tiles of a group are consecutive MM_BM-row chunks, the last one partial - unless tile_nrows says otherwise.
   const int rows = grp_count[g];
-  const long total = (long)CG * nt;
+  // element idx = tid + 256 k of the group's [nt][CG] statistics: tile idx / CG, channel idx % CG, walked incrementally
+  // (a 64-bit division per element made this kernel 0.3 ms on the 128 tiles x 512 channels of a 128 x 128 pair block);
+  // every thread adds its elements in the order of the division form: same sums, bit for bit
+  const int dq = 256 / CG, dr = 256 % CG;
+  const int ti0 = tid / CG, cc0 = tid % CG;
   double s1 = 0.0;
-  for (long idx = tid; idx < total; idx += 256) {
-    const int t = tile0 + (int)(idx / CG);
-    const int c = c0 + (int)(idx % CG);
-    s1 += (double)part[((long)t * 2 + 0) * ldp + c];
+  {
+    int ti = ti0, cc = cc0;
+    while (ti < nt) {
+      float v[4];
+      int n = 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v[u] = 0.f;
+        if (ti < nt) {
+          v[u] = part[((long)(tile0 + ti) * 2 + 0) * ldp + c0 + cc];
+          n = u + 1;
+          ti += dq;
+          cc += dr;
+          if (cc >= CG) { cc -= CG; ++ti; }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (u < n) s1 += (double)v[u];
+    }
   }
   s1 = wave_sum_d(s1);
   if (lane == 0) red[0][wave] = s1;
@@ -34,15 +54,34 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(
   const double mean = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / cnt;
   // Chan et al.: M2 = sum_chunks [ M2_chunk + n_chunk (mean_chunk - mean)^2 ], chunk = (tile, channel)
   double s2 = 0.0;
-  for (long idx = tid; idx < total; idx += 256) {
-    const int ti = (int)(idx / CG);
-    const int t = tile0 + ti;
-    const int c = c0 + (int)(idx % CG);
-    const int left = rows - ti * MM_BM;
-    const double n_t = tile_nrows ? (double)tile_nrows[t] : (double)(left < MM_BM ? left : MM_BM);
-    if (n_t > 0.0) {  // half tiles of the A-resident GEMM may be empty
-      const double d = (double)part[((long)t * 2 + 0) * ldp + c] / n_t - mean;
-      s2 += (double)part[((long)t * 2 + 1) * ldp + c] + n_t * d * d;
+  {
+    int ti = ti0, cc = cc0;
+    while (ti < nt) {
+      float vs[4], vm[4];
+      double nn[4];
+      int n = 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        vs[u] = vm[u] = 0.f;
+        nn[u] = 0.0;
+        if (ti < nt) {
+          const int t = tile0 + ti;
+          const int left = rows - ti * MM_BM;
+          nn[u] = tile_nrows ? (double)tile_nrows[t] : (double)(left < MM_BM ? left : MM_BM);
+          vs[u] = part[((long)t * 2 + 0) * ldp + c0 + cc];
+          vm[u] = part[((long)t * 2 + 1) * ldp + c0 + cc];
+          n = u + 1;
+          ti += dq;
+          cc += dr;
+          if (cc >= CG) { cc -= CG; ++ti; }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (u < n && nn[u] > 0.0) {  // half tiles of the A-resident GEMM may be empty
+          const double d = (double)vs[u] / nn[u] - mean;
+          s2 += (double)vm[u] + nn[u] * d * d;
+        }
     }
   }
   s2 = wave_sum_d(s2);
@@ -413,6 +452,7 @@ extern "C" int mmmot_row_layernorm(const float* X, int ldx, int C, const float* 
 // (~22 detections) still spreads over a dozen CUs, a 2048-detection batch reads the 0.8 MB of head weights 1024 times
 // from L2 (0.8 GB: tens of microseconds).
 #define SP_ROWS 2
+#define SP_JB 4
 __device__ __forceinline__ void sp_layernorm_row(const float* __restrict__ x, int C, const float* __restrict__ gamma,
                                                  const float* __restrict__ beta, float eps, bool relu, float* y, int lane) {
   float v[8];
@@ -438,64 +478,101 @@ __device__ __forceinline__ void sp_layernorm_row(const float* __restrict__ x, in
     }
 }
 
-// out[rr][j] = bias[j] + sum_k W[j][k] * x[rr][k] for the workgroup's SP_ROWS rows (x, out in LDS).  Lane l owns
-// k = l, l + 64, ... (coalesced 256-byte weight loads); a wave takes SP_JB output channels at a time so that all
-// their weight loads are in flight together (with few detections the kernel is a chain of L2 round trips, not work)
-#define SP_JB 4
+// out[rr][j] = bias[j] + sum_k W[j][k] * x[rr][k] for the workgroup's ROWS rows (x, out in LDS).  Lane l owns
+// k = l, l + 64, ... (coalesced 256-byte weight loads); a wave takes JB output channels at a time so that all
+// their weight loads are in flight together (with few detections the kernel is a chain of L2 round trips, not work).
+// ROWS x JB = 64 (the batch variant, 8 x 8): the 64 lane-partial sums of a step are reduced TOGETHER by a transposing
+// butterfly - at offset o a lane keeps the half of its partials whose index bit matches its own lane bit and adds the
+// partner's copy of them - 63 exchanges for 64 sums instead of 6 per sum.  Per (row, channel) the additions are those
+// of wave_sum (same pairs, same order: the two partners of an exchange add the same two numbers), so the result is
+// bit for bit the one of the per-sum butterfly, whatever ROWS is: a detection scores the same alone and in a batch.
+template <int ROWS, int JB>
 __device__ __forceinline__ void sp_matvec(const float* __restrict__ W, const float* __restrict__ bias, int N, int K,
                                           const float (*x)[512], float (*out)[128], int lane, int wave) {
   const int per = K >> 6;  // <= 8
-  for (int j0 = wave * SP_JB; j0 < N; j0 += 4 * SP_JB) {
-    float w[SP_JB][8];
+  for (int j0 = wave * JB; j0 < N; j0 += 4 * JB) {
+    float w[JB][8];
 #pragma unroll
-    for (int jb = 0; jb < SP_JB; ++jb)
+    for (int jb = 0; jb < JB; ++jb)
 #pragma unroll
       for (int i = 0; i < 8; ++i) w[jb][i] = (i < per && j0 + jb < N) ? W[(long)(j0 + jb) * K + lane + 64 * i] : 0.f;
-    float acc[SP_JB][SP_ROWS];
+    float acc[JB * ROWS];  // index jb * ROWS + rr
 #pragma unroll
-    for (int jb = 0; jb < SP_JB; ++jb)
-#pragma unroll
-      for (int rr = 0; rr < SP_ROWS; ++rr) acc[jb][rr] = 0.f;
+    for (int a = 0; a < JB * ROWS; ++a) acc[a] = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
       if (i < per) {
 #pragma unroll
-        for (int rr = 0; rr < SP_ROWS; ++rr) {
+        for (int rr = 0; rr < ROWS; ++rr) {
           const float xv = x[rr][lane + 64 * i];
 #pragma unroll
-          for (int jb = 0; jb < SP_JB; ++jb) acc[jb][rr] = fmaf(w[jb][i], xv, acc[jb][rr]);
+          for (int jb = 0; jb < JB; ++jb) acc[jb * ROWS + rr] = fmaf(w[jb][i], xv, acc[jb * ROWS + rr]);
         }
       }
+    if constexpr (JB * ROWS == 64) {
+      // transposing butterfly: after the step at offset o, slot i of a lane holds partial index i + (lane & o ? o : 0) + ...
+      // and finally slot 0 of lane l holds the complete sum of partial index l
 #pragma unroll
-    for (int jb = 0; jb < SP_JB; ++jb)
+      for (int o = 32; o > 0; o >>= 1) {
+        const bool up = (lane & o) != 0;
 #pragma unroll
-      for (int rr = 0; rr < SP_ROWS; ++rr) {
-        const float t = wave_sum(acc[jb][rr]);
-        if (lane == 0 && j0 + jb < N) out[rr][j0 + jb] = t + bias[j0 + jb];
+        for (int i = 0; i < o; ++i) {
+          const float keep = up ? acc[i + o] : acc[i];
+          const float send = up ? acc[i] : acc[i + o];
+          acc[i] = keep + __shfl_xor(send, o);
+        }
       }
+      const int jb = lane / ROWS, rr = lane % ROWS;
+      if (j0 + jb < N) out[rr][j0 + jb] = acc[0] + bias[j0 + jb];
+    } else {
+#pragma unroll
+      for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) {
+          const float t = wave_sum(acc[jb * ROWS + rr]);
+          if (lane == 0 && j0 + jb < N) out[rr][j0 + jb] = t + bias[j0 + jb];
+        }
+    }
   }
 }
 
+// ROWS = 2 (SP_ROWS): the latency form - a one-pair forward (~22 detections) still spreads over a dozen CUs.  ROWS = 8:
+// the batch form (R >= 256 rows): the 0.3 MB of head weights are read once per 8 rows instead of once per 2 and the
+// reductions are shared (sp_matvec); every wave normalises ROWS / 4 rows.
+template <int ROWS>
 __global__ __launch_bounds__(256) void skippool_head_kernel(
     const float* __restrict__ P, int ldp, int C, int C4, const float* __restrict__ g0, const float* __restrict__ b0,
     const float* __restrict__ w1, const float* __restrict__ c1, const float* __restrict__ g2,
     const float* __restrict__ b2, const float* __restrict__ w4, const float* __restrict__ c4,
     const float* __restrict__ g5, const float* __restrict__ b5, float eps, float* __restrict__ out, int ldo, int R) {
-  __shared__ __attribute__((aligned(16))) float xs[SP_ROWS][512];
-  __shared__ __attribute__((aligned(16))) float hs[SP_ROWS][512];  // normalised hidden rows (C4 <= 128 used)
-  __shared__ float h1[SP_ROWS][128];
+  constexpr int JB = ROWS == 8 ? 8 : SP_JB;
+  constexpr int RW = ROWS < 4 ? 1 : ROWS / 4;  // rows a wave normalises
+  __shared__ __attribute__((aligned(16))) float xs[ROWS][512];
+  __shared__ __attribute__((aligned(16))) float hs[ROWS][512];  // normalised hidden rows (C4 <= 128 used)
+  __shared__ float h1[ROWS][128];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row = blockIdx.x * SP_ROWS + wave;  // waves 0 .. SP_ROWS-1 normalise a row each; all four do the products
-  const bool mine = wave < SP_ROWS, live = mine && row < R;
-  if (mine) sp_layernorm_row(P + (long)(live ? row : 0) * ldp, C, g0, b0, eps, false, xs[wave], lane);
+  const int row0 = blockIdx.x * ROWS;
+#pragma unroll
+  for (int q = 0; q < RW; ++q) {
+    const int lr = wave * RW + q;  // ROWS = 2: waves 0, 1 normalise a row each; all four waves do the products
+    if (lr < ROWS) sp_layernorm_row(P + (long)(row0 + lr < R ? row0 + lr : 0) * ldp, C, g0, b0, eps, false, xs[lr], lane);
+  }
   __syncthreads();
-  sp_matvec(w1, c1, C4, C, xs, h1, lane, wave);
+  sp_matvec<ROWS, JB>(w1, c1, C4, C, xs, h1, lane, wave);
   __syncthreads();
-  if (mine) sp_layernorm_row(h1[wave], C4, g2, b2, eps, true, hs[wave], lane);
+#pragma unroll
+  for (int q = 0; q < RW; ++q) {
+    const int lr = wave * RW + q;
+    if (lr < ROWS) sp_layernorm_row(h1[lr], C4, g2, b2, eps, true, hs[lr], lane);
+  }
   __syncthreads();
-  sp_matvec(w4, c4, 128, C4, hs, h1, lane, wave);
+  sp_matvec<ROWS, JB>(w4, c4, 128, C4, hs, h1, lane, wave);
   __syncthreads();
-  if (live) sp_layernorm_row(h1[wave], 128, g5, b5, eps, true, out + (long)row * ldo, lane);
+#pragma unroll
+  for (int q = 0; q < RW; ++q) {
+    const int lr = wave * RW + q;
+    if (lr < ROWS && row0 + lr < R) sp_layernorm_row(h1[lr], 128, g5, b5, eps, true, out + (long)(row0 + lr) * ldo, lane);
+  }
 }
 
 extern "C" int mmmot_skippool_head(const float* P, int ldp, int C, int C4, const float* g0, const float* b0,
@@ -505,8 +582,12 @@ extern "C" int mmmot_skippool_head(const float* P, int ldp, int C, int C4, const
   if (!P || !g0 || !b0 || !w1 || !c1 || !g2 || !b2 || !w4 || !c4 || !g5 || !b5 || !out || R <= 0) return MMMOT_EINVAL;
   if (C <= 0 || C % 64 != 0 || C > 512 || C4 <= 0 || C4 % 64 != 0 || C4 > 128) return MMMOT_EINVAL;
   if (!mm_al16(w1) || !mm_al16(w4)) return MMMOT_EINVAL;
-  hipLaunchKernelGGL(skippool_head_kernel, dim3((R + SP_ROWS - 1) / SP_ROWS), dim3(256), 0, (hipStream_t)stream, P, ldp,
-                     C, C4, g0, b0, w1, c1, g2, b2, w4, c4, g5, b5, eps, out, ldo, R);
+  if (R >= 256)
+    hipLaunchKernelGGL(skippool_head_kernel<8>, dim3((R + 7) / 8), dim3(256), 0, (hipStream_t)stream, P, ldp,
+                       C, C4, g0, b0, w1, c1, g2, b2, w4, c4, g5, b5, eps, out, ldo, R);
+  else
+    hipLaunchKernelGGL(skippool_head_kernel<SP_ROWS>, dim3((R + SP_ROWS - 1) / SP_ROWS), dim3(256), 0, (hipStream_t)stream,
+                       P, ldp, C, C4, g0, b0, w1, c1, g2, b2, w4, c4, g5, b5, eps, out, ldo, R);
   return mm_check(hipGetLastError());
 }
 

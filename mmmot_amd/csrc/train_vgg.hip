@@ -229,9 +229,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16_kernel(const float* __r
   const int tap = blockIdx.z / nsplit, share = blockIdx.z - tap * nsplit;
   const int dy = tap / 3 - 1, dx = tap % 3 - 1;
   const float amax = dzamax ? *dzamax : 0.f;
-  int ex = 0;
-  if (amax > 0.f) (void)frexpf(amax, &ex);
-  const int shift = amax > 0.f ? 11 - ex : 0;
+  const int shift = mm_pow2_shift(amax, 11);
   const float sd = ldexpf(1.f, shift), inv_sd = ldexpf(1.f, -shift);
   const long P = (long)L * H * W;
   const long nchunk = (P + WG_ROWS - 1) / WG_ROWS;

@@ -23,6 +23,9 @@ The reference's training step is ``tracking_model.py:50-66``: training-mode ``Tr
   (mmmot_amd/train_vgg.py: batch-statistics BatchNorm2d, differentiable) unless ``model.freeze_appearance`` is set, in
   which case the image branch runs frozen on the eval-mode inference trunk (folded running statistics, no gradient).
 """
+import collections
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -309,14 +312,23 @@ def forward_train(model, dets, det_info, dets_split):
     points = points.reshape(-1, points.shape[-1]).contiguous()
     S = int(dets.shape[-1])
     # the plan (integer tile tables, uploaded once) and everything the backward caches on it (row tilings of the trunk's
-    # layers, segment tables) are kept per sample layout: a training loop revisits the same layouts epoch after epoch,
-    # and rebuilding them cost ~250 small host-to-device copies per step (rocprof, round 4)
-    cache = model.__dict__.setdefault('_train_plans', {})
+    # layers, segment tables) are kept per sample layout - the key holds the whole points_split, because the tables depend
+    # on it.  What this buys: loops that revisit a handful of samples (the overfit check, tools/bench_train.py, gradient
+    # accumulation over a fixed mini-set) skip ~250 small host-to-device copies per step (rocprof, round 4).  What it
+    # does not: a pass over a real dataset sees every layout once per epoch, so it never hits - hence a SMALL
+    # least-recently-used cache (MMMOT_TRAIN_PLAN_CACHE, default 8 plans of < 2 MB of device tables each) instead of one
+    # that pins 32 dead plans
+    cache = model.__dict__.get('_train_plans')
+    if cache is None:
+        cache = model.__dict__['_train_plans'] = collections.OrderedDict()
+    cap = max(int(os.environ.get('MMMOT_TRAIN_PLAN_CACHE', '8')), 1)
     key = (tuple(fc), ps.tobytes(), S, str(points.device))
     plan = cache.get(key)
-    if plan is None:
-        if len(cache) >= 32:
-            cache.pop(next(iter(cache)))
+    if plan is not None:
+        cache.move_to_end(key)
+    else:
+        while len(cache) >= cap:
+            cache.popitem(last=False)
         plan = cache[key] = BatchPlan([(fc, ps)], S, points.device, rows=(0, 1, 2), use_points=True)
     eng = _current_engine(model)
     if not getattr(model, 'freeze_appearance', False):

@@ -91,6 +91,38 @@ def test_bench_single_command_launcher_dry_run():
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['steps'] == 3 and out['warmup'] == 1 and out['gather_ok'] is True
     assert out['scaling'] == 'weak' and out['config']['pairs_per_step_per_gpu'] == 3
+    # host placement / telemetry of every rank: one entry per rank; no GPU here, so no NUMA node is
+    # found, nothing is bound and the clock / power samples are empty - the fields and the rank gather are what is checked
+    pr = out['per_rank']
+    assert set(pr) >= {'ms_per_step', 'sclk_mhz', 'power_w', 'numa_node', 'cpus', 'bound'}
+    assert all(len(v) == 2 for v in pr.values()) and pr['bound'] == [False, False] and all(c >= 1 for c in pr['cpus'])
+
+
+def test_numa_binding_follows_the_gpu_sysfs_entries(tmp_path, monkeypatch):
+    """bench.py binds a rank to the cores sysfs lists as local to its GPU (numa_node / local_cpulist of the PCI
+    device); node -1 or a missing entry leaves the affinity alone"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench._cpulist('0-3,8,10-11') == {0, 1, 2, 3, 8, 10, 11} and bench._cpulist('') == set()
+    have = sorted(os.sched_getaffinity(0))
+    d = tmp_path / 'dev'
+    d.mkdir()
+    (d / 'numa_node').write_text('1\n')
+    (d / 'local_cpulist').write_text('%d\n' % have[-1])
+    monkeypatch.setattr(bench, 'gpu_sysfs_dir', lambda i: str(d))
+    try:
+        info = bench.bind_to_gpu_numa_node(0, enable=False)
+        assert info == {'numa_node': 1, 'cpus': len(have), 'bound': False}
+        info = bench.bind_to_gpu_numa_node(0)
+        assert info == {'numa_node': 1, 'cpus': 1, 'bound': True} and os.sched_getaffinity(0) == {have[-1]}
+        os.sched_setaffinity(0, have)
+        (d / 'numa_node').write_text('-1\n')
+        assert bench.bind_to_gpu_numa_node(0)['bound'] is False and os.sched_getaffinity(0) == set(have)
+    finally:
+        os.sched_setaffinity(0, have)
 
 
 def test_forced_one_rank_gather_runs_the_collectives():

@@ -706,7 +706,8 @@ def test_pn_mlp64_matches_row_gemm_contract(hip, N, counts):
     close(pg[:, 0], p2[:, 0], 1e-5, 'pn_mlp64 vs gemm_rows sums')
 
 
-@pytest.mark.parametrize('C,C4,R', [(128, 64, 22), (256, 64, 5), (512, 128, 131), (512, 128, 1)])
+@pytest.mark.parametrize('C,C4,R', [(128, 64, 22), (256, 64, 5), (512, 128, 131), (512, 128, 1), (512, 128, 259),
+                                    (128, 64, 2048), (256, 64, 301)])
 def test_skippool_head_one_launch(hip, C, C4, R):
     """the fused SkipPool head (LayerNorm -> 1x1 -> LayerNorm + ReLU -> 1x1 -> LayerNorm + ReLU) vs its float64
     specification; partial last workgroup, strided output slice"""
@@ -721,3 +722,10 @@ def test_skippool_head_one_launch(hip, C, C4, R):
     hip.skippool_head(P.cuda(), C, {k: v.cuda() for k, v in hd.items()}, 1e-5, cat[:, 256:384], R)
     close(cat[:, 256:384], ref.float(), 2e-5, 'skippool head')
     assert (cat[:, :256] == 9.0).all() and (cat[:, 384:] == 9.0).all()
+    if R >= 256:
+        # the batch form (8 rows per workgroup, the 64 partial sums of a step reduced by one transposing butterfly) against
+        # the latency form (2 rows per workgroup, one butterfly per sum) on a slice of the same rows: bit for bit - a
+        # detection's appearance feature does not depend on the batch it is evaluated in
+        few = torch.zeros(37, 128).cuda()
+        hip.skippool_head(P[100:137].cuda(), C, {k: v.cuda() for k, v in hd.items()}, 1e-5, few, 37)
+        assert torch.equal(few, cat[100:137, 256:384])

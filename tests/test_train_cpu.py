@@ -259,4 +259,13 @@ def test_transposed_weight_cache_survives_address_reuse():
         dgrad_gemm(eng, W2, tiles, X, Y2)
         assert torch.allclose(Y2, X @ W2, atol=1e-5), 'stale transposed weight served for a new tensor at a reused address'
         assert W2.data_ptr() != ptr
-    assert len(eng._wt_cache) <= 32
+    assert len(eng._wt_cache) <= 64
+    # least-recently-USED eviction: a weight that is hit on every step survives any number of one-shot
+    # weights passing through; the round-4 first-in-first-out cache dropped it after 32 insertions
+    keep = torch.randn(16, 24, generator=g)
+    dgrad_gemm(eng, keep, tiles, X, torch.empty(8, 24))
+    kept_t = eng._wt_cache[(keep.data_ptr(), keep._version, 16, 24)][1]
+    for _ in range(200):
+        dgrad_gemm(eng, torch.randn(16, 24, generator=g), tiles, X, torch.empty(8, 24))
+        dgrad_gemm(eng, keep, tiles, X, torch.empty(8, 24))
+    assert eng._wt_cache[(keep.data_ptr(), keep._version, 16, 24)][1] is kept_t and len(eng._wt_cache) <= 64

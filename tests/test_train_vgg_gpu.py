@@ -64,6 +64,26 @@ def test_conv3x3_raw_hl16_with_device_side_scales(hip, L, H, W, Cin, Cout, scale
     assert (out < 0).any()  # no ReLU
 
 
+@pytest.mark.parametrize('amax', [0.0, 1e-45, 1e-40, float('inf'), float('nan'), 3e38])
+def test_device_side_scales_survive_degenerate_maxima(hip, amax):
+    """a zero / denormal / non-finite maximum must not become a 2^(+-huge) scale (ldexpf -> inf, 0 * inf = NaN
+    in the products): the exponent is clamped to +-100 and a non-finite or non-positive maximum means "unscaled""""
+    x = rnd(64, 64, seed=40).cuda() * (0.0 if amax == 0.0 else 1.0)
+    am = torch.tensor([amax], dtype=torch.float32, device=DEV)
+    y16, osc = torch.empty(64, 64, device=DEV), torch.empty(64, device=DEV)
+    hip.hl16_pack_pow2(x, y16, am, 11)
+    hip.pow2_oscale(osc, am, 11, am, 14)
+    from mmmot_amd.pack import from_hl16
+    back = from_hl16(y16.cpu())
+    assert torch.isfinite(back).all() and torch.isfinite(osc).all() and (osc > 0).all()
+    # whatever scale was chosen, unscaling by the vector's factor for ONE operand gives the input back (fp16-split accuracy)
+    one = torch.empty(64, device=DEV)
+    hip.pow2_oscale(one, am, 11, None, 0)
+    if not (0.0 < amax < float('inf')):  # "unscaled": the split of the data itself (a finite maximum that lies about the
+        assert one[0].item() == 1.0       # O(1) data - the other cases - only has to stay finite)
+        close(back.cuda(), x, 1e-5, 'pack_pow2 round trip')
+
+
 def test_rows_stats_and_bn_relu_pool(hip):
     emu = TorchOps(torch.float64)
     L, H, W, C = 3, 9, 7, 64
