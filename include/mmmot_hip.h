@@ -177,8 +177,8 @@ int mmmot_set_patch_grid_limit(int n);
  * 8 = such maps run as one haloed 8 x 8 block at 25 % fill like before ABI 7.  Results do not depend on it, bit for bit. */
 int mmmot_set_patch_min_block(int bs);
 #ifdef MMMOT_DEBUG
-/* -DMMMOT_DEBUG builds only (tools/, never the product library): timing experiments of the patch kernel
- * (0 = product; 1..8 remove loads / barriers / MFMAs / stores and give WRONG results) and their phase timers. */
+/* -DMMMOT_DEBUG builds only (tools/, never the product library; csrc/patch_debug.h): phase timers of the patch kernel
+ * (0 = the product kernels, 9 = the timed instantiations; results are correct either way) and their read-out. */
 int mmmot_set_patch_variant(int v);
 int mmmot_debug_read_patch_timers(unsigned long long* out8, int reset);
 #endif

@@ -167,7 +167,9 @@ def build(force=False, verbose=False, debug=False):
     -DMMMOT_DEBUG variant (timing experiments of the patch kernel) as libmmmot_hip_debug.so; load it by setting
     MMMOT_LIB_PATH before importing mmmot_amd (tools/ do)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, 'common.h'), os.path.join(_HERE, '..', 'include', 'mmmot_hip.h')]
+    # headers and the textual parts of the trunk kernel (csrc/patch_*.inc): any of them newer than the library rebuilds it
+    deps = srcs + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(('.h', '.inc'))] + \
+        [os.path.join(_HERE, '..', 'include', 'mmmot_hip.h')]
     lib_path = DEBUG_LIB_PATH if debug else LIB_PATH
     if not force and os.path.exists(lib_path):
         if all(os.path.getmtime(lib_path) >= os.path.getmtime(d) for d in deps):

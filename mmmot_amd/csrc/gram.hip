@@ -174,22 +174,35 @@ __global__ __launch_bounds__(GR_THREADS) void gram_rows_kernel(const float* __re
   (void)CT;
 }
 
-// sum of the super-tile partials of every group: red[g][K*K + K] doubles (Gram, then column sums)
+// sum of the super-tile partials of every group -> covariance and mean of the group's rows:
+// red[g][K*K + K] doubles = Cov(a) (K x K), then E[a] (K).  Every thread also re-adds the two column sums its element
+// needs (nt <= a few dozen terms each) so that the covariance is formed ONCE per group here instead of once per
+// workgroup of the finalize kernel (16 per group, 64 float64 divisions per thread each); sums, quotients and the
+// product are those of the round-4 kernels, in their order: bit-identical scale / shift.
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restrict__ Gp, const double* __restrict__ Sp,
                                                           const int* __restrict__ grp_tile0,
-                                                          const int* __restrict__ grp_ntiles, int K,
+                                                          const int* __restrict__ grp_ntiles,
+                                                          const int* __restrict__ grp_count, int K,
                                                           double* __restrict__ red) {
   const int g = blockIdx.y;
   const int idx = blockIdx.x * 256 + threadIdx.x;
   const int KK = K * K;
   if (idx >= KK + K) return;
   const int t0 = grp_tile0[g], nt = grp_ntiles[g];
-  double s = 0.0;
-  if (idx < KK)
+  const double cnt = (double)grp_count[g];
+  auto colsum = [&](int k) {
+    double s = 0.0;
+    for (int t = 0; t < nt; ++t) s += Sp[(long)(t0 + t) * K + k];
+    return s;
+  };
+  if (idx < KK) {
+    double s = 0.0;
     for (int t = 0; t < nt; ++t) s += Gp[(long)(t0 + t) * KK + idx];
-  else
-    for (int t = 0; t < nt; ++t) s += Sp[(long)(t0 + t) * K + (idx - KK)];
-  red[(long)g * (KK + K) + idx] = s;
+    const double mi = colsum(idx / K) / cnt, mj = colsum(idx % K) / cnt;
+    red[(long)g * (KK + K) + idx] = s / cnt - mi * mj;
+  } else {
+    red[(long)g * (KK + K) + idx] = colsum(idx - KK) / cnt;
+  }
 }
 
 // scale / shift of GroupNorm(N, N) applied to v = W a + b: one workgroup per (group, GF_CH output channels);
@@ -212,11 +225,9 @@ __global__ __launch_bounds__(256) void gn_finalize_gram_kernel(const double* __r
   __shared__ double m[K];
   constexpr int NR = K / 64;  // rows of C per lane
   const int g = blockIdx.x, n0 = blockIdx.y * GF_CH;
-  const double cnt = (double)grp_count[g];
-  const double* R = red + (long)g * (K * K + K);
-  for (int k = threadIdx.x; k < K; k += 256) m[k] = R[K * K + k] / cnt;
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < K * K; idx += 256) C[idx] = R[idx] / cnt - m[idx / K] * m[idx % K];
+  const double* R = red + (long)g * (K * K + K);  // covariance and mean of the group (gram_reduce_kernel)
+  for (int k = threadIdx.x; k < K; k += 256) m[k] = R[K * K + k];
+  for (int idx = threadIdx.x; idx < K * K; idx += 256) C[idx] = R[idx];
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -302,7 +313,7 @@ extern "C" int mmmot_gn_finalize_gram(const double* Gp, const double* Sp, const 
     return MMMOT_EINVAL;
   if ((K != 64 && K != 128) || G <= 0 || N <= 0) return MMMOT_EINVAL;
   hipLaunchKernelGGL(gram_reduce_kernel, dim3((K * K + K + 255) / 256, G), dim3(256), 0, s, Gp, Sp, grp_tile0,
-                     grp_ntiles, K, work);
+                     grp_ntiles, grp_count, K, work);
   if (K == 128)
     hipLaunchKernelGGL(gn_finalize_gram_kernel<128>, dim3(G, (N + GF_CH - 1) / GF_CH), dim3(256), 0, s, work, grp_count, W, bias,
                        N, gamma, beta, eps, sc, sh);

@@ -197,16 +197,20 @@ class LaunchProfiler:
             torch.cuda.synchronize()
         agg = {}
         for label, fl, by, e0, e1 in self.records:
-            r = agg.setdefault(label, [0, 0.0, 0.0, 0.0])
+            r = agg.setdefault(label, [0, 0.0, 0.0, 0.0, 0.0])
+            ms1 = e0.elapsed_time(e1) if self.cuda else (e1 - e0) * 1e3
             r[0] += 1
-            r[1] += e0.elapsed_time(e1) if self.cuda else (e1 - e0) * 1e3
+            r[1] += ms1
+            r[4] = max(r[4], ms1)
             r[2] += fl
             r[3] += by
         rows = []
-        for label, (n, ms, fl, by) in agg.items():
+        for label, (n, ms, fl, by, mx) in agg.items():
             t_mfma = fl / (self.peak_tf * 1e12) * 1e3     # ms at the matrix-core peak
             t_hbm = by / (PEAK_HBM_TBS * 1e12) * 1e3      # ms at the HBM peak
             row = {'class': label, 'launches_per_step': round(n / steps, 2), 'ms_per_step': round(ms / steps, 4)}
+            if n > steps:
+                row['longest_launch_ms'] = round(mx, 4)
             if max(t_mfma, t_hbm) / max(n, 1) < 5e-3:
                 row['bound'] = 'latency'
             elif t_mfma >= t_hbm:

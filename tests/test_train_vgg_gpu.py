@@ -67,7 +67,7 @@ def test_conv3x3_raw_hl16_with_device_side_scales(hip, L, H, W, Cin, Cout, scale
 @pytest.mark.parametrize('amax', [0.0, 1e-45, 1e-40, float('inf'), float('nan'), 3e38])
 def test_device_side_scales_survive_degenerate_maxima(hip, amax):
     """a zero / denormal / non-finite maximum must not become a 2^(+-huge) scale (ldexpf -> inf, 0 * inf = NaN
-    in the products): the exponent is clamped to +-100 and a non-finite or non-positive maximum means "unscaled""""
+    in the products): the exponent is clamped to +-100 and a non-finite or non-positive maximum means 'unscaled' """
     x = rnd(64, 64, seed=40).cuda() * (0.0 if amax == 0.0 else 1.0)
     am = torch.tensor([amax], dtype=torch.float32, device=DEV)
     y16, osc = torch.empty(64, 64, device=DEV), torch.empty(64, device=DEV)

@@ -28,7 +28,7 @@ def main():
         shift = hl16_weight_shift(w)
         wq = to_hq8_w(w.double() * 2.0 ** shift).cuda()
         bias, out = torch.zeros(Cout).cuda(), torch.empty(L * H * W, Cout).cuda()
-        for variant in (9, 10):  # 10 = the same without the global stores
+        for variant in (9,):  # (round 5: the 'no global stores' variant 10 left the kernel with the other experiments)
             lib.mmmot_set_patch_variant(variant)
             buf = (ctypes.c_ulonglong * 8)()
             for r in range(3):
