@@ -594,6 +594,15 @@ int mmmot_pointnet_layer1_bwd(const float* dY, const float* X, int K, const int*
 int mmmot_score_loss(const float* x, int ldx, const float* y, const float* mrow, const float* mcol, int M, int mask_mode,
                      float ignore, int kind, float scale, int R, int C, float* g, int ldg, float* PL, int nblocks,
                      int accumulate, void* stream);
+/* ABI 9.  The 'ghm' type of DetLoss (reference cost.py:105-110,126-128 -> modules/ghm_loss.py:15-61, GHMC_Loss):
+ * gradient-harmonised BCE-with-logits of x [R][C] against y [C] (shared by the R rows), entries with y == ignore masked.
+ * |sigmoid(x) - y| of the valid elements is histogrammed over `bins` (<= 64) equal bins of [0, 1]; acc_sum [bins]
+ * (float64, device) is the module's running state, updated in place: acc <- momentum * acc + (1 - momentum) * count for
+ * every non-empty bin (momentum == 0: acc = count, acc_sum untouched); weight = float(tot / acc) / (non-empty bins),
+ * tot = max(valid elements, 1).  g[r][c] = scale * w * (sigmoid(x) - y) / tot (weights are constants of the graph),
+ * PL[0] (+)= scale * sum(w * bce) / tot (accumulate != 0: added, like mmmot_score_loss).  One workgroup; R * C <= 2^24. */
+int mmmot_ghm_loss(const float* x, int ldx, const float* y, float ignore, float scale, int R, int C, int bins,
+                   float momentum, double* acc_sum, float* g, int ldg, float* PL, int accumulate, void* stream);
 
 /* MFMA fragment-layout self test: C[32][32] = A[32][K] * B[32][K]^T through
  * the same fragment mapping the GEMM kernels use (K % 8 == 0). */

@@ -151,6 +151,8 @@ SIGNATURES = {
     'mmmot_pointnet_layer1_bwd': [c_f, c_f, c_i, c_f, c_f, c_i, c_f, c_f],
     'mmmot_score_loss': [c_f, c_i, c_f, c_f, c_f, c_i, c_i, ctypes.c_float, c_i, ctypes.c_float, c_i, c_i, c_f, c_i, c_f,
                          c_i, c_i, c_f],
+    'mmmot_ghm_loss': [c_f, c_i, c_f, ctypes.c_float, ctypes.c_float, c_i, c_i, c_i, ctypes.c_float, c_f, c_f, c_i, c_f, c_i,
+                       c_f],
 }
 
 

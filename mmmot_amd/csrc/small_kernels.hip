@@ -25,14 +25,17 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(
   // every thread adds its elements in the order of the division form: same sums, bit for bit
   const int dq = 256 / CG, dr = 256 % CG;
   const int ti0 = tid / CG, cc0 = tid % CG;
+  // U elements per trip: the loop is a chain of HBM round trips on 256 threads per (group, norm group) - with 4 in flight
+  // the 128 tiles x 512 channels of a 128 x 128 pair block still took 194 us; the additions stay in element order
+  constexpr int U = 16;
   double s1 = 0.0;
   {
     int ti = ti0, cc = cc0;
     while (ti < nt) {
-      float v[4];
+      float v[U];
       int n = 0;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < U; ++u) {
         v[u] = 0.f;
         if (ti < nt) {
           v[u] = part[((long)(tile0 + ti) * 2 + 0) * ldp + c0 + cc];
@@ -43,7 +46,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < U; ++u)
         if (u < n) s1 += (double)v[u];
     }
   }
@@ -57,17 +60,17 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(
   {
     int ti = ti0, cc = cc0;
     while (ti < nt) {
-      float vs[4], vm[4];
-      double nn[4];
+      float vs[U], vm[U];
+      float nn[U];
       int n = 0;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < U; ++u) {
         vs[u] = vm[u] = 0.f;
-        nn[u] = 0.0;
+        nn[u] = 0.f;
         if (ti < nt) {
           const int t = tile0 + ti;
           const int left = rows - ti * MM_BM;
-          nn[u] = tile_nrows ? (double)tile_nrows[t] : (double)(left < MM_BM ? left : MM_BM);
+          nn[u] = tile_nrows ? (float)tile_nrows[t] : (float)(left < MM_BM ? left : MM_BM);  // a row count: exact in fp32
           vs[u] = part[((long)t * 2 + 0) * ldp + c0 + cc];
           vm[u] = part[((long)t * 2 + 1) * ldp + c0 + cc];
           n = u + 1;
@@ -77,10 +80,11 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (u < n && nn[u] > 0.0) {  // half tiles of the A-resident GEMM may be empty
-          const double d = (double)vs[u] / nn[u] - mean;
-          s2 += (double)vm[u] + nn[u] * d * d;
+      for (int u = 0; u < U; ++u)
+        if (u < n && nn[u] > 0.f) {  // half tiles of the A-resident GEMM may be empty
+          const double n_t = (double)nn[u];
+          const double d = (double)vs[u] / n_t - mean;
+          s2 += (double)vm[u] + n_t * d * d;
         }
     }
   }
@@ -364,6 +368,42 @@ __global__ __launch_bounds__(256) void rowdot_kernel(
   const int g = tile_group ? tile_group[t] : 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool norm = (sc != nullptr);
+  if (K <= 128) {
+    // short rows (the 128 -> 1 layers over the N x M pair rows: 0.8 GB per cfg4 step): a row is 32 lanes x 16 bytes, so
+    // the two halves of a wave take two rows at a time and the weight / scale / shift vectors are read once per
+    // workgroup, not once per row.  Per row the sum is the one of the general loop below, bit for bit: there the upper
+    // half holds zeros and the first butterfly step adds them (x + 0 = x); here that step is skipped.
+    const int hl = lane & 31, hi = lane >> 5, k = hl * 4;
+    const bool live = k < K;
+    f32x4 wv = {0.f, 0.f, 0.f, 0.f}, s4 = wv, h4 = wv;
+    if (live) {
+      wv = *reinterpret_cast<const f32x4*>(w + k);
+      if (norm) {
+        s4 = *reinterpret_cast<const f32x4*>(&sc[(long)g * ldsc + k]);
+        h4 = *reinterpret_cast<const f32x4*>(&sh[(long)g * ldsc + k]);
+      }
+    }
+    for (int r0 = 2 * wave; r0 < nrows; r0 += 8) {
+      const int r = r0 + hi;
+      float acc = 0.f;
+      if (live && r < nrows) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(X + (long)(row0 + r) * ldx + k);
+        if (norm) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], s4[e], h4[e]), 0.f);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = fmaf(v[e], wv[e], acc);
+      }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+      float s = acc + b;
+      s = mm_act(s, act);
+      if (use_thr && s < thr) s -= 1.f;
+      if (hl == 0 && r < nrows) out[omap ? omap[row0 + r] : row0 + r] = s;
+    }
+    return;
+  }
   for (int r = wave; r < nrows; r += 4) {
     const float* xr = X + (long)(row0 + r) * ldx;
     float acc = 0.f;
@@ -821,7 +861,7 @@ extern "C" int mmmot_softmax_pairs(const float* logits, float* out, const int* g
 }
 
 // ---------------------------------------------------------------------------
-extern "C" int mmmot_abi_version(void) { return 8; }
+extern "C" int mmmot_abi_version(void) { return 9; }
 
 extern "C" int mmmot_device_info(int device, int* cu_count, char* arch, int arch_len) {
   hipDeviceProp_t p;

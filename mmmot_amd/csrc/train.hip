@@ -156,3 +156,102 @@ extern "C" int mmmot_score_loss(const float* x, int ldx, const float* y, const f
                      mask_mode, ignore, kind, scale, R, C, g, ldg, PL, accumulate);
   return mm_check(hipGetLastError());
 }
+
+// ---------------------------------------------------------------------------
+// detloss_type / endloss_type 'ghm' of TrackingLoss (reference cost.py:105-110,126-128 -> modules/ghm_loss.py:15-61,
+// GHMC_Loss(bins = 30, momentum = 0.75)): gradient-harmonised binary cross entropy of x [R][C] against the target y [C]
+// shared by the R modality rows, entries with y == ignore masked out.  ONE workgroup (the det / new / end score tensors
+// of a sample hold 3 x L values), three passes over the elements:
+//   1. gradient length gl = |sigmoid(x) - y|, histogram of the valid elements over `bins` equal bins of [0, 1]
+//      (float32 comparisons against float32 edges like the reference's tensor-vs-scalar comparisons; last edge + 1e-6),
+//      tot = max(number of valid elements, 1);
+//   2. per non-empty bin (float64, like the reference's Python floats): acc_sum[b] <- momentum * acc_sum[b] +
+//      (1 - momentum) * count (momentum == 0: acc = count, acc_sum untouched), weight = float(tot / acc) / n with n the
+//      number of non-empty bins; acc_sum [bins] is the loss module's STATE (device memory, updated in place);
+//   3. l = w * bce_with_logits(x, y), g = scale * w * (sigmoid(x) - y) / tot (the weights are constants of the graph),
+//      PL[0] (+)= scale * sum(l) / tot.
+#define GHM_MAX_BINS 64
+__global__ __launch_bounds__(256) void ghm_loss_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ y,
+                                                       float ignore, float scale, int R, int C, int bins, float momentum,
+                                                       double* __restrict__ acc_sum, float* __restrict__ g, int ldg,
+                                                       float* __restrict__ PL, int accumulate) {
+  __shared__ int cnt[GHM_MAX_BINS];
+  __shared__ float wbin[GHM_MAX_BINS];
+  __shared__ float edge[GHM_MAX_BINS + 1];
+  __shared__ int nvalid, nbins_used;
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  const int n = R * C;
+  if (tid < bins) cnt[tid] = 0;
+  if (tid <= bins) edge[tid] = (float)((double)tid / (double)bins + (tid == bins ? 1e-6 : 0.0));
+  if (tid == 0) nvalid = 0;
+  __syncthreads();
+  auto bin_of = [&](float xv, float yv) {
+    const float gl = fabsf(1.f / (1.f + expf(-xv)) - yv);
+    int b = -1;
+    for (int i = 0; i < bins; ++i)
+      if (gl >= edge[i] && gl < edge[i + 1]) b = i;
+    return b;
+  };
+  for (int idx = tid; idx < n; idx += 256) {
+    const int r = idx / C, c = idx - r * C;
+    const float yv = y[c];
+    if (yv != ignore) {
+      atomicAdd(&nvalid, 1);
+      const int b = bin_of(x[(long)r * ldx + c], yv);
+      if (b >= 0) atomicAdd(&cnt[b], 1);
+    }
+  }
+  __syncthreads();
+  const double tot = nvalid > 1 ? (double)nvalid : 1.0;
+  if (tid == 0) {
+    int used = 0;
+    for (int b = 0; b < bins; ++b)
+      if (cnt[b] > 0) {
+        double acc = (double)cnt[b];
+        if (momentum > 0.f) {
+          acc = (double)momentum * acc_sum[b] + (1.0 - (double)momentum) * (double)cnt[b];
+          acc_sum[b] = acc;
+        }
+        wbin[b] = (float)(tot / acc);
+        ++used;
+      } else {
+        wbin[b] = 0.f;
+      }
+    nbins_used = used;
+  }
+  __syncthreads();
+  const float nused = (float)(nbins_used > 0 ? nbins_used : 1);
+  const float ftot = (float)tot;
+  float s = 0.f;
+  for (int idx = tid; idx < n; idx += 256) {
+    const int r = idx / C, c = idx - r * C;
+    const float xv = x[(long)r * ldx + c], yv = y[c];
+    float w = 0.f;
+    if (yv != ignore) {
+      const int b = bin_of(xv, yv);
+      if (b >= 0) w = wbin[b] / nused;
+    }
+    const float l = fmaxf(xv, 0.f) - xv * yv + log1pf(expf(-fabsf(xv)));
+    const float d = 1.f / (1.f + expf(-xv)) - yv;
+    s += w * l;
+    g[(long)r * ldg + c] = scale * (w * d) / ftot;
+  }
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) {
+    const float v = scale * ((red[0] + red[1] + red[2] + red[3]) / ftot);
+    PL[0] = accumulate ? PL[0] + v : v;
+  }
+}
+
+extern "C" int mmmot_ghm_loss(const float* x, int ldx, const float* y, float ignore, float scale, int R, int C, int bins,
+                              float momentum, double* acc_sum, float* g, int ldg, float* PL, int accumulate, void* stream) {
+  if (!x || !y || !acc_sum || !g || !PL || R <= 0 || C <= 0 || (long)R * C > (1L << 24)) return MMMOT_EINVAL;
+  if (bins <= 0 || bins > GHM_MAX_BINS || !(momentum >= 0.f) || momentum >= 1.f || ldx < C || ldg < C) return MMMOT_EINVAL;
+  hipLaunchKernelGGL(ghm_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ignore, scale, R, C, bins,
+                     momentum, acc_sum, g, ldg, PL, accumulate);
+  return mm_check(hipGetLastError());
+}
+

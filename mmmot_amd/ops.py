@@ -444,6 +444,13 @@ class HipOps:
         _lib.check(st, 'mmmot_score_loss')
 
     # ---- training step, third slice: training-mode VGG trunk (csrc/train_vgg.hip, conv3x3.hip RAW) ----
+    def ghm_loss(self, x, y, scale, g, PL, acc_sum, bins=30, momentum=0.75, ignore=-1.0, accumulate=False):
+        """the 'ghm' DetLoss term (mmmot_ghm_loss): x, g [R][C]; y [C]; acc_sum float64 [bins] = the module's running state"""
+        R, C = x.shape
+        st = self.lib.mmmot_ghm_loss(_ptr(x), _ld(x), _ptr(y), float(ignore), float(scale), R, C, int(bins), float(momentum),
+                                     _ptr(acc_sum, torch.float64), _ptr(g), _ld(g), _ptr(PL), int(accumulate), self._stream())
+        _lib.check(st, 'mmmot_ghm_loss')
+
     def conv3x3_raw(self, inp, wp, bias, out, L, H, W, Cin, Cout, first):
         st = self.lib.mmmot_conv3x3_raw(_ptr(inp), _ptr(wp), _ptr(bias), _ptr(out), L, H, W, Cin, Cout, int(first),
                                         self._stream())

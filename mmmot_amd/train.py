@@ -214,7 +214,11 @@ class _ScoreLossFn(torch.autograd.Function):
             x = scores[si].detach()
             x = x.reshape(x2d).contiguous() if x2d is not None else x.contiguous()
             g = torch.empty_like(x)
-            ops.score_loss(x, y, kind, scale, g, PL, accumulate=(k > 0), **mask)
+            if kind == 'ghm':  # mask['state']: the module's running per-bin counts (updated in place by the kernel)
+                ops.ghm_loss(x, y, scale, g, PL, mask['state'], bins=mask['bins'], momentum=mask['momentum'],
+                             accumulate=(k > 0))
+            else:
+                ops.score_loss(x, y, kind, scale, g, PL, accumulate=(k > 0), **mask)
             grads.append((si, g))
         ctx.grads, ctx.n = grads, len(scores)
         ctx.shapes = [tuple(s.shape) for s in scores]
@@ -238,8 +242,13 @@ class TrackingLoss(nn.Module):
                  trans_last=False, linkloss_type='l2_softmax'):
         super().__init__()
         for name, v in (('detloss_type', detloss_type), ('endloss_type', endloss_type)):
-            if not any(k in v for k in ('bce', 'l2', 'l1')) or 'ghm' in v:
-                raise NotImplementedError("%s %r: 'bce', 'l2' and 'l1' are built" % (name, v))
+            if not any(k in v for k in ('bce', 'l2', 'l1', 'ghm')):
+                raise NotImplementedError("%s %r: 'bce', 'l2', 'l1' and 'ghm' are built" % (name, v))
+        # 'ghm' (cost.py:105-110 -> modules/ghm_loss.py GHMC_Loss(bins=30, momentum=0.75)) keeps running per-bin counts
+        # between calls: one state per DetLoss instance of the reference - `det_loss`, and `end_loss`, which serves the new
+        # AND the end scores in that order (cost.py:154-155,164-166).  float64 [30] device tensors, created on first use.
+        self.ghm_bins, self.ghm_momentum = 30, 0.75
+        self._ghm_acc = {}
         # cost.py:73 - the reference's own default 'l2_softmax' trips this assert; its configs pass 'l2'
         assert linkloss_type in ['l1', 'l2']
         self.smooth_ratio, self.det_ratio, self.trans_ratio, self.trans_last = smooth_ratio, det_ratio, trans_ratio, trans_last
@@ -257,13 +266,22 @@ class TrackingLoss(nn.Module):
         """DetLoss.forward (cost.py:109-131): every type named in `loss_type` REPLACES the previous one (plain
         assignments in the reference), so the last matching one counts: order bce, l2, l1"""
         kind = None
-        for k in ('bce', 'l2', 'l1'):
+        for k in ('bce', 'l2', 'l1', 'ghm'):
             if k in loss_type:
                 kind = k
         R, C = score.shape
         gt = gt.to(torch.float32).contiguous()
+        if kind == 'ghm':  # no reduction='mean' here: GHMC_Loss divides by its own count of valid elements
+            return [(si, None, gt, 'ghm', ratio, dict(state='det' if si == 0 else 'end'))]
         mask = {} if kind == 'bce' else dict(mcol=gt, M=C, mask_mode=2, ignore=-1.0)
         return [(si, None, gt, LOSS_KINDS[kind], ratio / (R * C), mask)]
+
+    def ghm_state(self, which, device=None):
+        """running per-bin counts of the 'det' / 'end' GHMC_Loss (float64 [bins] device tensor; the reference's acc_sum)"""
+        t = self._ghm_acc.get(which)
+        if t is None or (device is not None and t.device != torch.device(device)):
+            t = self._ghm_acc[which] = torch.zeros(self.ghm_bins, dtype=torch.float64, device=device)
+        return t
 
     def forward(self, det_split, gt_det, gt_link, gt_new, gt_end, det_score, link_score, new_score, end_score, trans=None):
         split = [int(d.item()) if torch.is_tensor(d) else int(d) for d in det_split]
@@ -287,6 +305,9 @@ class TrackingLoss(nn.Module):
             for k in ('l2', 'l1'):
                 if k in self.linkloss_type:
                     terms.append((3 + i, (R, N * M), y, LOSS_KINDS[k], 1.0 / (R * N * M), mask))
+        for t in terms:  # 'ghm' terms: hand the kernel this module's state tensors
+            if t[3] == 'ghm':
+                t[5].update(state=self.ghm_state(t[5]['state'], det_score.device), bins=self.ghm_bins, momentum=self.ghm_momentum)
         loss = _ScoreLossFn.apply(self._ops(), terms, *scores)
         if trans is not None:
             # cost.py:175-184 (an ELEMENTWISE product with the transpose, as written there); 64 x 64: torch

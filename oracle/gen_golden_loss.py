@@ -104,6 +104,57 @@ def main():
         np.savez_compressed(os.path.join(GOLD, name + '.npz'), **out)
         print('%-16s frames %-10s loss %.6f   |reference - restatement| <= %.1e' % (name, counts, loss.item(), err))
     print('worst |reference - restatement| over loss values and gradients: %.2e' % worst)
+    ghm_sequence(ref_cost)
+
+
+def ghm_sequence(ref_cost):
+    """detloss_type / endloss_type 'ghm' (cost.py:105-110,126-128 -> modules/ghm_loss.py GHMC_Loss(bins=30, momentum=0.75)):
+    the loss keeps running per-bin counts between calls, so the fixture is a SEQUENCE - one criterion, three consecutive
+    samples; stored per step: inputs, loss, gradients and the running counts of both GHMC_Loss instances afterwards."""
+    kw = dict(detloss_type='ghm', endloss_type='ghm', linkloss_type='l2', det_ratio=1.5, trans_ratio=0.001)
+    # DetLoss('ghm') imports modules.ghm_loss, i.e. the `modules` package, whose __init__ imports torchvision (absent in
+    # this image, only dereferenced on resnet paths): the empty stub of oracle/gen_golden.py - a harness shim, no edit
+    import types
+    tv = types.ModuleType('torchvision')
+    tv.models = types.ModuleType('torchvision.models')
+    sys.modules.setdefault('torchvision', tv)
+    sys.modules.setdefault('torchvision.models', tv.models)
+    with contextlib.redirect_stdout(io.StringIO()):
+        crit = ref_cost.TrackingLoss(**kw)
+    state = dict(det=R.new_ghm_state(), end=R.new_ghm_state())
+    out = dict(kwargs=np.asarray(repr(sorted(kw.items()))), steps=np.asarray(3))
+    worst = 0.0
+    for k, counts in enumerate([[6, 5], [4, 7], [6, 5]]):
+        det, links, new, end, gt_det, gt_link, gt_new, gt_end, trans = make_inputs(counts, 700 + k)
+        gt_det[torch.rand(sum(counts), generator=torch.Generator().manual_seed(710 + k)) > 0.85] = -1.0  # ignored detections
+        leaves = [t.clone().requires_grad_(True) for t in [det, new, end] + links + trans]
+        split = [torch.tensor(c) for c in counts]
+        with uint8_eq():
+            loss = crit(split, gt_det, gt_link, gt_new, gt_end, leaves[0], leaves[3:4], leaves[1], leaves[2], leaves[4:])
+        loss.backward()
+        leaves2 = [t.clone().requires_grad_(True) for t in [det, new, end] + links + trans]
+        loss2 = R.tracking_loss(counts, gt_det, gt_link, gt_new, gt_end, leaves2[0], leaves2[3:4], leaves2[1], leaves2[2],
+                                leaves2[4:], ghm_state=state, **kw)
+        loss2.backward()
+        err = abs(loss.item() - loss2.item())
+        for a, b in zip(leaves, leaves2):
+            ga = a.grad if a.grad is not None else torch.zeros_like(a)
+            gb = b.grad if b.grad is not None else torch.zeros_like(b)
+            err = max(err, (ga - gb).abs().max().item())
+        acc_det, acc_end = crit.det_loss.GHMC_Loss.acc_sum, crit.end_loss.GHMC_Loss.acc_sum
+        err = max(err, max(abs(a - b) for a, b in zip(acc_det + acc_end, state['det'] + state['end'])))
+        worst = max(worst, err)
+        assert err < 1e-6, ('lossseq_ghm', k, err)
+        t = '_%d' % k
+        out.update({'counts' + t: np.asarray(counts), 'loss' + t: np.float32(loss.item()), 'det' + t: det.numpy(),
+                    'new' + t: new.numpy(), 'end' + t: end.numpy(), 'gt_det' + t: gt_det.numpy(), 'gt_new' + t: gt_new.numpy(),
+                    'gt_end' + t: gt_end.numpy(), 'link0' + t: links[0].numpy(), 'gt_link0' + t: gt_link[0].numpy(),
+                    'trans0' + t: trans[0].numpy(), 'trans1' + t: trans[1].numpy(),
+                    'g_det' + t: leaves[0].grad.numpy(), 'g_new' + t: leaves[1].grad.numpy(), 'g_end' + t: leaves[2].grad.numpy(),
+                    'g_link0' + t: leaves[3].grad.numpy(),
+                    'acc_det' + t: np.asarray(acc_det, np.float64), 'acc_end' + t: np.asarray(acc_end, np.float64)})
+        print('lossseq_ghm step %d frames %-8s loss %.6f   |reference - restatement| <= %.1e' % (k, counts, loss.item(), err))
+    np.savez_compressed(os.path.join(GOLD, 'lossseq_ghm.npz'), **out)
 
 
 if __name__ == '__main__':

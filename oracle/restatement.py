@@ -299,8 +299,44 @@ def tracking_forward_train(sd, cfg, img_feats, points, points_split, dets_split,
     return det, links, torch.cat(news, dim=1), torch.cat(ends, dim=1), trans
 
 
-def _det_loss(score, gt, loss_type, ignore_index=-1):
-    """reference cost.py:109-131 (DetLoss.forward; 'ghm' not restated): later types overwrite earlier ones"""
+GHM_BINS, GHM_MOMENTUM = 30, 0.75  # reference cost.py:108: GHMC_Loss(bins=30, momentum=0.75)
+
+
+def new_ghm_state(bins=GHM_BINS):
+    """the running per-bin counts a GHMC_Loss keeps between calls (reference modules/ghm_loss.py:25-26: acc_sum)"""
+    return [0.0] * bins
+
+
+def ghmc_loss(score, target, mask, state, bins=GHM_BINS, momentum=GHM_MOMENTUM):
+    """reference modules/ghm_loss.py:28-61 (GHMC_Loss.forward): gradient-harmonised binary cross entropy.  g = |sigmoid(x) -
+    y| is histogrammed over `bins` equal bins of [0, 1] (last edge + 1e-6), every valid element is weighted with
+    tot / (running count of its bin) / (number of non-empty bins), the weights are constants of the graph.  `state` (the
+    running counts, a list of `bins` floats) is UPDATED in place: count <- momentum * count + (1 - momentum) * n_in_bin."""
+    edges = [float(x) / bins for x in range(bins + 1)]
+    edges[-1] += 1e-6
+    weights = torch.zeros_like(score)
+    g = torch.abs(score.sigmoid().detach() - target)
+    valid = mask > 0
+    tot = max(valid.float().sum().item(), 1.0)
+    n = 0
+    for i in range(bins):
+        inds = (g >= edges[i]) & (g < edges[i + 1]) & valid
+        num_in_bin = inds.sum().item()
+        if num_in_bin > 0:
+            if momentum > 0:
+                state[i] = momentum * state[i] + (1 - momentum) * num_in_bin
+                weights[inds] = tot / state[i]
+            else:
+                weights[inds] = tot / num_in_bin
+            n += 1
+    if n > 0:
+        weights = weights / n
+    return F.binary_cross_entropy_with_logits(score, target, weights, reduction='sum') / tot
+
+
+def _det_loss(score, gt, loss_type, ignore_index=-1, ghm_state=None):
+    """reference cost.py:109-131 (DetLoss.forward): later types overwrite earlier ones.  'ghm': `ghm_state` is the
+    DetLoss instance's GHMC_Loss state (new_ghm_state(); the caller keeps it between calls like the module does)"""
     gt = gt.unsqueeze(0).repeat(score.size(0), 1)
     loss = None
     if 'bce' in loss_type:
@@ -311,6 +347,9 @@ def _det_loss(score, gt, loss_type, ignore_index=-1):
     if 'l1' in loss_type:
         mask = 1 - gt.eq(ignore_index).to(score.dtype)
         loss = F.smooth_l1_loss(score.mul(mask), gt)
+    if 'ghm' in loss_type:
+        mask = 1 - gt.eq(ignore_index).to(score.dtype)
+        loss = ghmc_loss(score, gt, mask, ghm_state)
     return loss
 
 
@@ -335,12 +374,15 @@ def _link_loss(det_split, gt_det, link_score, gt_link, loss_type):
 
 def tracking_loss(det_split, gt_det, gt_link, gt_new, gt_end, det_score, link_score, new_score, end_score, trans=None,
                   detloss_type='bce', endloss_type='l2', det_ratio=0.4, trans_ratio=0.4, trans_last=False,
-                  linkloss_type='l2_softmax'):
-    """reference cost.py:160-185 (TrackingLoss.forward)."""
+                  linkloss_type='l2_softmax', ghm_state=None):
+    """reference cost.py:160-185 (TrackingLoss.forward).  ``ghm_state``: dict(det=..., end=...) of new_ghm_state() lists
+    for 'ghm' loss types - the state of the module's two DetLoss instances (cost.py:154-155; the end instance serves the
+    new AND the end scores, in that order), carried from call to call by the caller."""
     split = [int(d) for d in det_split]
-    loss = _det_loss(det_score, gt_det, detloss_type) * det_ratio
-    loss = loss + _det_loss(new_score, gt_new[split[0]:], endloss_type) * 0.4
-    loss = loss + _det_loss(end_score, gt_end[:gt_end.shape[0] - split[-1]], endloss_type) * 0.4
+    gs = ghm_state or {}
+    loss = _det_loss(det_score, gt_det, detloss_type, ghm_state=gs.get('det')) * det_ratio
+    loss = loss + _det_loss(new_score, gt_new[split[0]:], endloss_type, ghm_state=gs.get('end')) * 0.4
+    loss = loss + _det_loss(end_score, gt_end[:gt_end.shape[0] - split[-1]], endloss_type, ghm_state=gs.get('end')) * 0.4
     loss = loss + _link_loss(split, gt_det, link_score, gt_link, linkloss_type)
     if trans is not None:
         idx = range(len(trans)) if trans_last else [len(trans) - 1]

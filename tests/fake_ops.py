@@ -532,6 +532,36 @@ class TorchOps:
             PL.zero_()
         PL[0] += float(scale * l.sum())
 
+    def ghm_loss(self, x, y, scale, g, PL, acc_sum, bins=30, momentum=0.75, ignore=-1.0, accumulate=False):
+        """executable specification of mmmot_ghm_loss (include/mmmot_hip.h): the three passes of the kernel"""
+        R, C = x.shape
+        xv = x.to(torch.float32)
+        yv = y.to(torch.float32).reshape(1, C).expand(R, C)
+        valid = yv != ignore
+        gl = (torch.sigmoid(xv) - yv).abs()
+        edges = torch.tensor([i / bins for i in range(bins)] + [1.0 + 1e-6], dtype=torch.float64).to(torch.float32)
+        tot = max(float(valid.sum()), 1.0)
+        w = torch.zeros(R, C, dtype=torch.float32)
+        used = 0
+        for b in range(bins):
+            inds = (gl >= edges[b]) & (gl < edges[b + 1]) & valid
+            cnt = int(inds.sum())
+            if cnt > 0:
+                acc = float(cnt)
+                if momentum > 0:
+                    acc = momentum * float(acc_sum[b]) + (1.0 - momentum) * cnt
+                    acc_sum[b] = acc
+                w[inds] = tot / acc
+                used += 1
+        w = w / float(max(used, 1))
+        xd, yd, wd = xv.to(self.dtype), yv.to(self.dtype), w.to(self.dtype)
+        l = torch.clamp(xd, min=0) - xd * yd + torch.log1p(torch.exp(-xd.abs()))
+        d = torch.sigmoid(xd) - yd
+        g[:, :C] = (scale * (wd * d) / tot).to(g.dtype)
+        if not accumulate:
+            PL.zero_()
+        PL[0] += float(scale * (wd * l).sum() / tot)
+
     def rowdot(self, X, K, w, b, tiles, out, sc=None, sh=None, act=ACT_NONE, use_thr=False, thr=0.0, omap=None):
         R = tiles.R
         A = X[:R, :K]

@@ -9,7 +9,7 @@ from fake_ops import TorchOps
 from mmmot_amd import TrackingLoss, build_criterion
 from mmmot_amd.train import FOLDED, fold_pointnet, pointnet_autograd
 from oracle import restatement as R
-from test_train_oracle import CASES, load_case
+from test_train_oracle import CASES, load_case, load_ghm_sequence
 
 HEADS = ('point_net.', 'fusion_module.', 'w_det.', 'w_link.')
 
@@ -36,9 +36,34 @@ def test_criterion_constructor_mirrors_the_reference():
     with pytest.raises(AssertionError):      # cost.py:73: the reference's own default link loss type fails its assert
         TrackingLoss()
     with pytest.raises(NotImplementedError):
-        TrackingLoss(detloss_type='ghm', linkloss_type='l2')
+        TrackingLoss(detloss_type='focal', linkloss_type='l2')
     c = build_criterion(dict(det_loss='bce', link_loss='l2', smooth_ratio=0, det_ratio=1.5, trans_ratio=0.001, trans_last=False))
     assert c.det_ratio == 1.5 and c.trans_ratio == 0.001 and c.linkloss_type == 'l2'
+
+
+def run_ghm_sequence(crit, dev, loss_tol, grad_tol):
+    """the 'ghm' loss types keep running per-bin counts: one criterion, the fixture's three consecutive samples"""
+    kw, steps = load_ghm_sequence()
+    for st in steps:
+        ins = st['ins']
+        leaf = lambda x: x.clone().to(dev).requires_grad_(True)
+        d = lambda x: x.to(dev)
+        det, new, end, link = leaf(ins['det']), leaf(ins['new']), leaf(ins['end']), leaf(ins['links'][0])
+        loss = crit([torch.tensor(c) for c in st['counts']], d(ins['gt_det']), [d(ins['gt_link'][0])], d(ins['gt_new']),
+                    d(ins['gt_end']), det, [link], new, end, [d(x) for x in ins['trans']])
+        loss.backward()
+        assert abs(loss.item() - st['loss']) < loss_tol * max(1.0, abs(st['loss']))
+        for got, key in ((det, 'det'), (new, 'new'), (end, 'end'), (link, 'link')):
+            assert (got.grad.cpu() - st['grads'][key]).abs().max().item() < grad_tol
+        for which in ('det', 'end'):  # the module's state after the step = the reference's acc_sum lists
+            assert (crit.ghm_state(which).cpu() - st['acc'][which]).abs().max().item() < 1e-9
+
+
+def test_ghm_loss_operator_sequence_matches_the_reference_fixture():
+    kw, _ = load_ghm_sequence()
+    crit = TrackingLoss(**kw)
+    crit.ops = TorchOps(torch.float64)
+    run_ghm_sequence(crit, 'cpu', 2e-6, 1e-6)
 
 
 def oracle_sd(model, dtype=torch.float64):

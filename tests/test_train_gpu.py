@@ -88,6 +88,34 @@ def test_tracking_loss_on_the_device_matches_the_reference_fixture(name):
         assert (g - want).abs().max().item() < 1e-6
 
 
+def test_ghm_loss_on_the_device_matches_the_reference_sequence():
+    """detloss_type / endloss_type 'ghm' (cost.py:105-110 -> modules/ghm_loss.py): mmmot_ghm_loss against the IMPORTED
+    reference's criterion over three consecutive samples - loss, gradients and the running per-bin counts"""
+    from test_train_cpu import run_ghm_sequence
+    from test_train_oracle import load_ghm_sequence
+    kw, _ = load_ghm_sequence()
+    crit = TrackingLoss(**kw)
+    run_ghm_sequence(crit, DEV, 2e-6, 1e-6)
+    assert crit.ops.name == 'hip'
+
+
+@pytest.mark.parametrize('R_,C_,mom', [(3, 11, 0.75), (3, 700, 0.75), (1, 5, 0.0), (3, 64, 0.5)])
+def test_ghm_loss_kernel_against_its_specification(hip, R_, C_, mom):
+    emu = TorchOps(torch.float64)
+    x = rnd(R_, C_, seed=70) * 3
+    y = (rnd(C_, seed=71) > 0).float()
+    y[::7] = -1.0
+    acc0 = rnd(30, seed=72).abs().double() * 5
+    gr, pr, ar = torch.zeros(R_, C_, dtype=torch.float64), torch.zeros(1, dtype=torch.float64), acc0.clone()
+    emu.ghm_loss(x, y, 1.5, gr, pr, ar, momentum=mom)
+    gg, pg, ag = torch.zeros(R_, C_).cuda(), torch.full((1,), 2.0).cuda(), acc0.clone().cuda()
+    hip.ghm_loss(x.cuda(), y.cuda(), 1.5, gg, pg, ag, momentum=mom, accumulate=True)
+    close(gg, gr.float(), 2e-6, 'ghm gradient')
+    assert abs(pg.item() - 2.0 - pr.item()) < 1e-5 * (1 + abs(pr.item()))
+    assert (ag.cpu() - ar).abs().max().item() < 1e-9 * (1 + ar.abs().max().item())
+    assert (gg.cpu()[:, ::7] == 0).all()  # ignored targets carry no gradient
+
+
 @pytest.mark.parametrize('name', ['s2_C_multiply_none', 's7_refl_B'])
 def test_pointnet_backward_on_the_device(name):
     c, base = get_case(name)

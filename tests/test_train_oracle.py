@@ -47,6 +47,39 @@ def test_oracle_loss_matches_the_reference_fixture(name):
         assert (g - want).abs().max().item() < 1e-7
 
 
+def load_ghm_sequence():
+    """tests/golden/lossseq_ghm.npz (oracle/gen_golden_loss.py::ghm_sequence): ONE criterion of the imported reference
+    with detloss_type = endloss_type = 'ghm' called on three consecutive samples - the loss keeps running per-bin counts"""
+    g = np.load(os.path.join(GOLD, 'lossseq_ghm.npz'))
+    kw = dict(ast.literal_eval(str(g['kwargs'])))
+    steps = []
+    for k in range(int(g['steps'])):
+        t = lambda key: torch.from_numpy(g['%s_%d' % (key, k)])
+        steps.append(dict(counts=[int(c) for c in g['counts_%d' % k]], loss=float(g['loss_%d' % k]),
+                          ins=dict(det=t('det'), new=t('new'), end=t('end'), links=[t('link0')], trans=[t('trans0'), t('trans1')],
+                                   gt_det=t('gt_det'), gt_new=t('gt_new'), gt_end=t('gt_end'), gt_link=[t('gt_link0')]),
+                          grads=dict(det=t('g_det'), new=t('g_new'), end=t('g_end'), link=t('g_link0')),
+                          acc=dict(det=t('acc_det'), end=t('acc_end'))))
+    return kw, steps
+
+
+def test_oracle_ghm_loss_sequence_matches_the_reference_fixture():
+    kw, steps = load_ghm_sequence()
+    state = dict(det=R.new_ghm_state(), end=R.new_ghm_state())
+    for st in steps:
+        ins = st['ins']
+        leaf = lambda x: x.clone().requires_grad_(True)
+        det, new, end, link = leaf(ins['det']), leaf(ins['new']), leaf(ins['end']), leaf(ins['links'][0])
+        loss = R.tracking_loss(st['counts'], ins['gt_det'], ins['gt_link'], ins['gt_new'], ins['gt_end'], det, [link], new, end,
+                               [x.clone() for x in ins['trans']], ghm_state=state, **kw)
+        loss.backward()
+        assert abs(loss.item() - st['loss']) < 1e-6
+        for got, key in ((det, 'det'), (new, 'new'), (end, 'end'), (link, 'link')):
+            assert (got.grad - st['grads'][key]).abs().max().item() < 1e-7
+        for which in ('det', 'end'):
+            assert (torch.tensor(state[which], dtype=torch.float64) - st['acc'][which]).abs().max().item() < 1e-12
+
+
 # ---- the training-mode forward and its gradients against the IMPORTED reference's training step ----
 from common import compare_train_step, load_train_case, train_case_names  # noqa: E402
 from mmmot_amd.weights import generate_state_dict  # noqa: E402

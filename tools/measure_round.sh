@@ -7,7 +7,8 @@ R=$PWD
 O=$R/gpurun_out/$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-Q="--cpu-pairs 0 --extra-trunks none --no-latency --no-workloads"
+# (--no-profile: the rocprof passes count exactly warm-up + timed steps; extra.kernels comes from the default run above)
+Q="--cpu-pairs 0 --extra-trunks none --no-latency --no-workloads --no-profile"
 # the driver's command line (defaults: cfg3, 16 pairs/step, f16x3; extra: f16q8, hipGraph, the other BASELINE configs, RCCL, latency)
 timeout 600 python $R/bench.py --steps 20 --warmup 5 > $O/bench_default.log 2>&1
 # kernel tables: the headline workload and the other BASELINE configs at their batch sizes
@@ -20,7 +21,7 @@ stats() {  # name, bench arguments
 stats cfg3_pairs16_f16x3
 stats cfg2_b32_f16x3 --workload cfg2 --pairs 32
 stats cfg4_b32_f16x3 --workload cfg4 --pairs 32
-stats cfg5_lidar_b8_f16x3 --rows 1 --pairs 8
+stats cfg5_lidar_b32_f16x3 --rows 1 --pairs 32
 stats cfg5_image_b8_f16x3 --rows 0 --pairs 8
 # counter passes (3 steps each): HBM traffic of every config, matrix-core busy cycles of the headline one
 pmc() {  # name, counters, bench arguments
@@ -41,6 +42,10 @@ pmc SQ_VALU_MFMA_BUSY_CYCLES_cfg4_pairs2_f16x3 "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GU
 rm -rf /tmp/prof_lat
 timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/prof_lat -- python $R/bench.py --latency-only > $O/rocprof_latency_run.log 2>&1
 python $R/tools/rocpd_summary.py stats $(find /tmp/prof_lat -name "*_results.db" | head -1) > $O/rocprofv3_kernel_stats_latency_b1.txt 2>&1
+# kernel table of the whole-network training step (cfg1 shape) at HEAD
+rm -rf /tmp/prof_train
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_train -- python $R/tools/profile_train_step.py --whole > $O/rocprof_train_run.log 2>&1
+python $R/tools/rocpd_summary.py stats $(find /tmp/prof_train -name "*_results.db" | head -1) > $O/rocprofv3_kernel_stats_train.txt 2>&1
 timeout 300 python $R/tools/bench_backward.py > $O/bench_backward.log 2>&1
 timeout 300 python $R/tools/bench_train.py > $O/bench_train.log 2>&1
 timeout 300 python $R/tools/bench_conv_small_maps.py > $O/conv_small_maps_ab.log 2>&1
