@@ -206,8 +206,13 @@ def load():
                     'libmmmot_hip.so is not built (%s). Run `python -c "import __graft_entry__ as g; '
                     'g.build()"`. There is no CPU fallback for the HIP path.' % LIB_PATH)
             lib = ctypes.CDLL(LIB_PATH)
+            # MMMOT_LIB_ALLOW_MISSING=1 (tools/ab_forward.py only: an OLDER build of the library beside the current one)
+            # tolerates entry points the other build does not have yet; the product never sets it
+            lenient = os.environ.get('MMMOT_LIB_ALLOW_MISSING', '0') == '1'
             for name, argtypes in SIGNATURES.items():
-                fn = getattr(lib, name)  # AttributeError if the symbol is missing
+                fn = getattr(lib, name, None) if lenient else getattr(lib, name)  # AttributeError if the symbol is missing
+                if fn is None:
+                    continue
                 fn.argtypes = argtypes
                 fn.restype = c_i
             for name, argtypes in DEBUG_SIGNATURES.items():  # present in -DMMMOT_DEBUG builds only

@@ -57,16 +57,52 @@ class _PlanAux:
         self._tsum = {}
 
     def tile_sums(self, tiles, device):
-        """(per-group, total) Segments that sum the [T][2][C] partials of a tiling, viewed as [2T][C] rows."""
+        """(per-group, total) segment tables that sum the [T][2][C] partials of a tiling, viewed as [2T][C] rows.  Each is
+        a Segments, or - long segments - a two-level (chunks, chunk sums) pair for _segsum: one segment is one workgroup,
+        and the 8 624 tiles of a full-resolution trunk layer walked by two workgroups were the 0.9 ms launches of the
+        training step's kernel table (profiles/r05/rocprofv3_kernel_stats_train.txt)."""
         key = id(tiles)
         if key not in self._tsum:
             G = tiles.G
             start = np.stack([2 * tiles.h_g_tile0, 2 * tiles.h_g_tile0 + 1], 1).reshape(-1)
             count = np.repeat(tiles.h_g_ntiles, 2)
-            grp = Segments(start, count, np.full(2 * G, 2), np.zeros(2 * G), device, div=np.ones(2 * G))
-            tot = Segments([0, 1], [tiles.T, tiles.T], [2, 2], [0, 0], device, div=[1, 1])
+            grp = _chunked_segments(start, count, 2, device)
+            tot = _chunked_segments(np.array([0, 1]), np.array([tiles.T, tiles.T]), 2, device)
             self._tsum[key] = (grp, tot)
         return self._tsum[key]
+
+
+SEGSUM_CHUNK = 128  # rows per first-level segment of a long strided sum
+
+
+def _chunked_segments(start, count, stride, device):
+    """sum (divisor 1) of `count[i]` rows from `start[i]` with `stride`: one Segments, or - any segment longer than
+    4 * SEGSUM_CHUNK rows - (first level: SEGSUM_CHUNK-row chunks of every segment, second level: a segment's chunk sums)"""
+    start, count = np.asarray(start, np.int64), np.asarray(count, np.int64)
+    n = len(start)
+    if n == 0 or count.max() <= 4 * SEGSUM_CHUNK:
+        return Segments(start, count, np.full(n, stride), np.zeros(n), device, div=np.ones(n))
+    nch = -(-count // SEGSUM_CHUNK)
+    s1, c1 = [], []
+    for i in range(n):
+        k = np.arange(nch[i])
+        s1.append(start[i] + stride * SEGSUM_CHUNK * k)
+        c1.append(np.minimum(SEGSUM_CHUNK, count[i] - SEGSUM_CHUNK * k))
+    s1, c1 = np.concatenate(s1), np.concatenate(c1)
+    first = Segments(s1, c1, np.full(len(s1), stride), np.zeros(len(s1)), device, div=np.ones(len(s1)))
+    off = np.concatenate([[0], np.cumsum(nch)[:-1]])
+    second = Segments(off, nch, np.ones(n), np.zeros(n), device, div=np.ones(n))
+    return (first, second)
+
+
+def _segsum(eng, X, C, segs, out):
+    """segment sums through mmmot_segment_mean (divisor 1); `segs`: a Segments or a two-level pair of _chunked_segments"""
+    if isinstance(segs, tuple):
+        part = torch.empty(segs[0].n, C, dtype=torch.float32, device=X.device)
+        eng.ops.segment_mean(X, C, segs[0], part, use_group=False)
+        eng.ops.segment_mean(part, C, segs[1], out, use_group=False)
+    else:
+        eng.ops.segment_mean(X, C, segs, out, use_group=False)
 
 
 def _aux(plan):
@@ -180,17 +216,37 @@ def affinity_forward_train(eng, plan, F):
     return link, ne[0], ne[1], t
 
 
+COLSUM_CHUNK = 2048  # rows per first-level segment of _colsum
+
+
 def _colsum(eng, X):
-    """column sums of a [rows][C] tensor (C % 4 == 0) through the strided-mean kernel with divisor 1"""
-    cache = eng.__dict__.setdefault('_colsum_segs', {})  # the one-segment table per row count: 5 small uploads saved per call
-    key = (int(X.shape[0]), str(X.device))
+    """column sums of a [rows][C] tensor (C % 4 == 0) through the strided-mean kernel with divisor 1.  One segment = one
+    workgroup per 256 channels: a single segment over the 1.1 M rows of a trunk layer's gradient walked 283 MB on ONE
+    workgroup (0.9 ms per call, a fifth of the kernel time of a training step: profiles/r05/rocprofv3_kernel_stats_train.txt),
+    so tall tensors are summed in two levels - COLSUM_CHUNK-row chunks, then the chunk sums."""
+    rows, C = int(X.shape[0]), int(X.shape[1])
+    cache = eng.__dict__.setdefault('_colsum_segs', {})  # the segment tables per row count: small uploads saved per call
+    key = (rows, str(X.device))
     seg = cache.get(key)
     if seg is None:
         if len(cache) > 256:
             cache.clear()
-        seg = cache[key] = Segments([0], [X.shape[0]], [1], [0], X.device, div=[1])
-    out = torch.empty(1, X.shape[1], dtype=torch.float32, device=X.device)
-    eng.ops.segment_mean(X, X.shape[1], seg, out, use_group=False)
+        if rows > 4 * COLSUM_CHUNK:
+            n = -(-rows // COLSUM_CHUNK)
+            start = [i * COLSUM_CHUNK for i in range(n)]
+            count = [min(COLSUM_CHUNK, rows - st) for st in start]
+            seg = (Segments(start, count, [1] * n, [0] * n, X.device, div=[1] * n),
+                   Segments([0], [n], [1], [0], X.device, div=[1]))
+        else:
+            seg = (Segments([0], [rows], [1], [0], X.device, div=[1]), None)
+        cache[key] = seg
+    out = torch.empty(1, C, dtype=torch.float32, device=X.device)
+    if seg[1] is None:
+        eng.ops.segment_mean(X, C, seg[0], out, use_group=False)
+    else:
+        part = torch.empty(seg[0].n, C, dtype=torch.float32, device=X.device)
+        eng.ops.segment_mean(X, C, seg[0], part, use_group=False)
+        eng.ops.segment_mean(part, C, seg[1], out, use_group=False)
     return out[0]
 
 
@@ -204,8 +260,8 @@ def _gn_backward(eng, plan, L, dA, out=None, relu=True):
     S = torch.empty(tiles.G * 2, C, dtype=torch.float32, device=dev)
     tot = torch.empty(2, C, dtype=torch.float32, device=dev)
     P2 = P.view(2 * tiles.T, C)
-    ops.segment_mean(P2, C, seg_g, S, use_group=False)
-    ops.segment_mean(P2, C, seg_t, tot, use_group=False)
+    _segsum(eng, P2, C, seg_g, S)
+    _segsum(eng, P2, C, seg_t, tot)
     M = torch.empty(tiles.G, 2, C, dtype=torch.float32, device=dev)
     ops.gn_bwd_finalize(S, tiles, C, L.NG, L.gamma, M)
     dY = out if out is not None else torch.empty(tiles.R, C, dtype=torch.float32, device=dev)

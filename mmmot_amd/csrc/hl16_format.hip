@@ -103,7 +103,11 @@ extern "C" int mmmot_hl16_pack_pow2(const float* x, void* y, long n, const float
 
 __global__ void pow2_oscale_kernel(float* __restrict__ out, int C, const float* __restrict__ amax_a, int target_a,
                                    const float* __restrict__ amax_b, int target_b) {
-  const float v = ldexpf(1.f, -(hl_pow2_shift(amax_a, target_a) + hl_pow2_shift(amax_b, target_b)));
+  // (each exponent is clamped to +-100 for degenerate maxima, mm_pow2_shift; their sum to +-126 so that the inverse scale
+  // of two clamped operands stays a finite normal float - with such maxima exactness is moot, finiteness is not)
+  int ex = -(hl_pow2_shift(amax_a, target_a) + hl_pow2_shift(amax_b, target_b));
+  ex = ex < -126 ? -126 : (ex > 126 ? 126 : ex);
+  const float v = ldexpf(1.f, ex);
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) out[c] = v;
 }
 

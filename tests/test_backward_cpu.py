@@ -190,3 +190,26 @@ def test_refresh_head_repacks_only_the_head():
     wa = eng.P['w_link']['wa']
     assert torch.allclose(wa[512:], wa_before[512:] * 1.5) and torch.equal(wa[:512], wa_before[:512])
     assert 'wa_h16' in eng.P['w_link']  # the fp16-split copies are rebuilt too
+
+
+def test_two_level_segment_sums_equal_the_direct_sums():
+    """long strided sums (the per-tile partials of a full-resolution trunk layer: thousands of rows per segment) are
+    summed in two levels - chunks, then chunk sums; short ones keep their single table"""
+    import numpy as np
+    from mmmot_amd.backward import SEGSUM_CHUNK, _chunked_segments, _colsum, _segsum
+    c, base = get_case('s2_C_multiply_none')
+    eng = build_model(c, base, ops=TorchOps(torch.float64)).engine()
+    g = torch.Generator().manual_seed(5)
+    T, C = 5 * SEGSUM_CHUNK + 37, 8
+    X = torch.randn(2 * T + 6, C, generator=g, dtype=torch.float64).float()
+    segs = _chunked_segments(np.array([0, 1, 2 * T]), np.array([T, T, 3]), 2, 'cpu')
+    assert isinstance(segs, tuple) and segs[0].n == 2 * 6 + 1 and segs[1].n == 3
+    out = torch.zeros(3, C)
+    _segsum(eng, X, C, segs, out)
+    want = torch.stack([X[0:2 * T:2].double().sum(0), X[1:2 * T:2].double().sum(0), X[2 * T:2 * T + 6:2].double().sum(0)])
+    assert (out.double() - want).abs().max().item() < 1e-4
+    short = _chunked_segments(np.array([0, 1]), np.array([40, 40]), 2, 'cpu')
+    assert not isinstance(short, tuple)
+    tall = torch.randn(9000, C, generator=g)
+    assert (_colsum(eng, tall).double() - tall.double().sum(0)).abs().max().item() < 1e-3
+    assert isinstance(eng._colsum_segs[(9000, 'cpu')], tuple) and eng._colsum_segs[(9000, 'cpu')][1] is not None

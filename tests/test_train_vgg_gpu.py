@@ -75,9 +75,8 @@ def test_device_side_scales_survive_degenerate_maxima(hip, amax):
     hip.pow2_oscale(osc, am, 11, am, 14)
     from mmmot_amd.pack import from_hl16
     back = from_hl16(y16.cpu())
-    # (two clamped exponents of +100 give an inverse scale of 2^-200 = 0 in fp32: a denormal maximum's products vanish -
-    # finite, which is the point; no 2^(+-huge) = inf, no 0 * inf = NaN)
-    assert torch.isfinite(back).all() and torch.isfinite(osc).all() and (osc >= 0).all()
+    # (every exponent is clamped to +-100 and the sum of two to +-126: no 2^(+-huge) = inf, no 0 * inf = NaN)
+    assert torch.isfinite(back).all() and torch.isfinite(osc).all() and (osc > 0).all()
     # whatever scale was chosen, unscaling by the vector's factor for ONE operand gives the input back (fp16-split accuracy)
     one = torch.empty(64, device=DEV)
     hip.pow2_oscale(one, am, 11, None, 0)
