@@ -821,14 +821,19 @@ def main():
             leg['whole_step_frac_of_f16x3_peak'] = round(fexec * value / 1e12 / world / (PEAK_F16_MFMA_TFLOPS / 3.0), 4)
         leg['inputs'] = '%d sets x %d pairs rotated over the steps, %.0f MiB resident' % (len(sets), wl['B'], wl['input_mb'])
         leg['telemetry'] = tele  # this rank's sustained shader clock / package power over the timed steps (hwmon)
-        if profile and not graph and rank == 0:
-            # per-launch-class device time of PROFILE_STEPS extra (untimed) steps: HIP events around every operator call
+        if profile and not graph:
+            # per-launch-class device time of PROFILE_STEPS extra (untimed) steps: HIP events around every operator call.
+            # EVERY rank runs them (a step of an N-rank run contains the result gather, a collective: a rank that took
+            # more steps than the others would hang the job); rank 0's table is the one reported
             from mmmot_amd.profiler import LaunchProfiler
             phase(PROFILE_STEPS)
             with LaunchProfiler(eng.ops, f32=(trunk == 'f32')) as prof:
                 for _ in range(PROFILE_STEPS):
                     step()
-            leg['kernels'] = prof.summary(steps=PROFILE_STEPS, top=24)
+            if rank == 0:
+                leg['kernels'] = prof.summary(steps=PROFILE_STEPS, top=24)
+            else:
+                torch.cuda.synchronize()
         if dist_on:
             # every rank's own wall time per step and the device time of its result gather (pack + RCCL all_gather +
             # unpack, HIP events): `value` uses the MAX over ranks; this shows which rank and which part set it
