@@ -12,7 +12,8 @@ matrix cores): per layer ``mmmot_conv3x3_raw`` -> ``mmmot_rows_stats`` + ``mmmot
 the per-channel GroupNorm with one group) -> ``mmmot_bn_relu_pool``; backward ``mmmot_maxpool_bwd`` -> the GroupNorm
 backward kernels of csrc/backward.hip -> ``mmmot_conv3x3_wgrad`` (dW) and ``mmmot_conv3x3_raw`` on the flipped / transposed
 weights (dX).  Everything numeric is in libmmmot_hip.so; torch permutes weights (data movement) and keeps the graph.
-DropBlock (``dropblock`` > 0, random; every shipped config sets 0) is not built.
+DropBlock (``dropblock`` > 0; every shipped config sets 0): the seed masks are drawn on the host like the reference's, the
+scaling of the stage outputs and of their gradients runs on the device (_dropblock_scale).
 """
 import numpy as np
 import torch
@@ -33,6 +34,13 @@ def _tiles(cache, rows, dev, each=None):
     key = (rows, each)
     if key not in cache:
         cache[key] = RowTiles([1] * rows if each else [rows], dev)
+    return cache[key]
+
+
+def _ident_rows(cache, n, dev):
+    key = ('ident', n)
+    if key not in cache:
+        cache[key] = torch.arange(n, dtype=torch.int32, device=dev)
     return cache[key]
 
 
@@ -89,8 +97,7 @@ def appearance_forward_train(eng, model, plan, crops, P):
     new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
     if plan.B != 1:
         raise NotImplementedError('training-mode trunk: one sample per call (BatchNorm2d statistics are those of the forward)')
-    if getattr(model.appearance, 'dropblock', 0):
-        raise NotImplementedError('DropBlock (appearance dropblock > 0) is not built; the shipped configs set dropblock: 0')
+    dropblock = int(getattr(model.appearance, 'dropblock', 0) or 0)  # block size; stages 2 / 3 (appear_net.py:143-152)
     cache = plan.__dict__.setdefault('_vgg_train_tiles', {})
     f16 = _f16_convs(ops)
     feats = new(L, 512)
@@ -132,12 +139,35 @@ def appearance_forward_train(eng, model, plan, crops, P):
                                    last=last, cidx=cidx, bn=bn, rows=rows, amw=amw))
         x, H, W, first = A, Ho, Wo, False
         if last:
-            tape['heads'].append(_head_forward(eng, plan, cache, s, x, H * W, cout, P, feats))
+            tape['heads'].append(_head_forward(eng, plan, cache, s, x, H * W, cout, P, feats,
+                                               drop=_dropblock_scale(L, H, W, dropblock, dev) if (dropblock and s >= 2) else None))
     return feats, tape
 
 
-def _head_forward(eng, plan, cache, s, x, hw, C, P, feats):
-    """SkipPool (appear_net.py:9-32) of stage s on its output x [L * hw][C] -> feats[:, 128 s : 128 (s + 1)], with tape"""
+DROPBLOCK_PROB = 0.1  # reference modules/dropblock.py:22: DropBlock2D's default (appear_net.py:18 passes the block size only)
+
+
+def _dropblock_scale(L, H, W, block_size, dev):
+    """DropBlock2D.forward in training mode (reference modules/dropblock.py:28-68) as ONE factor per (crop, pixel) row:
+    block_mask * numel / sum.  The Bernoulli seed mask is drawn on the HOST with the global torch generator, exactly like
+    the reference (`torch.rand(N, H, W)` then `.to(device)`): under the same `torch.manual_seed` and the same order of
+    draws (stage 2, then stage 3) the masks ARE the reference's.  The block growth (a max pool over L x H x W <= a few
+    thousand values) is mask bookkeeping, done where the mask is drawn; the tensor work - scaling the stage output before
+    the average pool and its gradient behind it - runs on the device (mmmot_rows_gather_scale)."""
+    import torch.nn.functional as Fn
+    gamma = DROPBLOCK_PROB / (block_size ** 2)
+    mask = (torch.rand(L, H, W) < gamma).float()
+    bm = Fn.max_pool2d(mask[:, None], kernel_size=(block_size, block_size), stride=(1, 1), padding=block_size // 2)
+    if block_size % 2 == 0:
+        bm = bm[:, :, :-1, :-1]
+    bm = 1 - bm.squeeze(1)
+    scale = bm * (bm.numel() / bm.sum())   # out = x * block_mask * numel / sum (dropblock.py:50-53), same fp32 operations
+    return scale.reshape(-1).contiguous().to(dev)
+
+
+def _head_forward(eng, plan, cache, s, x, hw, C, P, feats, drop=None):
+    """SkipPool (appear_net.py:9-32) of stage s on its output x [L * hw][C] -> feats[:, 128 s : 128 (s + 1)], with tape.
+    ``drop``: the DropBlock factor per pixel row (_dropblock_scale), applied in front of the average pool."""
     ops, L = eng.ops, plan.Lt
     dev = x.device
     new = lambda *s_: torch.empty(*s_, dtype=torch.float32, device=dev)
@@ -148,6 +178,11 @@ def _head_forward(eng, plan, cache, s, x, hw, C, P, feats):
         cache[key] = Segments(np.arange(L) * hw, np.full(L, hw), np.ones(L), np.zeros(L), dev)
     seg = cache[key]
     Pm = new(L, C)
+    if drop is not None:                                        # x * block_mask * numel / sum (dropblock.py:50-53)
+        ident = _ident_rows(cache, L * hw, dev)
+        xd = new(L * hw, C)
+        ops.rows_gather_scale(x, ident, drop, xd, C)
+        x = xd
     ops.segment_mean(x, C, seg, Pm, use_group=False)           # AdaptiveAvgPool2d(1)
     part = new(T1.T, 2, C)
     ops.rows_stats(Pm, C, T1, part)
@@ -164,7 +199,7 @@ def _head_forward(eng, plan, cache, s, x, hw, C, P, feats):
     ops.gemm(w4, T1, 128, C4, X=h1, bias=P[pre + '4.bias'], Y=h2, part=part, sc=L2.sc, sh=L2.sh, amode=A_NORM_RELU)
     L5 = _norm_layer(eng, part, T1, h2, 128, 1, P[pre + '5.weight'], P[pre + '5.bias'])
     ops.affine_act(h2, 128, L5.sc, L5.sh, T1, ACT_RELU, feats[:, 128 * s:128 * (s + 1)])
-    return dict(L0=L0, L2=L2, L5=L5, x0=x0, w1=w1, w4=w4, C=C, C4=C4, hw=hw, T1=T1, stage=s)
+    return dict(L0=L0, L2=L2, L5=L5, x0=x0, w1=w1, w4=w4, C=C, C4=C4, hw=hw, T1=T1, stage=s, drop=drop)
 
 
 def _head_backward(eng, plan, hd, dOut, g):
@@ -208,6 +243,11 @@ def appearance_backward(eng, model, plan, crops, tape, dF):
             scale = torch.full((L,), 1.0 / hw, dtype=torch.float32, device=dev)
             dpool = new(L * hw, cout)
             ops.rows_gather_scale(dP, rowidx, scale, dpool, cout)     # backward of AdaptiveAvgPool2d(1)
+            if hd.get('drop') is not None:                            # ... and of the DropBlock factor in front of it
+                cache = plan.__dict__.setdefault('_vgg_train_tiles', {})
+                dd = new(L * hw, cout)
+                ops.rows_gather_scale(dpool, _ident_rows(cache, L * hw, dev), hd['drop'], dd, cout)
+                dpool = dd
             if dA is None:
                 dA = dpool
             else:

@@ -44,6 +44,11 @@ CASES = [
     dict(name='train_s2_A_subabs', fusion='A', aff='minus_abs', sm='dual_add', N=6, M=5, S=64, pts=60, seed=1021, gt_seed=42),
     dict(name='train_s5_3frames_B', fusion='B', aff='multiply', sm='dual_add', counts=[3, 4, 2], S=32, pts=20, seed=1005,
          gt_seed=43),
+    # DropBlock in the SkipPools of stages 2 / 3 (appear_net.py:17-18,28-29,143-152; modules/dropblock.py): block size 5,
+    # drop probability 0.1; the seed masks are drawn on the HOST with the global torch generator - `rng_seed` is set right
+    # before the forward, so whoever draws in the same order (stage 2, then stage 3) sees the same masks
+    dict(name='train_s9_dropblock_C', fusion='C', aff='multiply', sm='none', N=7, M=6, S=96, pts=30, seed=1031, gt_seed=44,
+         dropblock=5, rng_seed=61),
 ]
 
 # element-wise gradient checks: key -> slice of the leading dimension (None = the whole tensor)
@@ -92,7 +97,8 @@ def main():
     worst = {}
     for c in CASES:
         counts = c.get('counts', [c.get('N'), c.get('M')])
-        kw = dict(BASE, score_fusion_arch=c['fusion'], affinity_op=c['aff'], softmax_mode=c['sm'], seq_len=len(counts))
+        kw = dict(BASE, score_fusion_arch=c['fusion'], affinity_op=c['aff'], softmax_mode=c['sm'], seq_len=len(counts),
+                  dropblock=c.get('dropblock', 0))
         with contextlib.redirect_stdout(io.StringIO()):
             model = ref_modules.TrackingNet(**kw)
             crit = ref_cost.TrackingLoss(**LOSS_KW)
@@ -101,6 +107,12 @@ def main():
         model.train()
         dets, info, dsplit = case_inputs(c)
         gts = make_gts(counts, c['gt_seed'])
+        if 'rng_seed' in c:
+            torch.manual_seed(c['rng_seed'])
+            if c.get('dropblock'):  # the fixture must exercise the layer: at least one dropped block in each of the two stages
+                probe = [float((torch.rand(sum(counts), c['S'] // d, c['S'] // d) < 0.1 / c['dropblock'] ** 2).sum()) for d in (16, 32)]
+                assert min(probe) >= 1, ('rng_seed %d drops nothing in one stage: %r' % (c['rng_seed'], probe))
+            torch.manual_seed(c['rng_seed'])
         det, links, new, end, trans = model(dets, info, dsplit)
         with uint8_eq():
             loss = crit(dsplit, gts[0], gts[1], gts[2], gts[3], det, links, new, end, trans)
@@ -113,8 +125,11 @@ def main():
                   else v.clone()) for k, v in sd0.items()}
         cfg = dict(fusion=c['fusion'], affinity_op=c['aff'], softmax_mode=c['sm'])
         stats = {}
+        if 'rng_seed' in c:
+            torch.manual_seed(c['rng_seed'])
         o_det, o_links, o_new, o_end, o_trans = R.tracking_forward_train(
-            sd, cfg, None, info['points'], info['points_split'], [int(d) for d in dsplit], crops=dets, bn_stats=stats)
+            sd, cfg, None, info['points'], info['points_split'], [int(d) for d in dsplit], crops=dets, bn_stats=stats,
+            dropblock=c.get('dropblock', 0))
         o_loss = R.tracking_loss(counts, gts[0], gts[1], gts[2], gts[3], o_det, o_links, o_new, o_end, o_trans, **LOSS_KW)
         o_loss.backward()
         e = dict(det=(det - o_det).abs().max().item(), new=(new - o_new).abs().max().item(),

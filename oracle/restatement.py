@@ -72,9 +72,29 @@ def vgg_stage(x, sd, stage, training=False, bn_stats=None):
     return x
 
 
-def skippool(x, sd, stage):
-    """reference modules/appear_net.py:9-32: global avg pool -> GN(1) -> 1x1 -> GN(1) -> ReLU -> 1x1 -> GN(1) -> ReLU."""
+DROPBLOCK_PROB = 0.1  # reference modules/dropblock.py:22 (DropBlock2D's default; appear_net.py:18 passes the size only)
+
+
+def dropblock2d(x, block_size, drop_prob=DROPBLOCK_PROB):
+    """reference modules/dropblock.py:28-68 (DropBlock2D.forward in training mode): a Bernoulli(gamma) seed mask per
+    (sample, pixel) - drawn on the HOST with the global torch generator, like the reference (`torch.rand(...)` then
+    `.to(x.device)`) -, grown to block_size x block_size blocks by a max pool, the kept pixels rescaled by numel / sum."""
+    gamma = drop_prob / (block_size ** 2)
+    mask = (torch.rand(x.shape[0], *x.shape[2:]) < gamma).float().to(x.device)
+    bm = F.max_pool2d(mask[:, None, :, :], kernel_size=(block_size, block_size), stride=(1, 1), padding=block_size // 2)
+    if block_size % 2 == 0:
+        bm = bm[:, :, :-1, :-1]
+    bm = 1 - bm.squeeze(1)
+    out = x * bm[:, None, :, :]
+    return out * bm.numel() / bm.sum()
+
+
+def skippool(x, sd, stage, dropblock=0):
+    """reference modules/appear_net.py:9-32: (DropBlock, training mode, stages whose SkipPool got a block size) ->
+    global avg pool -> GN(1) -> 1x1 -> GN(1) -> ReLU -> 1x1 -> GN(1) -> ReLU."""
     p = 'appearance.global_pool.%d.fc.' % stage
+    if dropblock:
+        x = dropblock2d(x, dropblock)
     o = F.adaptive_avg_pool2d(x, 1)
     o = _gn(o, sd, p + '0', 1)
     o = F.conv2d(o, sd[p + '1.weight'], sd[p + '1.bias'])
@@ -84,15 +104,17 @@ def skippool(x, sd, stage):
     return o.flatten(1)
 
 
-def appearance(crops, sd, keep=None, training=False, bn_stats=None):
-    """reference modules/appear_net.py:166-190 (vgg + skippool path): L x 3 x S x S -> L x 512."""
+def appearance(crops, sd, keep=None, training=False, bn_stats=None, dropblock=0):
+    """reference modules/appear_net.py:166-190 (vgg + skippool path): L x 3 x S x S -> L x 512.  ``dropblock`` (the
+    block size, training mode only): `_parse_vgg_layers` (appear_net.py:130-157) hands it to the SkipPools made after the
+    fourth and fifth max pool - stages 2 and 3; the first two stages get block size 0 = no DropBlock."""
     outs = []
     x = crops
     for s in range(4):
         x = vgg_stage(x, sd, s, training, bn_stats)
         if keep is not None:
             keep['vgg_stage%d' % s] = x
-        outs.append(skippool(x, sd, s))
+        outs.append(skippool(x, sd, s, dropblock if (training and s >= 2) else 0))
     return torch.cat(outs, dim=-1)
 
 
@@ -271,7 +293,7 @@ def det_head_train(feats, sd, bn_stats=None):
     return F.conv1d(x, sd['w_det.6.weight'], sd['w_det.6.bias']).squeeze(1)
 
 
-def tracking_forward_train(sd, cfg, img_feats, points, points_split, dets_split, crops=None, bn_stats=None):
+def tracking_forward_train(sd, cfg, img_feats, points, points_split, dets_split, crops=None, bn_stats=None, dropblock=0):
     """Training-mode ``TrackingNet.forward`` (reference modules/tracking_net.py:165-193 with ``self.training``): image
     encoder in training mode on ``crops`` (batch-statistics BatchNorm2d), or - ``crops`` None - GIVEN image features
     ``img_feats`` L x 512 (the product's frozen-image-branch mode); PointNet (GroupNorm only: identical in both modes),
@@ -279,7 +301,7 @@ def tracking_forward_train(sd, cfg, img_feats, points, points_split, dets_split,
     ``bn_stats`` (a dict): receives the BatchNorm buffers (trunk and w_det) as the modules hold them after this forward.
     Pinned to the imported reference's training step by oracle/gen_golden_train.py (tests/golden/train_*.npz)."""
     if crops is not None:
-        img_feats = appearance(crops, sd, training=True, bn_stats=bn_stats)
+        img_feats = appearance(crops, sd, training=True, bn_stats=bn_stats, dropblock=dropblock)
     split = points_split.reshape(-1).long()
     pts, trans = pointnet(points.transpose(-1, -2), split, sd)
     cat = torch.cat([img_feats, pts], dim=-1).t().unsqueeze(0)

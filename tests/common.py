@@ -49,6 +49,8 @@ def case_kwargs(c, base):
               end_mode=c.get('end_mode', base.get('end_mode', 'avg')))
     if c.get('refl'):
         kw['without_reflectivity'] = False
+    if 'dropblock' in c:
+        kw['dropblock'] = c['dropblock']
     if 'counts' in c:
         kw['seq_len'] = len(c['counts'])
     return kw

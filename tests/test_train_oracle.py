@@ -105,8 +105,10 @@ def test_oracle_training_step_matches_the_reference_fixture(name):
               and 'running_' not in k else v.detach().clone()) for k, v in m.state_dict().items()}
     cfg = dict(fusion=c['fusion'], affinity_op=c['aff'], softmax_mode=c['sm'])
     stats = {}
+    if 'rng_seed' in c:  # DropBlock fixtures: the seed masks come from the global host generator, like the reference's
+        torch.manual_seed(c['rng_seed'])
     det, links, new, end, trans = R.tracking_forward_train(sd, cfg, None, info['points'], info['points_split'], counts,
-                                                           crops=dets, bn_stats=stats)
+                                                           crops=dets, bn_stats=stats, dropblock=c.get('dropblock', 0))
     loss = R.tracking_loss(counts, gts[0], gts[1], gts[2], gts[3], det, links, new, end, trans, **kw)
     loss.backward()
     worst = compare_train_step(g, (det, links, new, end, trans), loss.item(),

@@ -131,6 +131,8 @@ def product_train_step(name, device='cpu', ops=None):
         m.set_trunk('f32')
         crit.ops = ops
     to = lambda x: [t.to(device) for t in x] if isinstance(x, list) else x.to(device)
+    if 'rng_seed' in c:  # DropBlock fixtures: the seed masks come from the global host generator, like the reference's
+        torch.manual_seed(c['rng_seed'])
     det, links, new, end, trans = m(to(dets), {k: to(v) for k, v in info.items()}, ds)
     loss = crit(ds, to(gts[0]), to(gts[1]), to(gts[2]), to(gts[3]), det, links, new, end, trans)
     loss.backward()
