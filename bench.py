@@ -35,9 +35,14 @@ Prints ONE JSON line on rank 0 with the contract fields plus
                  same seed) and of the CPU-baseline pairs against the oracle
   end_to_end   - F_ref / F_exec per pair and the whole-step fraction of the f16x3 ceiling (north_star: >= 0.50)
   extra        - the other arithmetic legs; ``workloads``: the other BASELINE.json configs at their batch sizes
-                 (cfg2 B=32, cfg4 32 pairs/GPU, cfg5 image-only / LiDAR-only rows), each with value, roofline and
-                 parity against its reference golden; ``rccl_world1``: the N-GPU step's collective sequence on a
-                 one-rank nccl group (child process); latency of one reference-shaped call (B=1, cfg1 shape)
+                 (cfg2 B=32, cfg4 32 pairs/GPU, cfg5 image-only 8 / LiDAR-only 32 pairs), each with value, roofline,
+                 parity against its reference golden, clock / power telemetry; ``kernels``: per launch class of every
+                 leg - ms per step, bound (mfma | hbm | latency), achieved TFLOP/s-equivalent or TB/s, fraction of that
+                 peak - from HIP events around every operator call of two extra untimed steps (mmmot_amd/profiler.py);
+                 ``prep``: point-cloud gather sweeps/s and crop-resize detections/s; ``rccl_world1``: the N-GPU step's
+                 collective sequence on a one-rank nccl group (child process); latency of one reference-shaped call
+  host / per_rank - NUMA node and cores the rank bound itself to (sysfs of its GPU), mean shader clock and package power
+                 over the timed steps (hwmon); inputs: three synthetic input sets rotate over the steps (``--input-sets``)
 """
 import argparse
 import json

@@ -1,4 +1,5 @@
 #!/bin/bash
+# round-end GPU pass of round 5 (one gpurun call): full -m gpu suite, tools/measure_round.sh, the --force-dist step, old-vs-new library A/B
 mkdir -p gpurun_out/r05b
 timeout 1200 python -m pytest tests -q -m gpu > gpurun_out/r05b/pytest_gpu_full.log 2>&1
 tail -n 3 gpurun_out/r05b/pytest_gpu_full.log
