@@ -836,7 +836,11 @@ def main():
                 for _ in range(PROFILE_STEPS):
                     step()
             if rank == 0:
-                leg['kernels'] = prof.summary(steps=PROFILE_STEPS, top=24)
+                # compact rows (the JSON line stays one line): [class, launches/step, ms/step, bound, achieved, frac]
+                summ = prof.summary(steps=PROFILE_STEPS, top=24)
+                leg['kernels'] = {'device_ms_per_step': summ['device_ms_per_step'],
+                                  'rows': [[r['class'], r['launches_per_step'], r['ms_per_step'], r['bound'],
+                                            r.get('achieved'), r.get('frac')] for r in summ['classes']]}
             else:
                 torch.cuda.synchronize()
         if dist_on:
@@ -949,12 +953,11 @@ def main():
 
     if rank == 0 and kernels:
         out['extra']['kernels'] = dict(
-            kernels, how='HIP events (torch.cuda.Event on the launch stream) around every operator call of %d untimed steps '
-            'behind each leg\'s timed region (mmmot_amd/profiler.py); per launch class: ms per step, the bound - mfma: '
-            'algorithmic FLOPs against %.0f TFLOP/s-equivalent (f16 MFMA dense peak / 3), hbm: algorithmic bytes against '
-            '%.0f TB/s, latency: under 5 us of roofline time per launch - achieved rate and fraction of that peak; '
-            'device_ms_per_step = their sum (compare ms_per_step of the leg)' % (PROFILE_STEPS, PEAK_F16_MFMA_TFLOPS / 3.0,
-                                                                             8.0))
+            kernels, columns=['launch class', 'launches per step', 'ms per step', 'bound', 'achieved', 'fraction of that peak'],
+            how='HIP events (torch.cuda.Event on the launch stream) around every operator call of %d untimed steps behind each '
+            'leg\'s timed region (mmmot_amd/profiler.py).  bound mfma: achieved = algorithmic TFLOP/s-equivalent against %.0f '
+            '(f16 MFMA dense peak / 3); hbm: algorithmic TB/s against %.0f; latency: under 5 us of roofline time per launch.  '
+            'device_ms_per_step = sum of the rows (compare the leg\'s ms_per_step)' % (PROFILE_STEPS, PEAK_F16_MFMA_TFLOPS / 3.0, 8.0))
     if rank == 0 and world == 1 and do_prof and not args.no_workloads:
         out['extra']['prep'] = prep_leg(dev)
 

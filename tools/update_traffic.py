@@ -58,10 +58,10 @@ def main():
             'fetch_bytes_per_pair': int(round(fetch)),
             'write_bytes_per_pair': int(round(write)),
             'launches_per_step': launches,
-            'source': ('%s (KB per dispatch summed over the kernel\'s launches of 3 steps of %d pair(s), x2: gfx950 FETCH_SIZE reports half '
-                       'of 16 B/lane reads, calibrated in profiles/README.md) + %s; separate --pmc passes of `python bench.py --steps 2 '
-                       '--warmup 1 %s --cpu-pairs 0 --extra-trunks none --no-latency --no-workloads`; traffic scales linearly with '
-                       'pairs/step' % (f, pairs, w, cmd)),
+            # (short: bench.py repeats it in every leg of its one JSON line; the method is in profiles/README.md: FETCH_SIZE x 2
+            # - gfx950 reports half of 16 B/lane reads - + WRITE_SIZE, KB per dispatch summed over the kernel's launches,
+            # separate --pmc passes of `python bench.py --steps 2 --warmup 1 <cmd> ... --no-profile`, linear in pairs/step)
+            'source': '%s x2 + %s (PMC passes at %d pair(s)/step: bench.py %s)' % (f, w, pairs, cmd),
         }
     with open(os.path.join(ROOT, 'profiles', 'traffic.json'), 'w') as fh:
         json.dump(out, fh, indent=1)
