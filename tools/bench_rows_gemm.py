@@ -27,8 +27,6 @@ def main():
     ap.add_argument('--pair', type=int, default=0, help='A_PAIR prologue instead of A_NORM_RELU: groups of M x M pair rows '
                     '(M = this value, a multiple of 32) generated from feature rows F [G * 2M][K]; --rows is rounded to whole groups')
     ap.add_argument('--ldf', type=int, default=0, help='row pitch of F in floats (default K)')
-    ap.add_argument('--wsm', action='store_true', help='also time variant 3: the wide kernel on the stage-major weight copy '
-                    '[K/32][N][32] (experiment: L2 channel spread of the weight stage); checked bitwise against variant 2')
     ap.add_argument('--variants', type=int, nargs='*', default=[1, 2])
     a = ap.parse_args()
     ops = HipOps()
@@ -59,11 +57,13 @@ def main():
         bias = torch.zeros(N).cuda()
         Y = torch.empty(sum(counts), N).cuda()
         part = torch.empty(tiles.T, 2, N).cuda()
-        W16sm = W16.cpu().view(N, K // 32, 32).permute(1, 0, 2).contiguous().cuda()
+        # (round 5 also timed the wide kernel on a stage-major weight copy [K/32][N][32] and on padded row pitches - the
+        # L2-channel-camping experiment, no effect: profiles/r05/exp_gemm_wide_weight_layout_and_pitch.log; that kernel
+        # variant was removed again, --ldx / --ldf still set the pitches)
         ref = None
-        for v in list(a.variants) + ([3] if a.wsm else []):
+        for v in list(a.variants):
             ops.lib.mmmot_set_gemm_rows_variant(v)
-            Wv = W16sm if v == 3 else W16
+            Wv = W16
             ts = []
             for r in range(6):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -83,7 +83,7 @@ def main():
             torch.cuda.synchronize()
             sus = e0.elapsed_time(e1) / max(a.sustain, 1)
             same = ''
-            if v in (2, 3):
+            if v == 2:
                 if ref is None:
                     ref = (Y.clone(), part.clone())
                 else:
