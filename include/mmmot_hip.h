@@ -308,6 +308,17 @@ int mmmot_gn_finalize_gram(const double* Gp, const double* Sp, const int* grp_ti
                            const int* grp_count, int G, int K, const float* W, const float* bias, int N,
                            const float* gamma, const float* beta, float eps, double* work, float* sc,
                            float* sh, void* stream);
+/* ABI 9.  The same route for a layer with a gathered per-detection bias, v[p] = W a[p] + dbias[det(p)]
+ * (PointNet_v1.conv1 after the 1088 -> 512 split, reference modules/point_net.py:26-28): the super-tiles handed to
+ * mmmot_gram_rows (K = 64) are cut along detections - super-tile t lies inside detection tile_det[t] (a row of dbias
+ * [.][lddb]) and holds tile_nrows[t] rows - so that its column sums Sp[t] give the cross term:
+ *   mean = w.m + dbar,  var = w^T Cov w + 2 (sum_t d_t (w.Sp[t]) / P - (w.m) dbar) + (sum_t c_t d_t^2 / P - dbar^2),
+ * dbar = sum_t c_t d_t / P, float64 throughout.  Replaces the statistics pass of mmmot_gemm_ares over every point.
+ * W [N][64] fp32 (unscaled); work: G*(K*K+K) doubles; sc / sh [G][N]. */
+int mmmot_gn_finalize_gram_dbias(const double* Gp, const double* Sp, const int* grp_tile0, const int* grp_ntiles,
+                                 const int* grp_count, int G, const int* tile_nrows, const int* tile_det, int K,
+                                 const float* W, const float* dbias, int lddb, int N, const float* gamma,
+                                 const float* beta, float eps, double* work, float* sc, float* sh, void* stream);
 
 /* GroupNorm statistics -> per-channel scale/shift (fp64 combine).
  * part is [T][2][ldp] = per-tile (sum, tile-centred M2) as written by

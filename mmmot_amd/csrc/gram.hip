@@ -322,3 +322,120 @@ extern "C" int mmmot_gn_finalize_gram(const double* Gp, const double* Sp, const 
                        N, gamma, beta, eps, sc, sh);
   return mm_check(hipGetLastError());
 }
+
+// ---------------------------------------------------------------------------
+// The same route for a layer with a GATHERED PER-DETECTION BIAS: v[p] = W a[p] + d[det(p)]  (PointNet_v1.conv1 after the
+// 1088 -> 512 split, reference modules/point_net.py:26-28: the 1024 broadcast channels became the bias row dbias[det]).
+// With the super-tiles cut along detections (every super-tile t lies inside one detection, tile_det[t]; c_t rows) the
+// per-super-tile column sums S_t of mmmot_gram_rows are all that is needed beside the group's moments:
+//   mean_n = w_n.m + dbar_n,                      dbar_n = sum_t c_t d_tn / P,   m = S / P,   S = sum_t S_t
+//   var_n  = w_n^T Cov w_n + 2 (sum_t d_tn (w_n.S_t) / P - (w_n.m) dbar_n) + (sum_t c_t d_tn^2 / P - dbar_n^2)
+// (covariance of the matrix product, cross covariance with the bias, variance of the bias), all in float64.  It replaces
+// the statistics pass of the 64 -> 512 GEMM over every point (0.87 ms per 4.2 M points) by a pass over the 64-channel
+// input (mmmot_gram_rows, K = 64) and this kernel.  One workgroup per (group, 64 output channels); thread = (channel,
+// quarter): a quarter takes 16 rows of the quadratic form and every fourth super-tile; fixed-order combine.
+template <int K>
+__global__ __launch_bounds__(256) void gn_finalize_gram_dbias_kernel(
+    const double* __restrict__ red, const double* __restrict__ Sp, const int* __restrict__ grp_tile0,
+    const int* __restrict__ grp_ntiles, const int* __restrict__ grp_count, const int* __restrict__ tile_nrows,
+    const int* __restrict__ tile_det, const float* __restrict__ Wm, const float* __restrict__ dbias, int lddb, int N,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float* __restrict__ sc,
+    float* __restrict__ sh) {
+  __shared__ double C[K * K];
+  __shared__ double m[K];
+  __shared__ double part[4][5][64];  // [quarter][quad, w.m, cross, sum c d, sum c d^2][channel]
+  __shared__ double Sl[32 * K];      // column sums of 32 super-tiles
+  const int g = blockIdx.x, n0 = blockIdx.y * 64;
+  const double* R = red + (long)g * (K * K + K);  // covariance and mean of the group (gram_reduce_kernel)
+  for (int k = threadIdx.x; k < K; k += 256) m[k] = R[K * K + k];
+  for (int idx = threadIdx.x; idx < K * K; idx += 256) C[idx] = R[idx];
+  __syncthreads();
+  const int cl = threadIdx.x & 63, qt = threadIdx.x >> 6;
+  const int n = n0 + cl;
+  const bool live = n < N;
+  float w[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) w[k] = live ? Wm[(long)n * K + k] : 0.f;
+  // this quarter's rows of w^T C w and of w . m (four partial sums per row: the float64 FMA chain is what this costs)
+  double quad = 0.0, wm = 0.0;
+  for (int i = qt * (K / 4); i < (qt + 1) * (K / 4); ++i) {
+    double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
+#pragma unroll
+    for (int j = 0; j < K; j += 4) {  // C is symmetric; all lanes read the same elements (LDS broadcast)
+      y0 += C[i * K + j] * (double)w[j];
+      y1 += C[i * K + j + 1] * (double)w[j + 1];
+      y2 += C[i * K + j + 2] * (double)w[j + 2];
+      y3 += C[i * K + j + 3] * (double)w[j + 3];
+    }
+    double wi = 0.0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) wi = (k == i) ? (double)w[k] : wi;  // w[i] without a dynamically indexed register array
+    quad += wi * ((y0 + y1) + (y2 + y3));
+    wm += wi * m[i];
+  }
+  // the group's super-tiles, 32 at a time: their column sums are staged in LDS by the whole workgroup (coalesced; a
+  // thread reading 64 doubles per super-tile straight from global memory made this kernel 0.2 ms), then a quarter takes
+  // every fourth one: cross term and the bias moments
+  double cross = 0.0, sd = 0.0, sd2 = 0.0;
+  const int t0 = grp_tile0[g], nt = grp_ntiles[g];
+  for (int tc = 0; tc < nt; tc += 32) {
+    const int nc = min(32, nt - tc);
+    __syncthreads();  // the previous chunk has been read by everyone
+    for (int idx = threadIdx.x; idx < nc * K; idx += 256) Sl[idx] = Sp[(long)(t0 + tc) * K + idx];
+    __syncthreads();
+    for (int tl = qt; tl < nc; tl += 4) {
+      const int t = t0 + tc + tl;
+      const double c = (double)tile_nrows[t];
+      const double d = live ? (double)dbias[(long)tile_det[t] * lddb + n] : 0.0;
+      const double* S = Sl + tl * K;
+      double u0 = 0.0, u1 = 0.0, u2 = 0.0, u3 = 0.0;
+#pragma unroll
+      for (int k = 0; k < K; k += 4) {
+        u0 += (double)w[k] * S[k];
+        u1 += (double)w[k + 1] * S[k + 1];
+        u2 += (double)w[k + 2] * S[k + 2];
+        u3 += (double)w[k + 3] * S[k + 3];
+      }
+      cross += d * ((u0 + u1) + (u2 + u3));
+      sd += c * d;
+      sd2 += c * d * d;
+    }
+  }
+  part[qt][0][cl] = quad;
+  part[qt][1][cl] = wm;
+  part[qt][2][cl] = cross;
+  part[qt][3][cl] = sd;
+  part[qt][4][cl] = sd2;
+  __syncthreads();
+  if (qt == 0 && live) {
+    double v[5];
+#pragma unroll
+    for (int e = 0; e < 5; ++e) v[e] = (part[0][e][cl] + part[1][e][cl]) + (part[2][e][cl] + part[3][e][cl]);
+    const double P = (double)grp_count[g];
+    const double dbar = v[3] / P;
+    const double mean = v[1] + dbar;
+    double var = v[0] + 2.0 * (v[2] / P - v[1] * dbar) + (v[4] / P - dbar * dbar);
+    var = var > 0.0 ? var : 0.0;
+    const double scv = (double)gamma[n] / sqrt(var + (double)eps);
+    sc[(long)g * N + n] = (float)scv;
+    sh[(long)g * N + n] = (float)((double)beta[n] - mean * scv);
+  }
+}
+
+extern "C" int mmmot_gn_finalize_gram_dbias(const double* Gp, const double* Sp, const int* grp_tile0, const int* grp_ntiles,
+                                            const int* grp_count, int G, const int* tile_nrows, const int* tile_det, int K,
+                                            const float* W, const float* dbias, int lddb, int N, const float* gamma,
+                                            const float* beta, float eps, double* work, float* sc, float* sh,
+                                            void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!Gp || !Sp || !grp_tile0 || !grp_ntiles || !grp_count || !tile_nrows || !tile_det || !W || !dbias || !gamma ||
+      !beta || !work || !sc || !sh)
+    return MMMOT_EINVAL;
+  if (K != 64 || G <= 0 || N <= 0 || lddb < N) return MMMOT_EINVAL;
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3((K * K + K + 255) / 256, G), dim3(256), 0, s, Gp, Sp, grp_tile0,
+                     grp_ntiles, grp_count, K, work);
+  hipLaunchKernelGGL(gn_finalize_gram_dbias_kernel<64>, dim3(G, (N + 63) / 64), dim3(256), 0, s, work, Sp, grp_tile0,
+                     grp_ntiles, grp_count, tile_nrows, tile_det, W, dbias, lddb, N, gamma, beta, eps, sc, sh);
+  return mm_check(hipGetLastError());
+}
+

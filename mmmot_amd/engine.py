@@ -488,10 +488,20 @@ class Engine:
         self._gemm(pn, 'wc1b', D, 512, 1024, X=seg1024, bias=pn['bc1'], Y=dbias)
         seg512 = self.buf('pn_seg512', Lt, 512)
         if ares:
-            part = self._part(TH, 512)
-            ops.gemm_ares(pn['wc1a_h16'], pn['wc1a_os'], TD, 512, 64, y1, sc1, sh1, dbias=dbias,
-                          tile_dbrow=plan.tile_det, part=part)
-            scc, shc = self._finalize('pnc1', part, TH, 512, 512, pn['gc1'], pn['bec1'])
+            if self.pn_gram and hasattr(ops, 'gn_finalize_gram_dbias'):
+                # statistics of v = W a + dbias[det] from the second moments of the 64-channel input a = relu(gn(y1)) over
+                # detection-aligned super-tiles: a pass over 256 B per point instead of the 64 -> 512 GEMM's statistics pass
+                GT = plan.gram64_tiles
+                Gp, Sp = self.buf64('gram64_G', GT.T, 64 * 64), self.buf64('gram64_S', GT.T, 64)
+                ops.gram_rows(y1, 64, sc1, sh1, GT, Gp, Sp)
+                scc, shc = self.buf('pnc1_sc', GT.G, 512), self.buf('pnc1_sh', GT.G, 512)
+                ops.gn_finalize_gram_dbias(Gp, Sp, GT, plan.gram64_tile_det, 64, pn['wc1a'], dbias, 512, pn['gc1'], pn['bec1'],
+                                           EPS, self.buf64('gram64_work', GT.G, 64 * 64 + 64), scc, shc)
+            else:
+                part = self._part(TH, 512)
+                ops.gemm_ares(pn['wc1a_h16'], pn['wc1a_os'], TD, 512, 64, y1, sc1, sh1, dbias=dbias,
+                              tile_dbrow=plan.tile_det, part=part)
+                scc, shc = self._finalize('pnc1', part, TH, 512, 512, pn['gc1'], pn['bec1'])
             cs = self.buf('pn_colsum', TH.T, 512)
             ops.gemm_ares(pn['wc1a_h16'], pn['wc1a_os'], TD, 512, 64, y1, sc1, sh1, dbias=dbias,
                           tile_dbrow=plan.tile_det, osc=scc, osh=shc, colsum=cs)

@@ -280,6 +280,16 @@ class HipOps:
                                              _ptr(work, torch.float64), _ptr(sc), _ptr(sh), self._stream())
         _lib.check(st, 'mmmot_gn_finalize_gram')
 
+    def gn_finalize_gram_dbias(self, Gp, Sp, tiles, tile_det, K, W, dbias, N, gamma, beta, eps, work, sc, sh):
+        """GroupNorm(N, N) scale/shift of v = W a + dbias[det] from the Gram partials of a over detection-aligned
+        super-tiles (tile_det: int32 [T], the dbias row of every super-tile); see mmmot_gn_finalize_gram_dbias."""
+        st = self.lib.mmmot_gn_finalize_gram_dbias(_ptr(Gp, torch.float64), _ptr(Sp, torch.float64), _iptr(tiles.g_tile0),
+                                                   _iptr(tiles.g_ntiles), _iptr(tiles.g_count), tiles.G, _iptr(tiles.nrows),
+                                                   _iptr(tile_det), K, _ptr(W), _ptr(dbias), _ld(dbias), N, _ptr(gamma),
+                                                   _ptr(beta), float(eps), _ptr(work, torch.float64), _ptr(sc), _ptr(sh),
+                                                   self._stream())
+        _lib.check(st, 'mmmot_gn_finalize_gram_dbias')
+
     def gn_finalize(self, part, tiles, C, NG, gamma, beta, eps, sc, sh):
         """part: [T][2][>=C] view (unit inner stride); statistics of its first C channels."""
         if part.dim() != 3 or part.stride(2) != 1 or part.stride(0) != 2 * part.stride(1):

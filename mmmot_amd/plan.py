@@ -209,6 +209,11 @@ class BatchPlan:
             # with - tests/test_parity_gpu.py::test_batched_equals_single_and_is_deterministic)
             gt = [min(4096, max(128, 128 * -(-p_b // (32 * 128)))) for p_b in P_b]
             self.gram_tiles = RowTiles(P_b, device, tile=gt)
+            # the same for PointNet_v1.conv1 (64-channel input, gathered per-detection bias): super-tiles of <= 2048 rows
+            # cut along DETECTIONS, so that a super-tile's column sums belong to one bias row (mmmot_gn_finalize_gram_dbias)
+            gt64 = [min(2048, max(128, 128 * -(-p_b // (32 * 128)))) for p_b in P_b]
+            self.gram64_tiles = RowTiles(P_b, device, sub_counts=per_sample, tile=gt64)
+            up(np.repeat(np.arange(Lt, dtype=np.int64), self.gram64_tiles.h_sub_ntiles), 'gram64_tile_det')
             # 64-row half tiles of ptd_tiles (the A-resident GEMM emits its partials per wave = per half tile)
             self.ptd_half = HalfTiles(self.ptd_tiles, device)
             self.det_half_segs = Segments(2 * self.ptd_tiles.h_sub_tile0, 2 * self.ptd_tiles.h_sub_ntiles,

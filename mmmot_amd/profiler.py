@@ -123,6 +123,7 @@ COSTS = {
     'pn_mlp64': _pn_mlp64,
     'gram_rows': _gram,
     'gn_finalize_gram': _latency('GroupNorm scale/shift from the Gram matrix'),
+    'gn_finalize_gram_dbias': _latency('GroupNorm scale/shift from the Gram matrix'),
     'gn_finalize': _latency('GroupNorm scale/shift from tile partials'),
     'segment_mean': _segment_mean,
     'rowdot': _rowdot,

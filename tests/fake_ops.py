@@ -252,6 +252,28 @@ class TorchOps:
             sc[g, :N] = scv.float()
             sh[g, :N] = (beta[:N].double() - mean * scv).float()
 
+    def gn_finalize_gram_dbias(self, Gp, Sp, tiles, tile_det, K, W, dbias, N, gamma, beta, eps, work, sc, sh):
+        """executable specification of mmmot_gn_finalize_gram_dbias: statistics of v = W a + dbias[det] from the moments"""
+        td = torch.as_tensor(tile_det).long()
+        for g in range(tiles.G):
+            t0, nt, P = int(tiles.h_g_tile0[g]), int(tiles.h_g_ntiles[g]), float(tiles.h_g_count[g])
+            St = Sp[t0:t0 + nt].double()                                   # [nt][K] column sums per super-tile
+            ct = torch.as_tensor(tiles.h_nrows[t0:t0 + nt]).double()       # rows per super-tile
+            D = dbias[td[t0:t0 + nt], :N].double()                         # [nt][N] bias row of every super-tile
+            m = St.sum(0) / P
+            C = Gp[t0:t0 + nt].double().sum(0).view(K, K) / P - torch.outer(m, m)
+            Wd = W[:N, :K].double()
+            wm = Wd @ m
+            dbar = (ct[:, None] * D).sum(0) / P
+            quad = torch.einsum('nk,kl,nl->n', Wd, C, Wd)
+            cross = (D * (St @ Wd.t())).sum(0) / P - wm * dbar
+            vard = (ct[:, None] * D * D).sum(0) / P - dbar * dbar
+            var = (quad + 2.0 * cross + vard).clamp(min=0.0)
+            mean = wm + dbar
+            scv = gamma[:N].double() / torch.sqrt(var + eps)
+            sc[g, :N] = scv.float()
+            sh[g, :N] = (beta[:N].double() - mean * scv).float()
+
     def gn_finalize(self, part, tiles, C, NG, gamma, beta, eps, sc, sh):
         CG = C // NG
         for g in range(tiles.G):

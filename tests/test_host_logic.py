@@ -318,3 +318,33 @@ def test_launch_profiler_classifies_every_forward_launch():
     assert any(r['class'].startswith('A-resident GEMM 128->1024') for r in s['classes'])
     assert any('pair prologue' in r['class'] for r in s['classes'])
     assert sum(r['launches_per_step'] for r in s['classes']) == len(prof.records)
+
+
+def test_gram_route_with_per_detection_bias_specification():
+    """the float64 specification of mmmot_gn_finalize_gram_dbias (tests/fake_ops.py) against direct statistics of
+    v = W relu(gn(x)) + dbias[det] - ragged detections, several super-tiles per detection, two samples"""
+    emu = TorchOps(torch.float64)
+    K, N = 64, 96
+    dets = [[300, 1, 130], [90, 257]]
+    counts = [sum(d) for d in dets]
+    tiles = RowTiles(counts, 'cpu', sub_counts=dets, tile=128)
+    Lt = sum(len(d) for d in dets)
+    tile_det = torch.from_numpy(np.repeat(np.arange(Lt), tiles.h_sub_ntiles)).int()
+    g = torch.Generator().manual_seed(11)
+    X = torch.randn(sum(counts), K, generator=g) * 2 + 0.7
+    sc, sh = torch.rand(2, K, generator=g) + 0.5, torch.randn(2, K, generator=g) * 0.5
+    W = torch.randn(N, K, generator=g) * K ** -0.5
+    dbias = torch.randn(Lt, N, generator=g) * 3 + 1.5
+    gamma, beta = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+    grp = torch.repeat_interleave(torch.arange(2), torch.tensor(counts))
+    row_det = torch.repeat_interleave(torch.arange(Lt), torch.tensor([c for d in dets for c in d]))
+    v = torch.relu(X.double() * sc.double()[grp] + sh.double()[grp]) @ W.double().t() + dbias.double()[row_det]
+    Gp, Sp = torch.zeros(tiles.T, K * K, dtype=torch.float64), torch.zeros(tiles.T, K, dtype=torch.float64)
+    emu.gram_rows(X, K, sc, sh, tiles, Gp, Sp)
+    s_, h_ = torch.zeros(2, N), torch.zeros(2, N)
+    emu.gn_finalize_gram_dbias(Gp, Sp, tiles, tile_det, K, W, dbias, N, gamma, beta, 1e-5, None, s_, h_)
+    for gi in range(2):
+        vg = v[grp == gi]
+        want = gamma.double() / torch.sqrt(vg.var(0, unbiased=False) + 1e-5)
+        assert (s_[gi].double() - want).abs().max().item() < 1e-6
+        assert (h_[gi].double() - (beta.double() - vg.mean(0) * want)).abs().max().item() < 1e-5

@@ -675,6 +675,54 @@ def test_gram_statistics_match_direct_statistics(hip, K, N):
     close(shg, sh_ref.float(), 5e-6, 'shift from the Gram route')
 
 
+@pytest.mark.parametrize('dets,tile', [([[700, 1, 130, 2048], [90, 300]], 512), ([[3, 5, 1]], 128), ([[2048] * 6, [1024] * 5], 2048)])
+def test_gram_statistics_with_a_gathered_per_detection_bias(hip, dets, tile):
+    """GroupNorm(N, N) scale/shift of v = W relu(X*sc+sh) + dbias[det] (PointNet_v1.conv1 after the 1088 -> 512 split) from
+    the Gram partials of the 64-channel input over detection-aligned super-tiles (gram_rows K = 64 +
+    gn_finalize_gram_dbias) against float64 statistics of v itself; ragged detections incl. one-point ones, several
+    super-tiles per detection, two groups, a bias whose spread across detections exceeds the spread of W a."""
+    emu = TorchOps(torch.float64)
+    K, N = 64, 512
+    counts = [sum(d) for d in dets]
+    G = len(dets)
+    cpu = RowTiles(counts, 'cpu', sub_counts=dets, tile=tile)
+    gpu = RowTiles(counts, 'cuda', sub_counts=dets, tile=tile)
+    Lt = sum(len(d) for d in dets)
+    tile_det = torch.from_numpy(np.repeat(np.arange(Lt), cpu.h_sub_ntiles)).int()
+    R = sum(counts)
+    X = rnd(R, K, seed=190) * 2.0 + 0.7
+    sc, sh = rnd(G, K, seed=191).abs() + 0.5, rnd(G, K, seed=192) * 0.5
+    W = rnd(N, K, seed=193, scale=K ** -0.5)
+    dbias = rnd(Lt, N, seed=194) * 3.0 + 1.5
+    gamma, beta = rnd(N, seed=195).abs() + 0.5, rnd(N, seed=196)
+    grp = torch.repeat_interleave(torch.arange(G), torch.tensor(counts))
+    row_det = torch.repeat_interleave(torch.arange(Lt), torch.tensor([c for d in dets for c in d]))
+    A = torch.relu(X.double() * sc.double()[grp] + sh.double()[grp])
+    v = A @ W.double().t() + dbias.double()[row_det]
+    sc_ref, sh_ref = torch.zeros(G, N, dtype=torch.float64), torch.zeros(G, N, dtype=torch.float64)
+    for g in range(G):
+        vg = v[grp == g]
+        s = gamma.double() / torch.sqrt(vg.var(0, unbiased=False) + 1e-5)
+        sc_ref[g], sh_ref[g] = s, beta.double() - vg.mean(0) * s
+    # the specification (float64 emulation) against the direct statistics
+    Ge, Se = torch.zeros(cpu.T, K * K, dtype=torch.float64), torch.zeros(cpu.T, K, dtype=torch.float64)
+    emu.gram_rows(X, K, sc, sh, cpu, Ge, Se)
+    sce, she = torch.zeros(G, N), torch.zeros(G, N)
+    emu.gn_finalize_gram_dbias(Ge, Se, cpu, tile_det, K, W, dbias, N, gamma, beta, 1e-5, None, sce, she)
+    close(sce, sc_ref.float(), 2e-6, 'specification: scale')
+    close(she, sh_ref.float(), 2e-6, 'specification: shift')
+    # the device
+    Gp = torch.zeros(gpu.T, K * K, dtype=torch.float64).cuda()
+    Sp = torch.zeros(gpu.T, K, dtype=torch.float64).cuda()
+    hip.gram_rows(X.cuda(), K, sc.cuda(), sh.cuda(), gpu, Gp, Sp)
+    scg, shg = torch.full((G, N), float('nan')).cuda(), torch.full((G, N), float('nan')).cuda()
+    work = torch.zeros(G, K * K + K, dtype=torch.float64).cuda()
+    hip.gn_finalize_gram_dbias(Gp, Sp, gpu, tile_det.cuda(), K, W.cuda(), dbias.cuda(), N, gamma.cuda(), beta.cuda(), 1e-5,
+                               work, scg, shg)
+    close(scg, sc_ref.float(), 5e-6, 'scale from the Gram route with a per-detection bias')
+    close(shg, sh_ref.float(), 5e-6, 'shift from the Gram route with a per-detection bias')
+
+
 @pytest.mark.parametrize('N', [64, 128])
 @pytest.mark.parametrize('counts', [[5, 300, 128], [1], [70001, 257]])
 def test_pn_mlp64_matches_row_gemm_contract(hip, N, counts):
