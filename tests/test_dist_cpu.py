@@ -150,3 +150,21 @@ def test_forced_one_rank_gather_runs_the_collectives():
             dist.all_gather_into_tensor = orig
     finally:
         dist.destroy_process_group()
+
+
+def test_executed_flops_figures_quoted_in_the_design_notes():
+    """F_ref / F_exec per frame pair (bench.py; DESIGN.md sections 5 and 7 quote them): reference-as-written FLOPs of
+    SURVEY 8d, and the FLOPs of the math this build executes - each GEMM once, plus the two Gram matrices"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_mod2', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    P = 128 * 2048
+    assert round(bench.reference_flops_per_pair(64, 64, 128, P, 'C') / 1e9, 1) == 1824.6
+    assert round(bench.executed_flops_per_pair(64, 64, 128, P, 'C') / 1e9, 1) == 1412.3
+    assert round(bench.executed_flops_per_pair(64, 64, 128, P, 'C', rows=(1,)) / 1e9, 1) == 114.8
+    assert round(bench.executed_flops_per_pair(64, 64, 128, P, 'C', rows=(0,)) / 1e9, 1) == 1290.1
+    # per point: one pass of every layer (184 521 MAC) + the 64 x 64 and 128 x 128 Gram matrices
+    per_pt = (bench.executed_flops_per_pair(64, 64, 128, P + 1000, 'C') - bench.executed_flops_per_pair(64, 64, 128, P, 'C')) / 2000
+    assert per_pt == 184521 + 4096 + 16384
