@@ -96,15 +96,15 @@ def reference_flops_per_pair(N, M, S, P, fusion):
                 3 * N * M * 852096 + 3 * L * 327808)
 
 
-def executed_flops_per_pair(N, M, S, P, fusion, rows=(0, 1, 2)):
+def executed_flops_per_pair(N, M, S, P, fusion, rows=(0, 1, 2), pn_gram=True):
     """F_exec: FLOPs (2 x MAC) of the math this build actually executes per frame pair.  Against
     F_ref: STN trunks removed (-282 816 MAC/pt), 1088->512 split (-524 288 MAC/pt, +524 288 MAC/det); added: the Gram
     matrices behind the statistics of conv5 (128 x 128: +16 384 MAC/pt) and - round 5 - of PointNet_v1.conv1 (64 x 64:
     +4 096 MAC/pt; it replaced a second 64->512 GEMM pass of 32 768 MAC/pt, so F_exec per point FELL by 28 672 MAC: a
     faster step now shows as more pairs/s at an unchanged fraction).  Each GEMM of the path is counted once, in the pass
     that normalises and reduces it.  The conv trunk term is F_ref's.  Single-modality rows drop the other branch and
-    the fusion module, and run the head on one row.  (The exact-fp32 mode keeps the second GEMM pass; the figure
-    describes the default arithmetic.)"""
+    the fusion module, and run the head on one row.  ``pn_gram=False``: the legs that keep the second 64->512 GEMM pass
+    instead of the 64 x 64 Gram matrix (exact-fp32 mode, MMMOT_PN_GRAM=0)."""
     L = N + M
     nR = len(rows)
     img = (0 in rows) or (2 in rows)
@@ -113,11 +113,221 @@ def executed_flops_per_pair(N, M, S, P, fusion, rows=(0, 1, 2)):
     if img:
         f += L * (305856 * S * S + 204800)
     if pts:
-        f += P * (184521 + 4096 + 16384) + L * (524288 + 262144)
+        f += P * (184521 + (4096 if pn_gram else 32768) + 16384) + L * (524288 + 262144)
     if nR == 3:
         f += L * (524288 if fusion in ('A', 'B') else 1048576)
     f += nR * L * 393472 + nR * N * M * 852096 + nR * L * 327808
     return 2.0 * f
+
+
+# ---- the ONE stdout line -------------------------------------------------------------------------------------------
+# The driver keeps a bounded tail of stdout and parses its last line: round 5's 20.8 KB line was cut and the round went
+# unmeasured.  So: the full record (every leg, per-launch-class tables, telemetry prose) goes to
+# gpurun_out/bench_detail_n<N>.json and to ONE stderr line prefixed ``BENCH_DETAIL `` (``--detail stdout`` prints it as
+# an EARLIER stdout line instead); stdout carries exactly one JSON line of at most LINE_LIMIT characters, built by
+# compact_line() below (tests/test_bench_line.py: size, round trip, required keys on a real round-5 record).
+LINE_LIMIT = 6000
+REQUIRED_KEYS = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'end_to_end', 'parity')
+ROOFLINE_KEYS = ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'algorithmic_bytes_per_launch',
+                 'avg_launch_ms', 'trunk_share_of_step', 'share_of_step')
+
+
+def _short(s, n):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 2] + '..'
+
+
+def _sig(x, d=4):
+    return round(x, d) if isinstance(x, float) else x
+
+
+def compact_line(out, limit=LINE_LIMIT):
+    """The final stdout line from the full record ``out``: contract fields, roofline, cpu_baseline, end_to_end, parity,
+    one row per other BASELINE config, the launch classes that cost most / sit furthest below their roofline.
+    Optional blocks are dropped (least important first) until the line fits ``limit``; the contract fields never are -
+    if they alone do not fit, that is a bug and this raises."""
+    c = {k: out.get(k) for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
+                                 'scaling', 'vs_baseline', 'dtype', 'data')}
+    cfg = out.get('config') or {}
+    c['config'] = {k: (_short(v, 150) if isinstance(v, str) else v) for k, v in cfg.items()}
+    rf = out.get('roofline') or {}
+    c['roofline'] = {k: (_short(rf[k], 90) if isinstance(rf[k], str) else rf[k]) for k in ROOFLINE_KEYS if k in rf}
+    cb = out.get('cpu_baseline')
+    c['cpu_baseline'] = None if cb is None else {
+        k: (_short(cb[k], 150) if isinstance(cb[k], str) else cb[k])
+        for k in ('value', 'unit', 'cores', 'threads', 'host_cores', 'kind', 'sample') if k in cb}
+    ee = out.get('end_to_end') or {}
+    c['end_to_end'] = {'ref_gflop_per_pair': ee.get('ref_gflop_per_pair'), 'exec_gflop_per_pair': ee.get('exec_gflop_per_pair'),
+                       'exec_tflops_equiv': ee.get('exec_tflops_equiv'),
+                       'whole_step_frac': ee.get('whole_step_frac_of_f16x3_peak')}
+    par = out.get('parity') or {}
+    c['parity'] = {k: (_sig(par[k], 8)) for k in ('tolerance', 'linf_vs_reference_golden', 'linf_vs_cpu_oracle') if k in par}
+    ex = out.get('extra') or {}
+    optional = []   # (key, value) in DROP order: the first entries go first when the line is too long
+    host = out.get('host') or {}
+    tele = host.get('telemetry') or {}
+    c['host'] = {'numa_node': host.get('numa_node'), 'cpus': host.get('cpus'), 'bound': host.get('bound'),
+                 'sclk_mhz': tele.get('sclk_mhz'), 'power_w': tele.get('power_w')}
+    if 'gather_ok' in out:
+        c['gather_ok'] = out['gather_ok']
+    if out.get('per_rank'):
+        c['per_rank'] = out['per_rank']
+    if out.get('solo'):
+        c['solo'] = out['solo']
+    wls = ex.get('workloads') or {}
+    if wls:
+        c['workloads'] = {'columns': ['pairs/s', 'whole_step_frac', 'ms_per_step', 'roofline_frac', 'linf_vs_reference'],
+                          **{k: [w.get('value'), w.get('whole_step_frac_of_f16x3_peak'), w.get('ms_per_step'),
+                                 (w.get('roofline') or {}).get('frac'), _sig(w.get('linf_vs_reference_golden'), 8)]
+                             for k, w in wls.items()}}
+    arith = {}
+    for k, leg in ex.items():
+        if isinstance(leg, dict) and 'value' in leg and 'dtype' in leg:
+            arith[k] = [leg.get('value'), (leg.get('roofline') or {}).get('frac'), _sig(leg.get('linf_vs_reference_golden'), 8)]
+    if arith:
+        c['arithmetic_legs'] = {'columns': ['pairs/s', 'roofline_frac', 'linf_vs_reference'], **arith}
+    lat = ex.get('latency') or {}
+    if lat:
+        c['latency_ms_b1'] = {'eager': lat.get('latency_ms_b1'), 'plan_cached': lat.get('latency_ms_b1_plan_cached'),
+                              'hipgraph': lat.get('latency_ms_b1_hipgraph_replay'), 'device': lat.get('device_ms_b1_eager')}
+    pipe = ex.get('pipeline') or {}
+    if pipe:
+        c['pipeline'] = {k: pipe[k] for k in ('frames_per_s', 'frames_per_s_serial', 'ms_per_frame', 'stage_ms', 'bitwise_equal')
+                         if k in pipe}
+    rc = ex.get('rccl_world1') or {}
+    if rc:
+        c['rccl_world1'] = {'ok': rc.get('ok'), 'gather_us_per_step': rc.get('gather_us_per_step')}
+    prep = ex.get('prep') or {}
+    if prep:
+        c['prep'] = {k: [v.get('value'), v.get('unit')] for k, v in prep.items() if isinstance(v, dict)}
+    # launch classes: per leg the device time and the rows that cost >= 1.5 % of the step, [class, ms/step, bound, frac];
+    # the other legs list what the headline leg does not (their trunk rows repeat the headline's fractions)
+    kern = ex.get('kernels') or {}
+    ktab = {}
+    for leg, tab in kern.items():
+        if not isinstance(tab, dict) or 'rows' not in tab:
+            continue
+        tot = tab.get('device_ms_per_step') or 0.0
+        head_leg = leg.startswith('headline') or not any(not r[0].startswith('trunk') and r[3] != 'latency' and tot
+                                                         and r[2] >= 0.015 * tot for r in tab['rows'])
+        rows = [[_short(r[0], 44), _sig(r[2], 3), r[3], _sig(r[5], 3)] for r in tab['rows']
+                if r[3] != 'latency' and tot and r[2] >= 0.015 * tot and (head_leg or not r[0].startswith('trunk'))]
+        ktab[leg] = {'device_ms_per_step': tot, 'rows': rows[:8 if leg.startswith('headline') else 6]}
+    if ktab:
+        c['kernels'] = dict(ktab, columns=['class', 'ms/step', 'bound', 'frac of that peak'])
+    c['detail'] = out.get('detail_file')
+
+    def line():
+        return json.dumps(c, separators=(',', ':'))
+
+    # drop order when over the limit: kernel rows of the non-headline legs (longest tables first), then the headline
+    # table, then the small optional blocks
+    drops = [('kernels', leg) for leg in list(ktab)[::-1]] + [('prep',), ('rccl_world1',), ('latency_ms_b1',), ('pipeline',),
+                                                                 ('arithmetic_legs',), ('solo',), ('host',), ('workloads',)]
+    dropped = []
+    for d in drops:
+        if len(line()) <= limit:
+            break
+        if len(d) == 2:
+            if d[1] in c.get('kernels', {}):
+                del c['kernels'][d[1]]
+                dropped.append('kernels.' + d[1])
+                if set(c['kernels']) <= {'columns'}:
+                    del c['kernels']
+        elif d[0] in c:
+            del c[d[0]]
+            dropped.append(d[0])
+        if dropped:
+            c['dropped_for_size'] = dropped
+    s = line()
+    if len(s) > limit:
+        raise RuntimeError('bench line is %d characters (> %d) even without the optional blocks' % (len(s), limit))
+    missing = [k for k in REQUIRED_KEYS if k not in c]
+    if missing:
+        raise RuntimeError('bench line misses %s' % missing)
+    return s
+
+
+def emit(out, world, detail='stderr'):
+    """rank 0: the full record to gpurun_out/bench_detail_n<world>.json and a BENCH_DETAIL line, then the ONE stdout line"""
+    name = 'gpurun_out/bench_detail_n%d.json' % world
+    try:
+        os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(ROOT, name), 'w') as f:
+            json.dump(out, f, indent=1)
+        out['detail_file'] = name
+    except OSError:
+        out['detail_file'] = None
+    full = 'BENCH_DETAIL ' + json.dumps(out)
+    if detail == 'stdout':
+        print(full, flush=True)
+    elif detail == 'stderr':
+        print(full, file=sys.stderr, flush=True)
+    print(compact_line(out), flush=True)
+
+
+def dry_record(args, world, G, dt, per_rank, gather_ok, place):
+    """--dry: a record with EVERY key and table the GPU run produces (placeholder numbers, the real strings and the
+    profiler's real launch-class names at 25 rows per leg), so that the size / key checks of the stdout line run on
+    the real shape without a GPU (tests/test_bench_line.py, tests/test_dist_cpu.py)."""
+    from mmmot_amd.profiler import COSTS  # noqa: F401 - the label strings below are the profiler's longest ones
+    fusion, aff, sm, N, M, S, pts, gold = WORKLOADS[args.workload]
+    B = per_rank['pairs'][0]
+    names = ['trunk conv1_1+conv1_2 (fused) 3->64->64 @128x128 +pool', 'trunk conv 256->256 @32x32 +pool',
+             'A-resident GEMM 128->1024 (norm+relu prologue, column sums only)', 'rows GEMM 512->1024 (pair prologue, reduced)',
+             'Gram matrix of the 128-channel rows (conv5 statistics)', 'GroupNorm scale/shift from the Gram matrix',
+             'segment mean, 1024 channels (norm+relu rows)', 'SkipPool head (LN, 1x1, LN, 1x1, LN)']
+    table = {'device_ms_per_step': 54.068,
+             'rows': [[names[i % len(names)] + ' #%d' % i, 1.0, round(7.0 / (i + 1), 4), ('mfma', 'hbm', 'latency')[i % 3],
+                       None if i % 3 == 2 else 443.7, None if i % 3 == 2 else 0.5325] for i in range(25)]}
+    roof = {'bound': 'mfma', 'kernel': 'conv3x3_hl16_patch_kernel (VGG16-BN trunk layers 2-13, 12 launches/step)',
+            'achieved': 0.0, 'peak': 833.3, 'unit': 'TFLOP/s', 'frac': 0.0, 'traffic': 4034477625,
+            'traffic_unit': 'bytes/launch (mean)', 'traffic_source': 'profiles/r05/rocprofv3_pmc_FETCH_SIZE_cfg3_pairs1_f16x3.txt '
+            '(KB per dispatch summed over the kernel\'s launches of 3 steps)', 'algorithmic_bytes_per_launch': 3276460032,
+            'peak_basis': '2500 TFLOP/s dense f16 MFMA / 3 MFMAs per algorithmic product (a_hi*w_hi + a_hi*w_lo + a_lo*w_hi, '
+            'fp32 accumulate)', 'avg_launch_ms': 0.0, 'trunk_share_of_step': 0.0,
+            'flops_basis': 'algorithmic 2*9*Cin*Cout per output pixel (conv1_1 counted at Cin=3)'}
+    tele = {'sclk_mhz': None, 'power_w': None, 'samples': 0}
+
+    def leg(key):
+        return {'value': 0.0, 'ms_per_step': 0.0, 'dtype': 'f16x3', 'roofline': dict(roof), 'exec_gflop_per_pair': 1412.3,
+                'exec_tflops_equiv_per_gpu': 0.0, 'whole_step_frac_of_f16x3_peak': 0.0,
+                'inputs': '3 sets x 16 pairs rotated over the steps, 1350 MiB resident', 'telemetry': dict(tele),
+                'linf_vs_reference_golden': 2.4e-05, 'unit': 'frame-pairs/s',
+                'config': '%s: Fusion C, N=M=128, 128x128 crops, 2048 pts/det, 32 pairs/step/GPU, modality rows (0, 1, 2)' % key}
+    out = {
+        'metric': METRIC, 'value': None, 'unit': 'frame-pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': None, 'data': 'dry-run stub (no kernel executed)', 'gather_ok': bool(gather_ok),
+        'config': {'workload': '%s: Fusion %s, %s/%s, N=M=%d (%d crops of %dx%d), %d pts/det; %d pairs/step/GPU' % (
+            args.workload, fusion, aff, sm, N, N + M, S, S, pts, B), 'pairs_per_step_per_gpu': B, 'global_pairs': G,
+            'trunk': None, 'parallelism': 'sample-sharded x%d, flat all_gather of scores (gloo, CPU)' % world,
+            'hipgraph': False, 'rccl': False},
+        'roofline': roof,
+        'cpu_baseline': {'value': None, 'unit': 'frame-pairs/s', 'cores': None, 'threads': None, 'host_cores': os.cpu_count(),
+                         'kind': 'port', 'sample': 'dry run: not timed. ' + 'x' * 300},
+        'end_to_end': {'ref_gflop_per_pair': 1824.6, 'ref_tflops_equiv': 0.0, 'exec_gflop_per_pair': 1412.3,
+                       'exec_tflops_equiv': 0.0, 'whole_step_frac_of_f16x3_peak': 0.0, 'basis': 'x' * 330},
+        'parity': {'tolerance': 1e-3, 'linf_vs_reference_golden': None, 'linf_vs_cpu_oracle': None,
+                   'golden': 'tests/golden/%s.npz' % gold},
+        'inputs': 'stub', 'host': dict(place, telemetry=tele, note='x' * 200), 'per_rank': per_rank,
+        'solo': {'ms_per_step': 0.0, 'pairs': B, 'steps': args.steps, 'sclk_mhz': None, 'power_w': None} if world > 1 else None,
+        'extra': {'f16q8': leg('cfg3'), 'f16x3_hipgraph': {'value': 0.0, 'ms_per_step': 0.0, 'dtype': 'f16x3',
+                                                           'linf_vs_reference_golden': 2.4e-05},
+                  'workloads': {k: leg(k) for k, _, _, _ in EXTRA_WORKLOADS},
+                  'rccl_world1': {'backend': 'nccl (RCCL)', 'world_size': 1, 'gather_us_per_step': 0.0,
+                                  'max_over_ranks_ok': True, 'ok': True},
+                  'latency': {'latency_ms_b1_hipgraph_replay': 0.0, 'device_ms_b1_eager': 0.0, 'shape': 'x' * 90,
+                              'latency_ms_b1': 0.0, 'latency_ms_b1_plan_cached': 0.0, 'includes': 'x' * 200},
+                  'pipeline': {'frames_per_s': 0.0, 'frames_per_s_serial': 0.0, 'ms_per_frame': 0.0, 'bitwise_equal': True,
+                               'stage_ms': {'h2d': 0.0, 'prep_points': 0.0, 'crop_resize': 0.0, 'forward': 0.0, 'scores_d2h': 0.0},
+                               'workload': 'x' * 200},
+                  'kernels': dict({k: dict(table) for k in ['headline_%s_f16x3' % args.workload] +
+                                   [k for k, _, _, _ in EXTRA_WORKLOADS]}, columns=['x'] * 6, how='x' * 500),
+                  'prep': {k: {'value': 0.0, 'unit': 'detections/s', 'workload': 'x' * 120}
+                           for k in ('point_gather', 'crop_resize_normalize_fp32', 'crop_resize_u8')}}}
+    return out
 
 
 def parse_args(argv=None):
@@ -154,6 +364,12 @@ def parse_args(argv=None):
     ap.add_argument('--latency-only', action='store_true', help='run only the B=1 latency leg (profiling)')
     ap.add_argument('--rccl-world1-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--device', type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument('--global-pairs', type=int, default=None,
+                    help='size of the GLOBAL batch (default: gpus x --pairs); not a multiple of --gpus = uneven shards '
+                         '(first ranks one pair more), gathered over the ragged form of the result gather')
+    ap.add_argument('--detail', default='stderr', choices=['stderr', 'stdout', 'none'],
+                    help='where the full record goes as ONE line prefixed "BENCH_DETAIL " (always also written to '
+                         'gpurun_out/bench_detail_n<N>.json); stdout carries the compact line last either way')
     ap.add_argument('--dry', action='store_true',
                     help='CPU / gloo dry run of the launcher, sharding, gather, timing and JSON with a stub step')
     return ap.parse_args(argv)
@@ -652,6 +868,39 @@ def latency_b1(dev, trunk):
                         'call launches the trunk first and PointNet beside it (MMMOT_IMAGE_FIRST / MMMOT_PN_BESIDE_TRUNK)'}
 
 
+def pipeline_leg(dev, trunk, n_frames=100):
+    """The rows of SURVEY section 8 chained per frame the way eval_seq.py:140-160 + dataset/test_seq_dataset.py:176-246 +
+    tracking_model.py:68-83 chain them, on a synthetic KITTI-shaped sequence (1242 x 375 frames, ~120 k-point sweeps,
+    10-12 detections per frame = BASELINE configs[0]'s shape): per frame H2D -> prep_points -> crop_resize_u8, per pair
+    TrackingNet.forward -> scores_for_solver; frame t+1's upload and preparation on a side stream under pair t's forward
+    (mmmot_amd/pipeline.py).  Reports frames/s of the overlapped and the serial order, the serial order's device ms per
+    stage, and that both orders return bitwise equal scores."""
+    from concurrent.futures import ThreadPoolExecutor
+    from mmmot_amd import TrackingNet
+    from mmmot_amd.pipeline import FrameFeed, stage_times, time_sequence
+    from mmmot_amd.synth import make_frame
+    from mmmot_amd.weights import init_module
+    model = TrackingNet(**dict(BASE_KW, score_fusion_arch='A', affinity_op='multiply', softmax_mode='none'))
+    init_module(model, seed=0)
+    model.eval().to(dev)
+    model.set_trunk(trunk)
+    rng = np.random.default_rng(5)
+    ndet = rng.integers(10, 13, n_frames)
+    with ThreadPoolExecutor(max(1, min(16, len(os.sched_getaffinity(0))))) as pool:
+        feeds = [FrameFeed(*f) for f in pool.map(lambda t: make_frame(7000 + t, 120000, int(ndet[t])), range(n_frames))]
+    fps_o, dt_o, res_o = time_sequence(model, feeds, 224, overlap=True)
+    fps_s, dt_s, res_s = time_sequence(model, feeds, 224, overlap=False)
+    same = all(torch.equal(a[0], b[0]) and torch.equal(a[1][0], b[1][0]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+               for a, b in zip(res_o, res_s))
+    st = stage_times(model, feeds[:40], 224)
+    return {'frames_per_s': round(fps_o, 1), 'frames_per_s_serial': round(fps_s, 1), 'ms_per_frame': round(1e3 / fps_o, 3),
+            'ms_per_frame_serial': round(1e3 / fps_s, 3), 'stage_ms': st, 'bitwise_equal': bool(same), 'frames': n_frames,
+            'workload': '%d synthetic frames: 1242x375 RGB (1.4 MB) + ~120 k x 4 fp32 sweep (2 MB) per frame from pinned host '
+                        'memory, %d-%d detections (mean %.1f), 224x224 8-bit crops, Fusion A; per frame H2D -> prep_points '
+                        '(image frustum + 3D boxes, one read-back) -> crop_resize_u8; per pair TrackingNet.forward -> '
+                        'scores_for_solver (one packed D2H); no solver time' % (n_frames, ndet.min(), ndet.max(), ndet.mean())}
+
+
 def main():
     args = parse_args()
     if args.rccl_world1_child:
@@ -666,9 +915,11 @@ def main():
     if world != args.gpus:
         raise SystemExit('WORLD_SIZE=%d but --gpus %d' % (world, args.gpus))
     fusion, aff, sm, N, M, S, pts, gold_name = WORKLOADS[args.workload]
-    B = args.pairs
-    # the global batch is world * B pairs; rank r owns the contiguous shard [lo, hi)
-    lo, hi = shard_range(world * B, rank, world)
+    # the global batch is G pairs (default world * --pairs); rank r owns the contiguous shard [lo, hi) of B pairs
+    G = args.global_pairs if args.global_pairs is not None else world * args.pairs
+    lo, hi = shard_range(G, rank, world)
+    B = hi - lo
+    even = G % world == 0   # equal shards: the flat gather needs no length exchange
 
     if args.dry:
         import torch.distributed as dist
@@ -682,29 +933,31 @@ def main():
 
         def step():
             res = stub_results(hi - lo, N, M, 1000 + lo)
-            return res if args.no_gather else gather_results(res, same_layout=True)
+            return res if args.no_gather else gather_results(res, same_layout=even)
 
         place = bind_to_gpu_numa_node(None, enable=not args.no_bind)  # no GPU in a dry run: reports the affinity it found
         for _ in range(args.warmup):
             step()
         dt_own, res = time_steps(step, args.steps, barrier)
         dt = max_over_ranks(dt_own, world, dev)
-        mine = dict(ms_per_step=round(dt_own / args.steps * 1e3, 3), sclk_mhz=None, power_w=None, **place)
+        mine = dict(ms_per_step=round(dt_own / args.steps * 1e3, 3), pairs=hi - lo, first_pair=lo, gather_us_per_step=None,
+                    sclk_mhz=None, sclk_vs_solo=None, power_w=None, **place)
         allr = [mine]
         if world > 1:
             allr = [None] * world
             dist.all_gather_object(allr, mine)
         per_rank = {k: [x[k] for x in allr] for k in mine}
-        ok = args.no_gather or (len(res) == world * B and all(
-            torch.equal(res[i][1][0], stub_results(1, N, M, 1000 + i)[0][1][0]) for i in range(0, world * B, max(B // 2, 1))))
+        # every rank checks the WHOLE gathered list: global (rank-major = pair-index) order, nothing lost or doubled
+        ok = args.no_gather or (len(res) == G and all(
+            torch.equal(res[i][1][0], stub_results(1, N, M, 1000 + i)[0][1][0]) and
+            torch.equal(res[i][3], stub_results(1, N, M, 1000 + i)[0][3]) for i in range(G)))
+        oks = [bool(ok)]
+        if world > 1:
+            oks = [None] * world
+            dist.all_gather_object(oks, bool(ok))
         if rank == 0:
-            print(json.dumps({'metric': METRIC, 'value': None, 'unit': 'frame-pairs/s', 'n_gpus': world, 'steps': args.steps,
-                              'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
-                              'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': None,
-                              'data': 'dry-run stub (no kernel executed)', 'gather_ok': bool(ok), 'per_rank': per_rank,
-                              'config': {'workload': args.workload, 'pairs_per_step_per_gpu': B,
-                                         'parallelism': 'sample-sharded x%d, flat all_gather of scores (gloo, CPU)' % world}}),
-                  flush=True)
+            out = dry_record(args, world, G, dt, per_rank, all(oks), place)
+            emit(out, world, args.detail)
         if world > 1:
             dist.destroy_process_group()
         if not ok:
@@ -733,7 +986,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def build_workload(name, Bw, rows, first):
+    def build_workload(name, Bw, rows, first, total=None):
         """model + plan + device-resident inputs of `Bw` frame pairs (global pair indices first .. first + Bw - 1)"""
         fusion_, aff_, sm_, N_, M_, S_, pts_, gold_ = WORKLOADS[name]
         mdl = TrackingNet(**dict(BASE_KW, score_fusion_arch=fusion_, affinity_op=aff_, softmax_mode=sm_))
@@ -761,6 +1014,7 @@ def main():
         torch.cuda.synchronize()
         set_bytes = sum(t.numel() * t.element_size() for t in sets[0] if t is not None)
         return dict(name=name, model=mdl, plan=plan_, sets=sets, ins=ins_, rows=rows, B=Bw, gold=gold_,
+                    G=total if total is not None else Bw * world,
                     shape=(N_, M_, S_, pts_, fusion_), input_mb=round(len(sets) * set_bytes / 2 ** 20, 1))
 
     def run_leg(wl, trunk, steps, warmup, graph=False, profile=False):
@@ -788,7 +1042,7 @@ def main():
                 return gather_results(res, same_layout=True)  # trivial for one process
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            res = gather_results(res, same_layout=True, force=args.force_dist)
+            res = gather_results(res, same_layout=(wl['G'] == wl['B'] * world), force=args.force_dist)
             e1.record()
             gather_ev.append((e0, e1))
             return res
@@ -820,8 +1074,9 @@ def main():
         dt = max_over_ranks(dt, world, dev)
         roof, layers = roofline_of(trunk, events, eng, wl['B'], wl['name'], dt, wl['rows'])
         N_, M_, S_, pts_, fusion_ = wl['shape']
-        value = steps * wl['B'] * world / dt
-        fexec = executed_flops_per_pair(N_, M_, S_, (N_ + M_) * pts_, fusion_, wl['rows'])
+        value = steps * wl['G'] / dt
+        fexec = executed_flops_per_pair(N_, M_, S_, (N_ + M_) * pts_, fusion_, wl['rows'],
+                                        pn_gram=(trunk != 'f32' and getattr(eng, 'pn_gram', True)))
         leg = {'value': round(value, 4), 'ms_per_step': round(dt / steps * 1e3, 3), 'dtype': trunk, 'roofline': roof,
                'exec_gflop_per_pair': round(fexec / 1e9, 1),
                'exec_tflops_equiv_per_gpu': round(fexec * value / 1e12 / world, 2)}
@@ -851,8 +1106,13 @@ def main():
             # unpack, HIP events): `value` uses the MAX over ranks; this shows which rank and which part set it
             import torch.distributed as dist
             gus = (sum(e0.elapsed_time(e1) for e0, e1 in gather_ev) / max(len(gather_ev), 1)) * 1e3 if gather_ev else 0.0
-            mine = dict(ms_per_step=round(dt_own / steps * 1e3, 3), gather_us_per_step=round(gus, 1),
-                        sclk_mhz=tele['sclk_mhz'], power_w=tele['power_w'], **place)
+            solo_clk = (solo or {}).get('sclk_mhz')
+            mine = dict(ms_per_step=round(dt_own / steps * 1e3, 3), pairs=wl['B'], gather_us_per_step=round(gus, 1),
+                        sclk_mhz=tele['sclk_mhz'], power_w=tele['power_w'],
+                        # this rank's sustained clock over rank 0's clock running ALONE on the node (solo_leg): a
+                        # power- or thermally-capped 8-GPU node shows up here as a ratio < 1 next to the scaling number
+                        sclk_vs_solo=round(tele['sclk_mhz'] / solo_clk, 4) if tele['sclk_mhz'] and solo_clk else None,
+                        **place)
             allr = [None] * world
             dist.all_gather_object(allr, mine)
             leg['per_rank'] = {k: [x[k] for x in allr] for k in mine}
@@ -860,8 +1120,35 @@ def main():
             leg['linf_vs_reference_golden'] = golden_linf(res[0], wl['gold'], wl['rows'])
         return leg, res, layers
 
+    def solo_leg(wl, trunk, n):
+        """N-rank runs: rank 0 runs `n` ungathered steps ALONE while the other ranks wait at a barrier - its shader
+        clock, package power and ms per step without neighbours drawing power on the same node (reference for
+        per_rank.sclk_vs_solo and for the 1-GPU point of the scaling curve measured in the same process)."""
+        import torch.distributed as dist
+        mdl = wl['model']
+        mdl.set_trunk(trunk)
+        info = [None]
+        barrier()
+        if rank == 0:
+            for k in range(n + 2):
+                if k == 2:
+                    torch.cuda.synchronize()
+                    telemetry.__enter__()
+                    t0 = time.perf_counter()
+                mdl.forward_batch(wl['plan'], *wl['sets'][k % len(wl['sets'])])
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t0
+            telemetry.__exit__()
+            t = telemetry.result()
+            info[0] = {'ms_per_step': round(dt1 / n * 1e3, 3), 'pairs': wl['B'], 'steps': n, 'sclk_mhz': t['sclk_mhz'],
+                       'power_w': t['power_w']}
+        barrier()
+        dist.broadcast_object_list(info, src=0)
+        return info[0]
+
     rows = tuple(int(r) for r in args.rows.split(',') if r != '')
-    head_wl = build_workload(args.workload, B, rows, lo)
+    head_wl = build_workload(args.workload, B, rows, lo, total=G)
+    solo = solo_leg(head_wl, args.trunk, max(args.steps, 20)) if dist_on else None
     model, ins = head_wl['model'], head_wl['ins']
     do_prof = not args.no_profile
     kernels = {}
@@ -885,7 +1172,7 @@ def main():
             'exec_gflop_per_pair': head['exec_gflop_per_pair'], 'exec_tflops_equiv': head['exec_tflops_equiv_per_gpu'],
             'whole_step_frac_of_f16x3_peak': head.get('whole_step_frac_of_f16x3_peak'),
             'basis': 'F_ref = reference-as-written FLOPs (SURVEY 8d); F_exec = FLOPs of the math executed (STN trunks and '
-                     'the 1088->512 broadcast eliminated, second PointNet_v1.conv1 pass and the Gram matrix added); '
+                     'the 1088->512 broadcast eliminated, the 128 x 128 and 64 x 64 Gram matrices behind two GroupNorms added); '
                      'whole-step fraction = F_exec x pairs/s / GPU / (2500/3) - north_star target >= 0.50'},
         'parity': {'tolerance': 1e-3},
         'inputs': head['inputs'],
@@ -895,6 +1182,8 @@ def main():
     }
     if 'per_rank' in head:
         out['per_rank'] = head['per_rank']
+    if solo is not None:
+        out['solo'] = solo
     if head.get('linf_vs_reference_golden') is not None:
         out['parity']['linf_vs_reference_golden'] = head['linf_vs_reference_golden']
         out['parity']['golden'] = ('tests/golden/%s.npz (output of the imported reference on the first pair of the batch)'
@@ -954,6 +1243,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_latency:
         out['extra']['latency'] = latency_b1(dev, args.trunk)
 
+    if rank == 0 and world == 1 and not args.no_latency and not args.no_workloads:
+        out['extra']['pipeline'] = pipeline_leg(dev, args.trunk)
+
     if rank == 0 and kernels:
         out['extra']['kernels'] = dict(
             kernels, columns=['launch class', 'launches per step', 'ms per step', 'bound', 'achieved', 'fraction of that peak'],
@@ -965,7 +1257,7 @@ def main():
         out['extra']['prep'] = prep_leg(dev)
 
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out, world, args.detail)
     if dist_on:
         import torch.distributed as dist
         dist.destroy_process_group()

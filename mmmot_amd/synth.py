@@ -62,3 +62,58 @@ CONFIGS = {
     'cfg3': dict(fusion='C', affinity_op='multiply', softmax_mode='none', N=64, M=64, S=128, pts=2048, ragged=False, batch=1),
     'cfg4': dict(fusion='C', affinity_op='minus_abs', softmax_mode='dual_add', N=128, M=128, S=64, pts=512, ragged=False, batch=32),
 }
+
+
+# ---- a synthetic KITTI-shaped SEQUENCE (camera frame + LiDAR sweep + detections per frame) ---------------------------
+# KITTI tracking calibration of sequence 0000 (public dataset constants), 4x4 like the reference's info['calib/*']
+KITTI_P2 = np.array([[721.5377, 0.0, 609.5593, 44.85728], [0.0, 721.5377, 172.854, 0.2163791],
+                     [0.0, 0.0, 1.0, 0.002745884], [0.0, 0.0, 0.0, 1.0]])
+KITTI_R0 = np.array([[0.9999239, 0.00983776, -0.007445048, 0.0], [-0.009869795, 0.9999421, -0.004278459, 0.0],
+                     [0.007402527, 0.004351614, 0.9999631, 0.0], [0.0, 0.0, 0.0, 1.0]])
+KITTI_TR = np.array([[0.007533745, -0.9999714, -0.000616602, -0.004069766],
+                     [0.01480249, 0.0007280733, -0.9998902, -0.07631618],
+                     [0.9998621, 0.00752379, 0.01480755, -0.2717806], [0.0, 0.0, 0.0, 1.0]])
+KITTI_HW = (375, 1242)
+
+
+def make_frame(seed, n_pts=120000, n_det=11, hw=KITTI_HW):
+    """One frame of a synthetic sequence in the form reference dataset/test_seq_dataset.py:176-246 reads it: RGB image
+    uint8 [H, W, 3], velodyne sweep fp32 [P, 4], ``frame_info`` (calibration + img_shape) and the detection dict
+    (camera-frame ``location`` / ``dimensions`` / ``rotation_y`` + 2D ``bbox``).  Every 3D box holds a cluster of
+    5..400 points; the 2D boxes are the projections of the box centres +- an extent, clipped loosely to the frame."""
+    rng = np.random.default_rng([0x5e9, int(seed)])
+    H, W = hw
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    pts = np.stack([rng.uniform(0, 70, n_pts), rng.uniform(-30, 30, n_pts), rng.uniform(-2.5, 1.0, n_pts),
+                    rng.uniform(0, 1, n_pts)], 1)
+    loc, dims, rot, bbox, extra = [], [], [], [], []
+    for _ in range(n_det):
+        c = np.array([rng.uniform(6, 45), rng.uniform(-8, 8), rng.uniform(-1.9, -1.2)])  # lidar frame, bottom centre
+        wlh = np.array([rng.uniform(1.4, 2.0), rng.uniform(3.2, 4.8), rng.uniform(1.3, 1.8)])
+        ry = rng.uniform(-np.pi, np.pi)
+        k = int(rng.integers(5, 400))
+        local = rng.uniform(-0.49, 0.49, (k, 3)) * wlh
+        local[:, 2] += wlh[2] / 2
+        cs, sn = np.cos(ry), np.sin(ry)
+        xy = local[:, :2] @ np.array([[cs, sn], [-sn, cs]])
+        extra.append(np.concatenate([np.concatenate([xy, local[:, 2:3]], 1) + c, rng.uniform(0, 1, (k, 1))], 1))
+        cam = (KITTI_R0 @ KITTI_TR @ np.append(c, 1.0))[:3]
+        loc.append(cam)
+        dims.append([wlh[1], wlh[2], wlh[0]])  # l, h, w
+        rot.append(ry)
+        uvw = KITTI_P2[:3] @ np.append(cam, 1.0)
+        u, v = uvw[0] / uvw[2], uvw[1] / uvw[2]
+        ext = 721.5 * 2.0 / max(cam[2], 1.0)
+        bbox.append(np.clip([u - ext, v - ext * 0.8, u + ext, v + ext * 0.2], [-20, -20, 10, 10], [W - 40, H - 35, W + 18, H + 15]))
+    pts = np.concatenate([pts] + extra, 0)
+    rng.shuffle(pts)
+    info = {'calib/R0_rect': KITTI_R0, 'calib/Tr_velo_to_cam': KITTI_TR, 'calib/P2': KITTI_P2, 'img_shape': np.array([H, W])}
+    dets = {'location': np.asarray(loc), 'dimensions': np.asarray(dims), 'rotation_y': np.asarray(rot),
+            'bbox': np.asarray(bbox)}
+    return img, pts.astype(np.float32), info, dets
+
+
+def make_sequence(n_frames, seed=0, n_pts=120000, det_range=(10, 12), hw=KITTI_HW):
+    """``n_frames`` frames with det_range[0]..det_range[1] detections each (BASELINE cfg1's shape: N ~ 10-12)."""
+    rng = np.random.default_rng([0x5ea, int(seed)])
+    return [make_frame(1000 * seed + t, n_pts, int(rng.integers(det_range[0], det_range[1] + 1)), hw) for t in range(n_frames)]

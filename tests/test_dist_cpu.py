@@ -94,8 +94,36 @@ def test_bench_single_command_launcher_dry_run():
     # host placement / telemetry of every rank: one entry per rank; no GPU here, so no NUMA node is
     # found, nothing is bound and the clock / power samples are empty - the fields and the rank gather are what is checked
     pr = out['per_rank']
-    assert set(pr) >= {'ms_per_step', 'sclk_mhz', 'power_w', 'numa_node', 'cpus', 'bound'}
+    assert set(pr) >= {'ms_per_step', 'pairs', 'sclk_mhz', 'sclk_vs_solo', 'power_w', 'numa_node', 'cpus', 'bound'}
     assert all(len(v) == 2 for v in pr.values()) and pr['bound'] == [False, False] and all(c >= 1 for c in pr['cpus'])
+    assert len(lines[0]) <= 6000 and 'solo' in out and 'roofline' in out and 'cpu_baseline' in out
+
+
+def test_bench_eight_ranks_uneven_shards_dry_run():
+    """`python bench.py --gpus 8 --global-pairs 250` (cfg4's 256 minus a few): eight gloo ranks, shards of 32 / 31 pairs,
+    the RAGGED form of the result gather; every rank checks that the gathered list is the whole batch in global pair
+    order; rank 0's line carries one per_rank entry per rank (pairs, first_pair, the clock-ratio field) and stays
+    under the size limit with every table populated."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['OMP_NUM_THREADS'] = '1'
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--dry', '--gpus', '8', '--workload', 'tiny',
+                        '--steps', '2', '--warmup', '1', '--global-pairs', '250'], capture_output=True, text=True,
+                       timeout=600, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1 and len(lines[0]) <= 6000
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 8 and out['config']['global_pairs'] == 250
+    pr = out['per_rank']
+    assert pr['pairs'] == [32, 32, 31, 31, 31, 31, 31, 31] and sum(pr['pairs']) == 250
+    assert pr['first_pair'] == [0, 32, 64, 95, 126, 157, 188, 219]
+    assert all(len(v) == 8 for v in pr.values()) and len(pr['sclk_vs_solo']) == 8
+    det = [l for l in p.stderr.splitlines() if l.startswith('BENCH_DETAIL ')]
+    assert len(det) == 1 and json.loads(det[0][len('BENCH_DETAIL '):])['gather_ok'] is True
 
 
 def test_numa_binding_follows_the_gpu_sysfs_entries(tmp_path, monkeypatch):

@@ -74,3 +74,38 @@ def test_two_frames_end_to_end():
     assert (det_s - o[0][tm]).abs().max() < TOL
     assert (link_s[0] - o[1][0][tm:tm + 1]).abs().max() < TOL
     assert (new_s - o[2][tm]).abs().max() < TOL and (end_s - o[3][tm]).abs().max() < TOL
+
+
+def test_sequence_pipeline_overlapped_equals_serial_equals_direct_calls():
+    """mmmot_amd/pipeline.py: frame t+1's H2D + point gather + crop/resize on a side stream under pair t's forward
+    returns BITWISE the scores of the serial order, and both equal the plain per-pair chain of the first test."""
+    from mmmot_amd.crops import crop_resize_u8
+    from mmmot_amd.pipeline import FrameFeed, SequencePipeline, stage_times
+    from mmmot_amd.synth import make_frame
+    S = 64
+    model = TrackingNet(**KW)
+    init_module(model, seed=0)
+    model.eval().cuda()
+    frames = [make_frame(90 + t, 20000, 4 + t % 3) for t in range(6)]
+    feeds = [FrameFeed(*f) for f in frames]
+    res_o = SequencePipeline(model, S, overlap=True).run(feeds)
+    res_s = SequencePipeline(model, S, overlap=False).run(feeds)
+    assert len(res_o) == len(res_s) == 5
+    for a, b in zip(res_o, res_s):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1][0], b[1][0]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    # direct chain for pair (2, 3): the un-batched prep_points, u8 crops, one model call
+    crops, pts, split, ds = [], [], [0], []
+    for img, sweep, info, dets in frames[2:4]:
+        crops.append(crop_resize_u8(torch.from_numpy(img).cuda(), dets['bbox'], S))
+        pc = prep_points(torch.from_numpy(sweep).cuda(), info, dets, without_reflectivity=True)
+        pts.append(pc['points'])
+        split += [split[-1] + s for s in pc['points_split'][1:]]
+        ds.append(torch.tensor([len(dets['rotation_y'])]))
+    det_info = {'points': torch.cat(pts).unsqueeze(0), 'points_split': torch.tensor(split, dtype=torch.float32).unsqueeze(0).cuda()}
+    with torch.no_grad():
+        det, links, new, end, _ = model(torch.cat(crops), det_info, ds)
+    d = scores_for_solver(det, links, new, end, model.test_mode)
+    a = res_o[2]
+    assert torch.equal(a[0], d[0]) and torch.equal(a[1][0], d[1][0]) and torch.equal(a[2], d[2]) and torch.equal(a[3], d[3])
+    st = stage_times(model, feeds, S)
+    assert set(st) >= {'h2d', 'prep_points', 'crop_resize', 'forward', 'sum_of_parts'} and st['forward'] > 0
