@@ -255,8 +255,9 @@ int mmmot_gemm_rows(const mmmot_gemm_args* a, void* stream);
 /* ABI 7.  tests: which kernel serves mmmot_gemm_rows - 0 = automatic (the wide kernel of csrc/gemm_wide.hip for the
  * K >= 256 layers of the pairwise block, reference modules/gcn.py:59-66 / new_end.py:48-52, when w_hl16 = 1, amode is
  * PAIR or NORM_RELU, N % 256 == 0, no dbias / colsum / activation and the launch fills the chip), 1 = the tile kernel
- * only (the kernel before ABI 7), 2 = the wide kernel whenever the layer is eligible (N % 128 == 0, K = 256 or 512,
- * any size).  Y does not depend on it, bit for bit; part (per-tile statistics) to rounding. */
+ * only (the kernel before ABI 7), 3 / 4 = the wide kernel whenever the layer is eligible (N % 256 == 0, K = 256 or 512,
+ * any size) with one 128-row tile per four-wave workgroup (two workgroups per CU) / two tiles per eight-wave workgroup;
+ * 2 (the round-5 form of the wide kernel, removed in round 6) is rejected.  Y and part do not depend on it, bit for bit. */
 int mmmot_set_gemm_rows_variant(int v);
 
 /* A-resident row GEMM for layers whose output is only ever reduced (PointNet conv5 128->1024 and

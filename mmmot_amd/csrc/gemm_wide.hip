@@ -3,30 +3,38 @@
 // (A_PAIR) and the two GroupNorm-fed layers behind it (A_NORM_RELU).  Same contract and arithmetic as the f16 path of
 // gemm_rows.hip (3-term fp16 hi/lo split on v_mfma_f32_32x32x16_f16, fp32 accumulate, identical accumulation order,
 // identical order of the statistics sums: Y and part are bit for bit the tile kernel's, so a sample scores the same
-// whether it runs alone on the tile kernel or in a batch on this one), different data movement - driven by the round-3
-// profile: the tile kernel regenerates the A tile (op(a_i, b_j) or relu(x*sc+sh), clamp, hi/lo split, ds_write: ~7 VALU
-// instructions per element) for every one of the N/128 column tiles and spends MORE VALU than MFMA cycles (21 %
-// MFMA-busy at full clock).
+// whether it runs alone on the tile kernel or in a batch on this one), different data movement: the tile kernel
+// regenerates the A tile (op(a_i, b_j) or relu(x*sc+sh), clamp, hi/lo split, ds_write) for every one of the N/128
+// column tiles and spends more VALU than MFMA cycles.
 //
-//   * a workgroup = 8 waves = TWO 128-row tiles of the plan x BN = 32 TN columns (TN = 8: 256 columns, 128 accumulator
-//     registers per wave); one wave owns 32 rows x all BN columns: its A fragments are generated IN REGISTERS, straight
-//     in the MFMA operand layout (lane = row, 8 consecutive k), from 32-byte global loads of the fp32 source rows issued
-//     two 16-k steps ahead - no LDS traffic for A at all, and every generated fragment feeds 3 TN MFMAs: VALU work per
-//     MFMA drops 4x against the tile kernel and the 256 rows share one copy of the weight stage;
+//   * a wave owns 32 rows x 256 columns (128 accumulator registers): its A fragments are generated IN REGISTERS,
+//     straight in the MFMA operand layout (lane = row, 8 consecutive k), from 32-byte loads of the fp32 source rows
+//     requested three 16-k steps ahead - no LDS traffic for A, every generated fragment feeds 24 MFMAs;
 //   * what is the same for all 32 rows of a wave - the a_i row of a pair tile (the caller guarantees M % 32 == 0, so a
-//     32-row block never straddles two i), the per-group scale / shift rows of the GroupNorm prologue - is staged in LDS
-//     once per item and read as broadcast fragments: the kernel is bound by the RATE of vector-memory instructions a CU
-//     gets through (~90 cycles each with eight requesting waves), and those redundant per-lane requests were a third
-//     (PAIR) / half (NORM_RELU) of them;
-//   * weights stream through a 3-slot LDS ring of (BN rows x 128 B) stages (32 k = 4 hl16 units per row) by LDS-DMA
-//     (global_load_lds, no VGPR staging), two stages ahead, XOR-swizzled on the source side like the trunk kernel's
-//     weight ring (piece ^ ((row >> 1) & 7): conflict-free ds_read_b128 fragments); one s_barrier per stage with a
-//     counted vmcnt (the requests of the stage after next stay in flight across it).  All eight waves load: the L2 -> CU
-//     path returns ~3.5 B/clk per requesting wave (profiles/README.md, r01 probe) - a first version of this kernel with
-//     four 512-register waves per CU (32 rows x 512 columns each) was load-bound at 27 % MFMA-busy like the tile kernel;
-//   * persistent workgroups (one per CU), tiles chained: the first two weight stages and the source rows of the NEXT item
-//     are requested during the last two stages of the current one; the output leaves through LDS as 16-byte stores.
+//     32-row block never straddles two i), the per-group scale / shift rows of the GroupNorm prologue - is staged in
+//     LDS once per item by LDS-DMA and read as broadcast values;
+//   * weights stream through a 3-slot LDS ring of 16-k stages (256 rows x 64 B = 16 KB) by LDS-DMA (global_load_lds,
+//     no VGPR staging), requested two steps ahead, XOR-swizzled on the source side (piece ^ ((row >> 2) & 3):
+//     conflict-free ds_read_b128 fragments); ONE s_barrier per 16-k step with counted vmcnt;
+//   * a workgroup is NH row tiles of 128 rows (template parameter): NH = 1 - four waves, TWO workgroups per CU (<= 80 KB
+//     of LDS each) that drift out of phase, one's epilogue and waits under the other's K loop; NH = 2 - eight waves, the
+//     two tiles share every weight stage (two thirds of the L2 -> CU bytes per MFMA), one workgroup per CU.  The launcher
+//     takes NH = 2 when every workgroup walks a long chain of items (cfg4's 32-pair batches), NH = 1 below that;
+//   * the K loop is written out as MFMA slots - one MFMA + one piece of other work (a fragment read, two elements of
+//     the next A fragment, a weight request) with sched_barrier pinning the order - and the source-row loads are
+//     inline assembly with counted waits: left to itself the compiler sinks every fragment read next to its use (an LDS
+//     round trip four to six times per step) and answers a register that waits for a load with vmcnt(0) while LDS-DMA
+//     is in flight.  No scratch, 253-256 registers;
+//   * persistent workgroups, items chained: the first weight stages, source rows and uniform rows of the NEXT item are
+//     requested during the last steps of the current one; the output leaves through LDS as 16-byte stores.
 // Epilogue: bias, per-tile per-channel sum / tile-centred M2 (input of mmmot_gn_finalize), store - as gemm_rows.hip.
+//
+// Round 6 history (profiles/r06/gw_experiments.log): the round-5 form of this kernel (256 x 256 tile, 32-k stages,
+// compiler-scheduled, 180-228 B of scratch) ran at 0.37 / 0.33 of the f16x3 ceiling on cfg4's two layers; timing
+// experiments (no loads -12 %, no operand arithmetic -13 %, no MFMA -34 %) showed no single limiter but eight waves in the
+// same phase at the same time.  This form: 0.41 / 0.405 (4.82 / 2.44 ms at 32 pairs).  What is left: the K loop runs at
+// 65-70 % of its MFMA time, the epilogue (6.4 GB of fp32 rows per cfg4 launch through LDS staging + two statistics
+// passes) adds 20 % that nothing overlaps - 128 accumulator registers per wave leave no room for a second set.
 #include <atomic>
 #include <type_traits>
 
@@ -34,10 +42,6 @@
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-#define GW_BK 32
-#define GW_ROWB 128  // bytes of one weight row per stage
-#define GW_NSLOT 3   // ring slots: the stage in use, the next one (landed), the one after (in flight)
 
 __device__ __forceinline__ void gw_dma16(const u32x4* src, unsigned char* dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -55,69 +59,54 @@ struct GwRaw {  // source values of one 16-k step of this lane's row: 8 consecut
   f32x4 x[2];
 };
 
-template <int TN, int AMODE, int PAIROP>
-__global__ __launch_bounds__(512, 1) void gemm_wide_kernel(mmmot_gemm_args a, int ntn, int nitems) {
-  constexpr int BN = 32 * TN;
-  constexpr int SLOT = BN * GW_ROWB;            // 32 KB (TN = 8) / 16 KB (TN = 4)
-  constexpr int NG = TN / 4;                    // column groups of 4 MFMA tiles: 2 / 1
-  constexpr int NDMA = BN / 8 / 8;              // weight DMA instructions per wave and stage: 4 / 2
-  constexpr int NRAW = 2;                       // source-row load instructions per wave and 16-k step (b_j / X: 32 B per lane)
-  constexpr int SCOLS = 16;                     // output staging: 16 columns at a time
-  constexpr int CLD = SCOLS + 4;                // floats per staged row
-  constexpr int STG_WAVE = 32 * CLD * 4;        // bytes per wave
-  constexpr int RED_OFF = GW_NSLOT * SLOT;      // [8][BN] per-wave column partials, [2][BN] column means
-  constexpr int STG_OFF = RED_OFF + 10 * BN * 4;
-  // wave-uniform source vectors, double-buffered by item parity: PAIR [2][8 waves][512] (a_i of the wave's rows),
-  // NORM_RELU [2][2 halves][2][512] (scale, shift of the half's group)
-  constexpr int UNI_OFF = STG_OFF + 8 * STG_WAVE;
-  constexpr int UNI_BUF = (AMODE == MMMOT_A_PAIR) ? 8 * 2048 : 2 * 2 * 2048;
+#define G2_ROWB 64   // bytes of one weight row per 16-k stage
+#define G2_NSLOT 3
+
+// NH = row tiles per workgroup: 1 -> four waves, two workgroups per CU; 2 -> eight waves (two tiles share the weight
+// stages: two thirds of the L2 -> CU bytes per MFMA), one workgroup per CU
+template <int NH, int AMODE, int PAIROP>
+__global__ __launch_bounds__(256 * NH, 2 / NH) void gemm_wide_kernel(mmmot_gemm_args a, int ntn, int nitems) {
+  constexpr int NW = 4 * NH;                    // waves
+  constexpr int TN = 8, BN = 256;
+  constexpr int SLOT = BN * G2_ROWB;            // 16 KB
+  constexpr int NDMA = 4 / NH;                  // weight DMA instructions per wave and stage (16 rows x 64 B each)
+  constexpr int NRAW = 2;
+  constexpr int SCOLS = 16, CLD = SCOLS + 4;
+  constexpr int STG_WAVE = 32 * CLD * 4;
+  constexpr int RED_OFF = G2_NSLOT * SLOT;      // [4 waves][BN] column partials, [BN] column means
+  constexpr int STG_OFF = RED_OFF + 5 * NH * BN * 4;
+  constexpr int UNI_OFF = STG_OFF + NW * STG_WAVE;
+  constexpr int UNI_BUF = (AMODE == MMMOT_A_PAIR) ? NW * 2048 : NH * 2 * 2048;  // PAIR: a_i per wave; NORM: scale, shift per tile
   constexpr int SMEM = UNI_OFF + 2 * UNI_BUF;
-  static_assert(SMEM <= 160 * 1024, "LDS budget");
+  static_assert(SMEM <= 160 * 1024 / (2 / NH), "LDS budget (NH = 1: two workgroups per CU)");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = wave >> 2, wq = wave & 3;    // plan tile of the item (0 / 1), 32-row block inside it
+  const int half = wave >> 2, wq = wave & 3;    // row tile of the workgroup, 32-row block of the tile
   const int lr = lane & 31, h = lane >> 5;
-  const int nst = a.K / GW_BK;
+  const int nst = a.K >> 4;                     // 16-k steps
   const long wrow = (long)(a.K >> 2);           // 16-byte pieces per weight row
   const u32x4* Wp = reinterpret_cast<const u32x4*>(a.W);
 
-  // weight DMA: instruction q = wave * NDMA + b covers rows 8q .. 8q + 7; lane = (row in 8, slot in row); the swizzle
-  // (row >> 1) & 7 = (4 q + (lane >> 4)) & 7 depends on the parity of q only (NDMA is even: parity of q = parity of b)
-  unsigned dma_off[2];
-#pragma unroll
-  for (int par = 0; par < 2; ++par)
-    dma_off[par] = (unsigned)((lane >> 3) * wrow + ((lane & 7) ^ ((4 * par + (lane >> 4)) & 7)));
-  // weight fragment of column tile tn, k-step j: row r = 32 tn + lr, piece (4 j + 2 h) ^ ((r >> 1) & 7) (hi; lo: ^ 1)
-  const int boff = lr * GW_ROWB + (((2 * h) ^ ((lr >> 1) & 7)) << 4);
+  // weight DMA: instruction q = wave * NDMA + b covers rows 16 q .. 16 q + 15; lane = (row in 16, LDS slot in row)
+  const unsigned dma_off = (unsigned)((lane >> 2) * wrow + ((lane & 3) ^ ((lane >> 4) & 3)));
+  // weight fragment of column tile tn: row r = 32 tn + lr, hi piece 2 h -> slot (2 h) ^ ((r >> 2) & 3); lo: ^ 1
+  const int boff = lr * G2_ROWB + (((2 * h) ^ ((lr >> 2) & 3)) << 4);
 
-  struct Item {  // this WAVE's plan tile of the item (the two halves of a workgroup may belong to different groups)
-    int t, nt, row0, nrows, grp;
-  };
-  // item -> (pair of row tiles u, column tile nt): the ntn column tiles of a row-tile pair are items it, it + 8, ... of one
-  // group of 8 ntn - with a grid that is a multiple of 8 ntn they run at the same time on workgroups b, b + 8, ... = on the
-  // SAME XCD, so the source rows (NORM_RELU: X from HBM; PAIR: a_i / b_j) are fetched once into that XCD's L2 and the
-  // other column tiles hit it.  Row-tile pairs beyond the last one (the item count is padded to whole groups) are empty.
-  auto item_u = [&](int it) { return (it & 7) + 8 * (it / (8 * ntn)); };
+  struct Item { int t, nt, row0, nrows, grp; };
+  auto item_u = [&](int it) { return (it & 7) + 8 * (it / (8 * ntn)); };  // group of NH row tiles
   auto decode = [&](int it, Item& I) {
-    const int u = item_u(it);
+    const int t = NH * item_u(it) + half;
     I.nt = (it >> 3) % ntn;
-    const int t = 2 * u + half;
     const bool ok = t < a.T;
     I.t = ok ? t : a.T - 1;
     I.row0 = a.tile_row0[I.t];
-    I.nrows = ok ? a.tile_nrows[I.t] : 0;  // an odd tile count: the last workgroup's second half is empty
+    I.nrows = ok ? a.tile_nrows[I.t] : 0;
     I.grp = a.tile_group ? a.tile_group[I.t] : 0;
   };
-  // per-lane source rows of the A operand (row 32 wq + lr of the tile; rows beyond the tile read row 0 and are zeroed)
-  struct Src {
-    const float* p0;   // per lane: b_j (PAIR) / X row (NORM_RELU), + 8 h
-    const float* u0;   // wave-uniform rows for the LDS staging: a_i (PAIR) / scale (NORM_RELU)
-    const float* u1;   //                                        shift (NORM_RELU)
-    float top;
-  };
+  struct Src { const float* p0; const float* u0; const float* u1; float top; };
   auto sources = [&](const Item& I, Src& S) {
     const int r = wq * 32 + lr;
     const bool ok = r < I.nrows;
@@ -128,9 +117,6 @@ __global__ __launch_bounds__(512, 1) void gemm_wide_kernel(mmmot_gemm_args a, in
       const int M = a.grp_M[I.grp];
       const int ii = q / M, jj = q - ii * M;
       S.p0 = a.FB + (long)(a.grp_boff[I.grp] + jj) * a.ldf + 8 * h;
-      // M % 32 == 0 (pair_uniform32) and tiles start at multiples of 128 rows of their group: the wave's rows share ii;
-      // rows beyond the tile stand in for the wave's first row (or, in a wave without valid rows, the tile's first row:
-      // it contributes zeros whatever it reads)
       const int iw = __builtin_amdgcn_readfirstlane(ii);
       S.u0 = a.FA + (long)(a.grp_aoff[I.grp] + iw) * a.ldf;
       S.u1 = nullptr;
@@ -140,89 +126,41 @@ __global__ __launch_bounds__(512, 1) void gemm_wide_kernel(mmmot_gemm_args a, in
       S.u1 = a.sh + (long)I.grp * a.ldsc;
     }
   };
-  auto load_raw = [&](const Src& S, int s, int j, GwRaw& R) {  // k = 32 s + 16 j + 8 h .. + 7
-    const int k = s * GW_BK + 16 * j;
-    R.x[0] = *reinterpret_cast<const f32x4*>(S.p0 + k);
-    R.x[1] = *reinterpret_cast<const f32x4*>(S.p0 + k + 4);
+  auto load_raw = [&](const float* p0, int n, GwRaw& R) {  // k = 16 n + 8 h .. + 7
+    // written-out loads: the compiler's waitcnt pass answers a register that waits for a load with vmcnt(0) once
+    // LDS-DMA requests are in flight beside it - here that would drain the source rows requested a few instructions
+    // earlier (a full HBM round trip every second step).  The loads are invisible to it; the counted waits in front of
+    // the arithmetic that consumes them (gw_wait_vm in step / the prologue) are written out too.  The kernel has no
+    // scratch: no register of R is copied or parked between the request and that wait (checked in the ISA).
+    const float* p = p0 + 16 * n;
+    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
+                 : "=&v"(R.x[0]), "=&v"(R.x[1]) : "v"(p) : "memory");
   };
-  // the wave-uniform vectors of an item -> LDS buffer `ub` (lane-linear 1 KB pieces: 256 floats per instruction)
   auto dma_uniform = [&](const Src& S, int ub) {
     if constexpr (AMODE == MMMOT_A_PAIR) {
       unsigned char* dst = smem + UNI_OFF + ub * UNI_BUF + wave * 2048;
       gw_dma16(reinterpret_cast<const u32x4*>(S.u0) + lane, dst);
       if (a.K > 256) gw_dma16(reinterpret_cast<const u32x4*>(S.u0) + 64 + lane, dst + 1024);
     } else {
-      // wave 1 of each half fetches its group's shift row, the other waves the scale row (the same bytes into the same
-      // place): every wave issues the same NUMBER of requests - the counted waits assume it
-      const int v = (wq == 1) ? 1 : 0;
+      const int v = wq & 1;  // waves 1, 3: the shift row; 0, 2: the scale row (same NUMBER of requests per wave)
       unsigned char* dst = smem + UNI_OFF + ub * UNI_BUF + (half * 2 + v) * 2048;
       const float* src = v ? S.u1 : S.u0;
       gw_dma16(reinterpret_cast<const u32x4*>(src) + lane, dst);
       if (a.K > 256) gw_dma16(reinterpret_cast<const u32x4*>(src) + 64 + lane, dst + 1024);
     }
   };
-  // the A fragment of one k-step: op / normalise, fp16 range clamp (rows beyond the tile: bound 0), hi/lo split
-  // step: 16-k step inside the item (k = 16 step + 8 h); ub: LDS buffer of the item's uniform vectors
-  auto generate = [&](const GwRaw& R, float top, int step, int ub, f16x8& ah, f16x8& al) {
-    const int k = 16 * step + 8 * h;
-    f32x4 u4[2], w4[2];
-    if constexpr (AMODE == MMMOT_A_PAIR) {
-      const float* U = reinterpret_cast<const float*>(smem + UNI_OFF + ub * UNI_BUF + wave * 2048) + k;
-      u4[0] = *reinterpret_cast<const f32x4*>(U);
-      u4[1] = *reinterpret_cast<const f32x4*>(U + 4);
-    } else {
-      const float* U = reinterpret_cast<const float*>(smem + UNI_OFF + ub * UNI_BUF + half * 2 * 2048) + k;
-      u4[0] = *reinterpret_cast<const f32x4*>(U);
-      u4[1] = *reinterpret_cast<const f32x4*>(U + 4);
-      w4[0] = *reinterpret_cast<const f32x4*>(U + 512);
-      w4[1] = *reinterpret_cast<const f32x4*>(U + 516);
-    }
+  auto dma_stage = [&](const u32x4* wbase, int n, int slot) {  // this wave's share of the weights of 16-k step n
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      // PAIR: x = b_j (per lane), u = a_i (the wave's row): a_i op b_j with the operand order of the tile kernel
-      const float x = R.x[e >> 2][e & 3], u = u4[e >> 2][e & 3];
-      float y;
-      if constexpr (AMODE == MMMOT_A_PAIR) {
-        if constexpr (PAIROP == MMMOT_PAIR_MULTIPLY) y = u * x;
-        else if constexpr (PAIROP == MMMOT_PAIR_MINUS_ABS) y = fabsf((u - x) * 0.5f);
-        else y = (u - x) * 0.5f;
-      } else {
-        y = fmaxf(fmaf(x, u, w4[e >> 2][e & 3]), 0.f);
-      }
-      y = __builtin_amdgcn_fmed3f(y, -top, top);
-      ah[e] = (_Float16)y;
-      al[e] = (_Float16)(y - (float)ah[e]);
-    }
-  };
-  auto issue_dma = [&](auto BC, const u32x4* wbase, int s, int slot) {  // instruction b of this wave's NDMA
-    constexpr int b = decltype(BC)::value;
-    if constexpr (b < NDMA) {
+    for (int b = 0; b < NDMA; ++b) {
       const int q = wave * NDMA + b;
-      const unsigned long ubl = (unsigned long)(wbase + ((long)(8 * q) * wrow + 8 * s));
+      const unsigned long ubl = (unsigned long)(wbase + ((long)(16 * q) * wrow + 4 * n));
       const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(ubl >> 32));
       const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ubl);
       const u32x4* ub = (const u32x4*)(((unsigned long)hi << 32) | (unsigned long)lo);
-      gw_dma16(ub + dma_off[b & 1], smem + slot * SLOT + q * 1024);
+      gw_dma16(ub + dma_off, smem + slot * SLOT + q * 1024);
     }
   };
-  auto dma_stage = [&](const u32x4* wb, int s2, int slot2) {  // this wave's share of one weight stage
-    issue_dma(std::integral_constant<int, 0>{}, wb, s2, slot2);
-    issue_dma(std::integral_constant<int, 1>{}, wb, s2, slot2);
-    issue_dma(std::integral_constant<int, 2>{}, wb, s2, slot2);
-    issue_dma(std::integral_constant<int, 3>{}, wb, s2, slot2);
-  };
 
-  // ---- persistent loop over items (pair of row tiles x column tile; column tile fastest) -----------------------
-  // The K loop is ONE stream of 16-k steps across the items of a workgroup, software-pipelined by hand:
-  //   step n uses the A fragment f[n & 1] and walks the NG column groups; the weight fragments of group g + 1 (or of
-  //   group 0 of step n + 1) are read BEFORE the 12 MFMAs of group g are issued; fragment f[(n + 1) & 1] is generated
-  //   under the MFMAs of group 0 from the source values raw[(n + 1) & 1], which are then reloaded with the values of
-  //   step n + 3; the weights of stage s + 2 are requested at the start of stage s and the stage barrier sits in front
-  //   of the LAST group of the stage's odd step - behind it the first fragments of the next stage are read, so the
-  //   matrix cores never wait for a barrier or a load.
-  // Order of the vector-memory instructions of a stage (per wave): [even step] NDMA weight requests, NRAW source loads;
-  // [odd step] NRAW source loads - the counted wait at the stage barrier leaves the requests of the two newest steps'
-  // source rows and of the newest weight stage in flight.
   int item = blockIdx.x;
   if (item >= nitems) return;
   Item cur, nxt;
@@ -232,124 +170,215 @@ __global__ __launch_bounds__(512, 1) void gemm_wide_kernel(mmmot_gemm_args a, in
   const u32x4* wcur = Wp + (long)(cur.nt * BN) * wrow;
   GwRaw raw[2];
   f16x8 fh[2], fl[2];
-  f16x8 bh[2][4], bl[2][4];  // weight fragments: [buffer][column tile of the group]
-  auto read_b = [&](int buf, int bbase, int j, int g) {  // bbase: boff + slot * SLOT
+  f16x8 wh[2][2], wl[2][2];  // weight fragments: [buffer][tile of the pair] - groups of two column tiles, one group ahead
+  f32x4 uv[2], wv[2];        // wave-uniform operand values of the step being generated (wv: NORM_RELU shift)
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  auto read_w = [&](auto BUFC, auto TC, int sbase, int tile) {  // sbase: boff + slot * SLOT
+    constexpr int b = decltype(BUFC)::value, t = decltype(TC)::value;
+    const int off = sbase + tile * 32 * G2_ROWB;
+    wh[b][t] = *reinterpret_cast<const f16x8*>(smem + off);
+    wl[b][t] = *reinterpret_cast<const f16x8*>(smem + (off ^ 16));
+  };
+  auto read_u = [&](int step, int ubuf, bool second) {  // second: the shift row (NORM_RELU)
+    const int k = 16 * step + 8 * h;
+    const float* U = reinterpret_cast<const float*>(
+        smem + UNI_OFF + ubuf * UNI_BUF + ((AMODE == MMMOT_A_PAIR) ? wave * 2048 : half * 2 * 2048)) + k + (second ? 512 : 0);
+    f32x4* dst = second ? wv : uv;
+    dst[0] = *reinterpret_cast<const f32x4*>(U);
+    dst[1] = *reinterpret_cast<const f32x4*>(U + 4);
+  };
+  // two elements of the A fragment of the next step: op / normalise, clamp, hi/lo split (the arithmetic of generate())
+  auto gen_pair = [&](auto JTC, auto PC, float top) {
+    constexpr int jt = decltype(JTC)::value, p = decltype(PC)::value;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int off = (bbase ^ (64 * j)) + (4 * g + q) * 32 * GW_ROWB;
-      bh[buf][q] = *reinterpret_cast<const f16x8*>(smem + off);
-      bl[buf][q] = *reinterpret_cast<const f16x8*>(smem + (off ^ 16));
+    for (int q = 0; q < 2; ++q) {
+      constexpr int e0 = 2 * p;
+      const int e = e0 + q;
+      const float x = raw[jt].x[e >> 2][e & 3], u = uv[e >> 2][e & 3];
+      float y;
+      if constexpr (AMODE == MMMOT_A_PAIR) {
+        if constexpr (PAIROP == MMMOT_PAIR_MULTIPLY) y = u * x;
+        else if constexpr (PAIROP == MMMOT_PAIR_MINUS_ABS) y = fabsf((u - x) * 0.5f);
+        else y = (u - x) * 0.5f;
+      } else {
+        y = fmaxf(fmaf(x, u, wv[e >> 2][e & 3]), 0.f);
+      }
+      y = __builtin_amdgcn_fmed3f(y, -top, top);
+      fh[jt][e] = (_Float16)y;
+      fl[jt][e] = (_Float16)(y - (float)fh[jt][e]);
     }
   };
-  // source values of stream step m of the CURRENT item (m >= 2 nst: the successor's step m - 2 nst)
-  auto load_stream = [&](int m, GwRaw& R) {
-    const bool nx = m >= 2 * nst;
-    const int ml = nx ? m - 2 * nst : m;
-    Src sn;
-    sn.p0 = nx ? snxt.p0 : scur.p0;
-    load_raw(sn, ml >> 1, ml & 1, R);
+  auto dma2 = [&](const u32x4* wbase, int n, int slot, int g) {  // half of this wave's NDMA weight requests of step n
+    constexpr int PER = NDMA / 2;
+#pragma unroll
+    for (int b = 0; b < PER; ++b) {
+      const int q = wave * NDMA + g * PER + b;
+      const unsigned long ubl = (unsigned long)(wbase + ((long)(16 * q) * wrow + 4 * n));
+      const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(ubl >> 32));
+      const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ubl);
+      const u32x4* ub = (const u32x4*)(((unsigned long)hi << 32) | (unsigned long)lo);
+      gw_dma16(ub + dma_off, smem + slot * SLOT + q * 1024);
+    }
   };
-  int ub = 0;  // LDS buffer of the current item's uniform vectors
-  {  // first item of this workgroup: load prologue (K >= 64: two stages exist)
+  int ub = 0;
+  {  // first item of this workgroup: load prologue (K >= 64: four steps exist)
     dma_uniform(scur, 0);
     dma_stage(wcur, 0, 0);
-    load_raw(scur, 0, 0, raw[0]);
-    load_raw(scur, 0, 1, raw[1]);
+    load_raw(scur.p0, 0, raw[0]);
+    load_raw(scur.p0, 1, raw[1]);
     dma_stage(wcur, 1, 1);
-    gw_wait_vm<NDMA>();  // stage 0 and the first source values landed; stage 1 may be in flight
+    gw_wait_vm<NDMA>();  // the uniform rows, stage 0 and the first source values landed; stage 1 may be in flight
     __builtin_amdgcn_s_barrier();
-    generate(raw[0], scur.top, 0, 0, fh[0], fl[0]);
-    load_raw(scur, 1, 0, raw[0]);
-    read_b(0, boff, 0, 0);
+    read_u(0, 0, false);
+    if constexpr (AMODE != MMMOT_A_PAIR) read_u(0, 0, true);
+    gen_pair(I0{}, I0{}, scur.top);
+    gen_pair(I0{}, I1{}, scur.top);
+    gen_pair(I0{}, std::integral_constant<int, 2>{}, scur.top);
+    gen_pair(I0{}, std::integral_constant<int, 3>{}, scur.top);
+    __builtin_amdgcn_sched_barrier(0);
+    load_raw(scur.p0, 2, raw[0]);
+    read_u(1, 0, false);
+    if constexpr (AMODE != MMMOT_A_PAIR) read_u(1, 0, true);
+    read_w(I0{}, I0{}, boff, 0);
+    read_w(I0{}, I1{}, boff, 1);
   }
-  int slot = 0;  // ring slot of the current stage
+  int slot = 0;  // ring slot of the current step
   for (; item < nitems; item += gridDim.x) {
     const int item_n = item + gridDim.x;
     const bool has_next = item_n < nitems;
-    // (no successor: the last stages request this item's first stages again - harmless, and the K loop stays free of
-    // branches: one scheduling region per stage)
     decode(has_next ? item_n : item, nxt);
     sources(nxt, snxt);
     const u32x4* wnxt = Wp + (long)(nxt.nt * BN) * wrow;
-    dma_uniform(snxt, ub ^ 1);  // read from the last step of this item on: many stage barriers away
+    dma_uniform(snxt, ub ^ 1);
     f32x16 acc[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[tn][e] = 0.f;
 
-    for (int s = 0; s < nst; ++s) {
-      const int slot1 = (slot == GW_NSLOT - 1) ? 0 : slot + 1;     // next stage
-      const int slot2 = (slot1 == GW_NSLOT - 1) ? 0 : slot1 + 1;   // the stage after it: requested now
-      const bool wrap = (s + 2 >= nst);                            // it belongs to the successor
-      const u32x4* wb2 = wrap ? wnxt : wcur;
-      const int s2 = wrap ? s + 2 - nst : s + 2;
-      const bool last = (s == nst - 1);
-      const int bcur = boff + slot * SLOT, bnxt = boff + slot1 * SLOT;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int n = 2 * s + j;  // step of this item; f[j] holds its A fragment
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-          // fragment buffers: group (step, g) uses buffer (NG * step + g) & 1; NG = 2: g, NG = 1: j
-          const int bc = (NG == 1) ? j : (g & 1), bn = bc ^ 1;
-          // ---- requests first: the next group's weight fragments; the weight stage after next; the source rows ----
-          if (g + 1 < NG) {
-            read_b(bn, bcur, j, g + 1);
-          } else if (j == 0) {
-            read_b(bn, bcur, 1, 0);  // group 0 of the odd step, same slot
-          } else {
-            // the next stage's weights (requested a stage ago) and every older request have landed; the requests of
-            // this stage (weights of the stage after next, source rows of the two steps to come) may stay in flight;
-            // every wave is past its last read of this slot
-            gw_wait_vm<NDMA + 2 * NRAW>();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            read_b(bn, bnxt, 0, 0);
-          }
-          if (j == 0 && g == 0) dma_stage(wb2, s2, slot2);
-          if (g == 0) {  // the A fragment of step n + 1 (the successor's first step behind the last one)
-            const bool nx = last && j == 1;
-            generate(raw[j ^ 1], nx ? snxt.top : scur.top, nx ? 0 : n + 1, nx ? (ub ^ 1) : ub, fh[j ^ 1], fl[j ^ 1]);
-            load_stream(n + 3, raw[j ^ 1]);
-          }
-          // ---- 12 MFMAs, term-major: consecutive ones hit different accumulators (per accumulator the order of
-          // gemm_rows.hip: lo*hi, hi*lo, hi*hi) ----
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            acc[4 * g + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[j], bh[bc][q], acc[4 * g + q], 0, 0, 0);
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            acc[4 * g + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[j], bl[bc][q], acc[4 * g + q], 0, 0, 0);
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            acc[4 * g + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[j], bh[bc][q], acc[4 * g + q], 0, 0, 0);
+    // One 16-k step = 24 MFMAs in four groups of two column tiles (per accumulator the order lo*hi, hi*lo, hi*hi of the
+    // tile kernel), written as ONE MFMA + ONE piece of other work at a time with sched_barrier pinning the order (left to
+    // itself the scheduler sinks every fragment read next to its use - a wave then sits out an LDS round trip four to
+    // six times per step with nothing but its partner to cover it).  Step n carries, beside its MFMAs:
+    //   groups 0..2: the fragment reads of the next group (other buffer, same ring slot);
+    //   groups 0, 1: the weight requests of step n + 2 (into the slot step n - 1 has finished with);
+    //   group  p   : elements 2 p, 2 p + 1 of the A fragment of step n + 1;
+    //   end of group 2: counted wait (weights of step n + 1 landed; the newest NRAW + NDMA requests stay in flight),
+    //                barrier (every wave is past its reads of this slot);
+    //   group 3: the first fragment reads of step n + 1 (next slot), the uniform operand values of step n + 2, the
+    //            source-row loads of step n + 3.
+    auto step = [&](auto JC, int nn, int sl, int sl1) {
+      constexpr int j = decltype(JC)::value, jt = j ^ 1;
+      using JT = std::integral_constant<int, jt>;
+      const int bcur = boff + sl * SLOT, bnxt = boff + sl1 * SLOT;
+      const bool nx1 = (nn + 1 >= nst);                 // the fragment being generated belongs to the successor
+      const float top1 = nx1 ? snxt.top : scur.top;
+      auto mma = [&](auto BC, auto TC, int tile, int term) {
+        constexpr int b = decltype(BC)::value, t = decltype(TC)::value;
+        if (term == 0) acc[tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[j], wh[b][t], acc[tile], 0, 0, 0);
+        else if (term == 1) acc[tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[j], wl[b][t], acc[tile], 0, 0, 0);
+        else acc[tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[j], wh[b][t], acc[tile], 0, 0, 0);
+      };
+      auto group = [&](auto GC) {
+        constexpr int g = decltype(GC)::value;
+        using B = std::integral_constant<int, g & 1>;
+        using BN_ = std::integral_constant<int, (g & 1) ^ 1>;
+        if constexpr (g == 3) {
+          gw_wait_vm<NRAW + NDMA>();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
         }
-      }
-      slot = slot1;
+        // r = 0
+        mma(B{}, I0{}, 2 * g, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (g < 3) read_w(BN_{}, I0{}, bcur, 2 * g + 2);
+        else read_w(BN_{}, I0{}, bnxt, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // r = 1
+        mma(B{}, I1{}, 2 * g + 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (g == 0) {
+          // the source rows of step nn + 1 (requested two steps ago) have landed: the weight requests of step nn + 1 and
+          // the source rows of step nn + 2 behind them may stay in flight
+          gw_wait_vm<NDMA + NRAW>();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        gen_pair(JT{}, GC, top1);
+        __builtin_amdgcn_sched_barrier(0);
+        // r = 2
+        mma(B{}, I0{}, 2 * g, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (g < 3) read_w(BN_{}, I1{}, bcur, 2 * g + 3);
+        else read_w(BN_{}, I1{}, bnxt, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // r = 3
+        mma(B{}, I1{}, 2 * g + 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (g < 2) {
+          const int m = nn + 2;
+          const bool mx = m >= nst;
+          const int sl2 = (sl1 == G2_NSLOT - 1) ? 0 : sl1 + 1;
+          dma2(mx ? wnxt : wcur, mx ? m - nst : m, sl2, g);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (g == 3) {  // uniform operand values of step nn + 2 (generated during step nn + 1)
+          const int m = nn + 2;
+          const bool mx = m >= nst;
+          read_u(mx ? m - nst : m, mx ? (ub ^ 1) : ub, false);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // r = 4
+        mma(B{}, I0{}, 2 * g, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (g == 3 && AMODE != MMMOT_A_PAIR) {
+          const int m = nn + 2;
+          const bool mx = m >= nst;
+          read_u(mx ? m - nst : m, mx ? (ub ^ 1) : ub, true);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // r = 5
+        mma(B{}, I1{}, 2 * g + 1, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (g == 3) {  // source rows of step nn + 3 (their buffer's last element has just been consumed)
+          const int m = nn + 3;
+          const bool mx = m >= nst;
+          load_raw(mx ? snxt.p0 : scur.p0, mx ? m - nst : m, raw[jt]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      group(I0{});
+      group(I1{});
+      group(std::integral_constant<int, 2>{});
+      group(std::integral_constant<int, 3>{});
+    };
+    for (int n = 0; n < nst; n += 2) {
+      const int s1 = (slot == G2_NSLOT - 1) ? 0 : slot + 1;
+      const int s2 = (s1 == G2_NSLOT - 1) ? 0 : s1 + 1;
+      step(I0{}, n, slot, s1);
+      step(I1{}, n + 1, s1, s2);
+      slot = s2;
     }
 
-    // ---------------- epilogue ---------------------------------------------------------------------------------
-    // (the ring is untouched: the successor's first two stages are in it / on their way)
+    // ---------------- epilogue (the order of every sum is the tile kernel's: bit-identical Y and part) -------------
     const int n0 = cur.nt * BN;
     const float oscale = a.oscale;
     const int nrows = cur.nrows;
     const int rbase = wq * 32;
-    // v = oscale * accumulator + bias is formed where it is used (three times)
     float bv[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) bv[tn] = a.bias ? a.bias[n0 + tn * 32 + lr] : 0.f;
     if (a.Y) {
       float* stg = reinterpret_cast<float*>(smem + STG_OFF + wave * STG_WAVE);  // wave-private
 #pragma unroll
-      for (int c = 0; c < 2 * TN; ++c) {  // 16 columns at a time: the column halves of the lanes lr < 16 / lr >= 16
+      for (int c = 0; c < 2 * TN; ++c) {
         if ((lr >> 4) == (c & 1)) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) stg[mm_acc_row(e, lane) * CLD + (lr & 15)] = fmaf(acc[c >> 1][e], oscale, bv[c >> 1]);
         }
-        // same wave writes and reads: LDS operations of a wave execute in order
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {  // 4 lanes per row (64 B), 16 rows per instruction
+        for (int it = 0; it < 2; ++it) {
           const int r = it * 16 + (lane >> 2), p = lane & 3;
           const f32x4 v = *reinterpret_cast<const f32x4*>(&stg[r * CLD + 4 * p]);
           if (rbase + r < nrows)
@@ -358,53 +387,64 @@ __global__ __launch_bounds__(512, 1) void gemm_wide_kernel(mmmot_gemm_args a, in
       }
     }
     if (a.part) {
-      // per 32-row block: the lane's 16 values in register order, then the two lane halves; per tile (s0 + s1) + (s2 + s3)
-      // over its four blocks - the order of gemm_rows.hip, bit for bit
-      float* red = reinterpret_cast<float*>(smem + RED_OFF);  // [8 waves][BN]
-      float* colmean = red + 8 * BN;                          // [2 halves][BN]
+      float* red = reinterpret_cast<float*>(smem + RED_OFF) + half * 5 * BN;  // per tile: [4 waves][BN] partials, [BN] means
+      float* colmean = red + 4 * BN;
+      const int t2 = NH * item_u(item) + half;
+      // (a wave whose 32 rows are all inside the tile - every wave of every tile but a group's last - sums without
+      // the per-element row test: same values in the same order)
+      const bool wfull = __builtin_amdgcn_readfirstlane((int)(nrows - rbase >= 32)) != 0;
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
         float s1 = 0.f;
+        if (wfull) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e)
-          if (rbase + mm_acc_row(e, lane) < nrows) s1 += fmaf(acc[tn][e], oscale, bv[tn]);
+          for (int e = 0; e < 16; ++e) s1 += fmaf(acc[tn][e], oscale, bv[tn]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            if (rbase + mm_acc_row(e, lane) < nrows) s1 += fmaf(acc[tn][e], oscale, bv[tn]);
+        }
         s1 = mm_xor32_sum(s1);
-        if (lane < 32) red[wave * BN + tn * 32 + lr] = s1;
+        if (lane < 32) red[wq * BN + tn * 32 + lr] = s1;
       }
       gw_lds_barrier();
-      for (int x = tid; x < 2 * BN; x += 512) {
-        const int hf = x / BN, cl = x - hf * BN;
-        const float* rp = red + hf * 4 * BN + cl;
-        const float sum = (rp[0] + rp[BN]) + (rp[2 * BN] + rp[3 * BN]);
-        const int t2 = 2 * item_u(item) + hf;
+      {
+        const int cl = tid & 255;  // 256 threads of the tile's four waves, 256 columns
+        const float sum = (red[cl] + red[BN + cl]) + (red[2 * BN + cl] + red[3 * BN + cl]);
         if (t2 < a.T) {
           a.part[((long)t2 * 2 + 0) * a.N + n0 + cl] = sum;
-          colmean[x] = sum / (float)a.tile_nrows[t2];
+          colmean[cl] = sum / (float)a.tile_nrows[t2];
         }
       }
       gw_lds_barrier();
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
-        const float mu = colmean[half * BN + tn * 32 + lr];
+        const float mu = colmean[tn * 32 + lr];
         float s2 = 0.f;
+        if (wfull) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e)
-          if (rbase + mm_acc_row(e, lane) < nrows) {
+          for (int e = 0; e < 16; ++e) {
             const float d = fmaf(acc[tn][e], oscale, bv[tn]) - mu;
             s2 = fmaf(d, d, s2);
           }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            if (rbase + mm_acc_row(e, lane) < nrows) {
+              const float d = fmaf(acc[tn][e], oscale, bv[tn]) - mu;
+              s2 = fmaf(d, d, s2);
+            }
+        }
         s2 = mm_xor32_sum(s2);
-        if (lane < 32) red[wave * BN + tn * 32 + lr] = s2;  // red[] was consumed before the barrier above
+        if (lane < 32) red[wq * BN + tn * 32 + lr] = s2;
       }
       gw_lds_barrier();
-      for (int x = tid; x < 2 * BN; x += 512) {
-        const int hf = x / BN, cl = x - hf * BN;
-        const float* rp = red + hf * 4 * BN + cl;
-        const float sum = (rp[0] + rp[BN]) + (rp[2 * BN] + rp[3 * BN]);
-        const int t2 = 2 * item_u(item) + hf;
+      {
+        const int cl = tid & 255;
+        const float sum = (red[cl] + red[BN + cl]) + (red[2 * BN + cl] + red[3 * BN + cl]);
         if (t2 < a.T) a.part[((long)t2 * 2 + 1) * a.N + n0 + cl] = sum;
       }
-      gw_lds_barrier();  // the partials and means are rewritten by the next item's epilogue
+      gw_lds_barrier();
     }
     cur = nxt;
     scur = snxt;
@@ -414,33 +454,34 @@ __global__ __launch_bounds__(512, 1) void gemm_wide_kernel(mmmot_gemm_args a, in
 }
 
 static std::atomic<int> g_gemm_variant{0};
-// Test knob: 0 = automatic (the wide kernel when the layer is eligible and fills the chip), 1 = the tile kernel of
-// gemm_rows.hip only, 2 = the wide kernel whenever the layer is eligible.  Results do not depend on it (bit for bit).
+// Test knob: 0 = automatic (the wide kernel when the layer is eligible and fills the chip; NH by the length of the item
+// chains), 1 = the tile kernel of gemm_rows.hip only, 3 / 4 = the wide kernel whenever the layer is eligible, with NH = 1
+// (four waves, two workgroups per CU) / NH = 2 (eight waves).  Results do not depend on it (bit for bit).
 extern "C" int mmmot_set_gemm_rows_variant(int v) {
-  if (v < 0 || v > 2) return MMMOT_EINVAL;
+  if (v < 0 || v > 4 || v == 2) return MMMOT_EINVAL;
   g_gemm_variant.store(v);
   return MMMOT_OK;
 }
 
-template <int TN, int AMODE, int PAIROP>
+template <int NH, int AMODE, int PAIROP>
 static int gw_launch(const mmmot_gemm_args* a, hipStream_t s, int n_cu) {
-  const int ntn = a->N / (32 * TN);
-  const int nu = (a->T + 1) / 2;                     // pairs of row tiles
-  const int nitems = ((nu + 7) / 8) * 8 * ntn;       // padded to whole groups of 8 row-tile pairs x ntn column tiles
-  int grid = (n_cu / (8 * ntn)) * (8 * ntn);         // whole groups: column tiles of a row-tile pair on one XCD
+  const int ntn = a->N / 256;
+  const int nu = (a->T + NH - 1) / NH;               // groups of NH row tiles
+  const int nitems = ((nu + 7) / 8) * 8 * ntn;       // padded to whole groups of 8 x ntn column tiles
+  int grid = ((2 / NH) * n_cu / (8 * ntn)) * (8 * ntn);  // NH = 1: two workgroups per CU; whole groups (column tiles of a row tile on one XCD)
   if (grid < 8 * ntn) grid = 8 * ntn;
   if (grid > nitems) grid = nitems;
-  hipLaunchKernelGGL((gemm_wide_kernel<TN, AMODE, PAIROP>), dim3(grid), dim3(512), 0, s, *a, ntn, nitems);
+  hipLaunchKernelGGL((gemm_wide_kernel<NH, AMODE, PAIROP>), dim3(grid), dim3(256 * NH), 0, s, *a, ntn, nitems);
   return mm_check(hipGetLastError());
 }
 
-template <int TN>
+template <int NH>
 static int gw_dispatch(const mmmot_gemm_args* a, hipStream_t s, int n_cu) {
-  if (a->amode == MMMOT_A_NORM_RELU) return gw_launch<TN, MMMOT_A_NORM_RELU, 0>(a, s, n_cu);
+  if (a->amode == MMMOT_A_NORM_RELU) return gw_launch<NH, MMMOT_A_NORM_RELU, 0>(a, s, n_cu);
   switch (a->pairop) {
-    case MMMOT_PAIR_MULTIPLY: return gw_launch<TN, MMMOT_A_PAIR, MMMOT_PAIR_MULTIPLY>(a, s, n_cu);
-    case MMMOT_PAIR_MINUS_ABS: return gw_launch<TN, MMMOT_A_PAIR, MMMOT_PAIR_MINUS_ABS>(a, s, n_cu);
-    default: return gw_launch<TN, MMMOT_A_PAIR, MMMOT_PAIR_MINUS>(a, s, n_cu);
+    case MMMOT_PAIR_MULTIPLY: return gw_launch<NH, MMMOT_A_PAIR, MMMOT_PAIR_MULTIPLY>(a, s, n_cu);
+    case MMMOT_PAIR_MINUS_ABS: return gw_launch<NH, MMMOT_A_PAIR, MMMOT_PAIR_MINUS_ABS>(a, s, n_cu);
+    default: return gw_launch<NH, MMMOT_A_PAIR, MMMOT_PAIR_MINUS>(a, s, n_cu);
   }
 }
 
@@ -457,10 +498,14 @@ int mmmot_gemm_wide_try(const mmmot_gemm_args* a, hipStream_t s, int* status) {
   if (a->Y && (a->ldy % 4 != 0)) return 0;
   const int n_cu = mm_num_cu();
   if (n_cu <= 0) return 0;
-  const bool wide256 = (a->N % 256 == 0);
-  const long items = (long)((a->T + 1) / 2) * (a->N / (wide256 ? 256 : 128));
+  if (a->N % 256 != 0) return 0;  // 256-column items (the N = 128 layer of the block is HBM-bound on the tile kernel)
+  const long items = (long)((a->T + 1) / 2) * (a->N / 256);
   // small problems (one reference-shaped frame pair) are latency-bound: more, smaller workgroups finish sooner
-  if (variant == 0 && (a->K < 256 || !wide256 || items < n_cu / 2)) return 0;
-  *status = wide256 ? gw_dispatch<8>(a, s, n_cu) : gw_dispatch<4>(a, s, n_cu);
+  if (variant == 0 && items < n_cu / 2) return 0;
+  // eight waves sharing the weight stages win once every workgroup walks a long chain of items (cfg4's 32-pair batches:
+  // -4 .. -6 % against the four-wave form, tools/bench_rows_gemm.py); below that the two forms are within the box spread
+  // of each other and the four-wave form fills the chip with half as many rows
+  const bool nh2 = (variant == 4) || (variant == 0 && items >= 24L * n_cu);
+  *status = nh2 ? gw_dispatch<2>(a, s, n_cu) : gw_dispatch<1>(a, s, n_cu);
   return 1;
 }

@@ -620,6 +620,24 @@ class TrackingNet(nn.Module):
             return forward_train(self, dets, det_info, dets_split)
         return self.forward_rows(dets, det_info, dets_split, rows=(0, 1, 2))
 
+    def _trunk_first(self, fc, S, crops):
+        """The point split is on the HOST already (a pipeline that prepared the points itself, mmmot_amd/pipeline.py): no
+        read-back to hide, but the image branch still launches first so that PointNet's small launches run on the engine's
+        side stream beside the trunk instead of behind it.  Returns False when the engine is not the HIP one."""
+        self._repack_if_trained()
+        eng = self.engine()
+        if eng.ops.name != 'hip':
+            return False
+        key = (tuple(fc), S, str(crops.device))
+        plan_img = self._img_plans.get(key)
+        if plan_img is None:
+            if len(self._img_plans) > 256:
+                self._img_plans.clear()
+            plan_img = BatchPlan([(fc, None)], S, crops.device, rows=(0,), use_points=False)
+            self._img_plans[key] = plan_img
+        eng.image_first(plan_img, crops)
+        return True
+
     def _split_behind_trunk(self, ps_t, fc, S, crops):
         """The point split (device tensor) is needed on the host to build the plan; the trunk is not waiting for it.  Copy it
         on a side stream, launch the image branch (Engine.image_first: its tables depend on the frame counts only and are
@@ -677,6 +695,9 @@ class TrackingNet(nn.Module):
                     and not torch.cuda.is_current_stream_capturing()):
                 ps = self._split_behind_trunk(ps_t, fc, S, crops)
                 beside = ps is not None
+            elif (need_img and not ps_t.is_cuda and crops.is_cuda and points.is_cuda and self.image_first
+                  and not self.training and not torch.cuda.is_current_stream_capturing()):
+                beside = self._trunk_first(fc, S, crops)
             if ps is None:
                 ps = ps_t.detach().to('cpu').numpy().astype(np.int64)  # one D2H copy (reference: 2 .item() per detection)
         try:

@@ -78,7 +78,7 @@ def test_gemm_f16_pair(hip, pairop):
     close(pg[:, 0], part[:, 0], 1e-5, 'pair f16x3 tile sums')
 
 
-# ---- the wide kernel (csrc/gemm_wide.hip): A fragments generated in registers, 32 rows x 512 columns per wave ----
+# ---- the wide kernel (csrc/gemm_wide.hip): A fragments generated in registers, 32 rows x 256 columns per wave ----
 @pytest.fixture
 def variants(hip):
     from mmmot_amd import _lib
@@ -119,18 +119,19 @@ def test_gemm_wide_pair(hip, variants, pairop, N, K, NM):
     W16, osc = split_w(W)
     Fg, Wg, bg, pt = Fm.cuda(), W16.cuda(), bias.cuda(), _pair_tables(tl, NM, aoff, boff, 'cuda')
     outs = {}
-    for v in (2, 1):
+    for v in (3, 4, 1):
         assert variants(v) == 0
         Yg, pg = torch.full((R + 1, N), float('nan')).cuda(), torch.full((tl.cpu.T, 2, N), float('nan')).cuda()
         hip.gemm(Wg, tl.gpu, N, K, FA=Fg, FB=Fg, pair=pt, amode=2, pairop=pairop, bias=bg, Y=Yg, part=pg, w_hl16=True,
                  oscale=osc)
         assert torch.isnan(Yg[R]).all(), 'row beyond the last tile written'
         outs[v] = (Yg[:R].cpu(), pg.cpu())
-    close(outs[2][0], Y, 3e-6, 'wide gemm pair Y')
-    close(outs[2][1][:, 0], part[:, 0], 1e-5, 'wide gemm pair tile sums')
-    close(outs[2][1][:, 1], part[:, 1], 1e-4, 'wide gemm pair tile M2')
-    assert torch.equal(outs[2][0], outs[1][0]), 'wide and tile kernels differ in Y'
-    assert torch.equal(outs[2][1], outs[1][1]), 'wide and tile kernels differ in the per-tile statistics'
+    close(outs[3][0], Y, 3e-6, 'wide gemm pair Y')
+    close(outs[3][1][:, 0], part[:, 0], 1e-5, 'wide gemm pair tile sums')
+    close(outs[3][1][:, 1], part[:, 1], 1e-4, 'wide gemm pair tile M2')
+    # NH = 1 (variant 3) and NH = 2 (variant 4); layers the wide kernel does not take fall through to the tile kernel
+    for v in (3, 4):
+        assert torch.equal(outs[v][0], outs[1][0]) and torch.equal(outs[v][1], outs[1][1]), 'wide kernel (variant %d) differs from the tile kernel' % v
 
 
 @pytest.mark.parametrize('N,K,ldx,counts', [(512, 512, 1024, [300, 5, 128, 1000]), (128, 512, 512, [77, 260]),
@@ -151,17 +152,17 @@ def test_gemm_wide_norm_relu(hip, variants, N, K, ldx, counts):
     W16, osc = split_w(W)
     bufg = buf.cuda()
     outs = {}
-    for v in (2, 1):
+    for v in (3, 4, 1):
         assert variants(v) == 0
         Yg, pg = torch.full((R, N), float('nan')).cuda(), torch.full((tl.cpu.T, 2, N), float('nan')).cuda()
         hip.gemm(W16.cuda(), tl.gpu, N, K, X=bufg[:, ldx - K:], bias=bias.cuda(), Y=Yg, part=pg, sc=sc.cuda(), sh=sh.cuda(),
                  amode=1, w_hl16=True, oscale=osc)
         outs[v] = (Yg.cpu(), pg.cpu())
-    close(outs[2][0], Y, 3e-6, 'wide gemm norm_relu Y')
-    close(outs[2][1][:, 0], part[:, 0], 1e-5, 'wide gemm norm_relu tile sums')
-    close(outs[2][1][:, 1], part[:, 1], 1e-4, 'wide gemm norm_relu tile M2')
-    assert torch.equal(outs[2][0], outs[1][0]), 'wide and tile kernels differ in Y'
-    assert torch.equal(outs[2][1], outs[1][1]), 'wide and tile kernels differ in the per-tile statistics'
+    close(outs[3][0], Y, 3e-6, 'wide gemm norm_relu Y')
+    close(outs[3][1][:, 0], part[:, 0], 1e-5, 'wide gemm norm_relu tile sums')
+    close(outs[3][1][:, 1], part[:, 1], 1e-4, 'wide gemm norm_relu tile M2')
+    for v in (3, 4):
+        assert torch.equal(outs[v][0], outs[1][0]) and torch.equal(outs[v][1], outs[1][1]), 'wide kernel (variant %d) differs from the tile kernel' % v
 
 
 def test_gemm_wide_long_chains_are_deterministic(hip, variants):
@@ -175,12 +176,12 @@ def test_gemm_wide_long_chains_are_deterministic(hip, variants):
     W16, osc = split_w(W)
     pt = _pair_tables(tl, NM, [0], [250], 'cuda')
     outs = []
-    for v in (1, 2, 2, 2):
+    for v in (1, 3, 3, 3, 4, 4, 4, 0):
         assert variants(v) == 0
         Yg, pg = torch.full((40000, N), float('nan')).cuda(), torch.full((tl.cpu.T, 2, N), float('nan')).cuda()
         hip.gemm(W16.cuda(), tl.gpu, N, K, FA=Fm, FB=Fm, pair=pt, amode=2, pairop=0, Y=Yg, part=pg, w_hl16=True, oscale=osc)
         outs.append((Yg, pg))
     for Yg, pg in outs[1:]:
         assert torch.equal(Yg, outs[0][0]), 'wide kernel (chained tiles) differs from the tile kernel'
-    assert torch.equal(outs[1][1], outs[2][1]) and torch.equal(outs[1][1], outs[3][1])
+    assert all(torch.equal(outs[1][1], outs[i][1]) for i in (2, 3, 4, 5, 6, 7))
     close(outs[1][1][:, 0].cpu(), outs[0][1][:, 0].cpu(), 1e-5, 'tile sums wide vs tile kernel')

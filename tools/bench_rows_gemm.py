@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Timing of the GroupNorm-fed row GEMM (mmmot_gemm_rows, A_NORM_RELU prologue) per kernel variant (tile kernel of
-gemm_rows.hip = 1, wide kernel of gemm_wide.hip = 2) on the w_link.conv1.3 / conv1.6 shapes.
+gemm_rows.hip = 1, wide kernel of gemm_wide.hip with NH = 1 / 2: variants 3 / 4) on the w_link.conv1.3 / conv1.6 shapes.
 
     python tools/bench_rows_gemm.py [--rows 524288] [--n 128 512] [--k 512]
 """
@@ -27,7 +27,7 @@ def main():
     ap.add_argument('--pair', type=int, default=0, help='A_PAIR prologue instead of A_NORM_RELU: groups of M x M pair rows '
                     '(M = this value, a multiple of 32) generated from feature rows F [G * 2M][K]; --rows is rounded to whole groups')
     ap.add_argument('--ldf', type=int, default=0, help='row pitch of F in floats (default K)')
-    ap.add_argument('--variants', type=int, nargs='*', default=[1, 2])
+    ap.add_argument('--variants', type=int, nargs='*', default=[1, 3, 4])
     a = ap.parse_args()
     ops = HipOps()
     K, G = a.k, a.groups
@@ -83,11 +83,10 @@ def main():
             torch.cuda.synchronize()
             sus = e0.elapsed_time(e1) / max(a.sustain, 1)
             same = ''
-            if v == 2:
-                if ref is None:
-                    ref = (Y.clone(), part.clone())
-                else:
-                    same = '; bitwise == variant 2: %s' % (torch.equal(ref[0], Y) and torch.equal(ref[1], part))
+            if ref is None:
+                ref = (v, Y.clone(), part.clone())
+            else:
+                same = '; bitwise == variant %d: %s' % (ref[0], torch.equal(ref[1], Y) and torch.equal(ref[2], part))
             print('%s K=%d ld=%d N=%4d rows=%d variant %d  %.3f ms  %.0f TFLOP/s-equivalent; %d calls back to back: %.3f ms each%s' % (
                 'PAIR M=%d' % a.pair if a.pair else 'NORM', K, ldx, N, sum(counts), v, ms,
                 2.0 * sum(counts) * N * K / ms / 1e9, a.sustain, sus, same), flush=True)
