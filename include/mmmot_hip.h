@@ -297,8 +297,9 @@ int mmmot_set_gemm_ares_variant(int v);
  * so PointNet conv5 128->1024 + GroupNorm(1024,1024) (reference modules/point_net.py:138) needs ONE pass of
  * the 128->1024 GEMM (the normalise + ReLU + per-detection-sum pass of mmmot_gemm_ares) instead of two.
  * mmmot_gram_rows: per super-tile t (tile_row0/nrows/group, any row count, fp32 accumulation restarts every 128
- *   rows and is merged with compensated summation) Gout[t][K][K] = sum a a^T and Sout[t][K] = sum a, float64.
- *   K = 64 or 128.
+ *   rows; the 128-row sums are added up in float64 (K = 128) / compensated fp32 pairs (K = 64)) Gout[t][K][K] = sum a a^T
+ *   and Sout[t][K] = sum a, float64.  K = 64 or 128.  K = 128 writes the 32 x 32 blocks on and above the block
+ *   diagonal only (the matrix is symmetric; mmmot_gn_finalize_gram mirrors) - the other blocks of Gout are not touched.
  * mmmot_gn_finalize_gram: sums the super-tiles of every group (grp_tile0 / grp_ntiles), forms Cov in float64
  *   and writes sc[g][n] = gamma[n]*rstd, sh[g][n] = beta[n] - mean*sc for the N output channels of
  *   W [N][K] (fp32, unscaled) / bias [N] (may be NULL).  work: G*(K*K+K) doubles. */

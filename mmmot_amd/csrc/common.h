@@ -122,6 +122,28 @@ __device__ __forceinline__ float mm_relu_sum32(const f32x16& a, const f32x16& b,
   return s;
 }
 
+// The lo halves of the two-term fp16 split of (y0, y1), given their rounded hi halves packed in one register:
+// (f16)(y - (float)hi) per element.  v_fma_mix{lo,hi}_f16 computes an fp32 fma of mixed fp16 / fp32 sources and rounds the
+// result to f16 into one half of the destination: ONE instruction per element where convert-back + subtract + convert take
+// 2.5 (y - hi is exact in fp32, the rounding to f16 is the mode's RNE with subnormals kept, like v_cvt_f16_f32: bit for bit
+// the three-instruction form - tests/test_gemm_f16_gpu.py compares a kernel that uses this against one that does not).
+__device__ __forceinline__ unsigned mm_split_lo2(unsigned hi2, float y0, float y1) {
+  unsigned lo2;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(lo2)
+      : "v"(hi2), "v"(y0), "v"(y1));
+  return lo2;
+}
+
+// two values -> their packed fp16 hi halves and lo halves (RNE both; three instructions: v_cvt_pk_f16_f32 + the two above)
+__device__ __forceinline__ void mm_split2(float y0, float y1, unsigned& hi2, unsigned& lo2) {
+  typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+  const h2_t h = {(_Float16)y0, (_Float16)y1};
+  hi2 = __builtin_bit_cast(unsigned, h);
+  lo2 = mm_split_lo2(hi2, y0, y1);
+}
+
 __device__ __forceinline__ float mm_act(float v, int act) {
   if (act == MMMOT_ACT_RELU) return fmaxf(v, 0.f);
   if (act == MMMOT_ACT_SIGMOID) return 1.f / (1.f + expf(-v));

@@ -154,21 +154,25 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
         const f32x4 x1 = __builtin_bit_cast(f32x4, stg[r * 4 * KS + 2 * u + 1]);
         const f32x4 s0 = *reinterpret_cast<const f32x4*>(psc + 8 * u), s1 = *reinterpret_cast<const f32x4*>(psc + 8 * u + 4);
         const f32x4 h0 = *reinterpret_cast<const f32x4*>(psh + 8 * u), h1 = *reinterpret_cast<const f32x4*>(psh + 8 * u + 4);
-        f16x8 hi, lo;
+        u32x4 hi, lo;
+        float y[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float y0 = fminf(fmaxf(fmaf(x0[e], s0[e], h0[e]), 0.f), 65000.f);
-          float y1 = fminf(fmaxf(fmaf(x1[e], s1[e], h1[e]), 0.f), 65000.f);
-          if (!rv) y0 = y1 = 0.f;
-          hi[e] = (_Float16)y0;
-          lo[e] = (_Float16)(y0 - (float)hi[e]);
-          hi[4 + e] = (_Float16)y1;
-          lo[4 + e] = (_Float16)(y1 - (float)hi[4 + e]);
+          y[e] = fminf(fmaxf(fmaf(x0[e], s0[e], h0[e]), 0.f), 65000.f);
+          y[4 + e] = fminf(fmaxf(fmaf(x1[e], s1[e], h1[e]), 0.f), 65000.f);
+          if (!rv) y[e] = y[4 + e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {  // lo = (f16)(y - (float)hi) as one v_fma_mix per value (common.h)
+          unsigned h2, l2;
+          mm_split2(y[2 * e], y[2 * e + 1], h2, l2);
+          hi[e] = h2;
+          lo[e] = l2;
         }
         const int k = aq * (16 * KS) + 8 * u;  // channel of the unit
         const int ks = k / 64, kk = k - ks * 64;  // 64-k block of the activation planes
-        *reinterpret_cast<f16x8*>(&As[ks][0][row * AR_LDT + kk]) = hi;
-        *reinterpret_cast<f16x8*>(&As[ks][1][row * AR_LDT + kk]) = lo;
+        *reinterpret_cast<u32x4*>(&As[ks][0][row * AR_LDT + kk]) = hi;
+        *reinterpret_cast<u32x4*>(&As[ks][1][row * AR_LDT + kk]) = lo;
       }
     }
   };

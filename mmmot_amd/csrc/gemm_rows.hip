@@ -175,17 +175,22 @@ __global__ __launch_bounds__(MM_THREADS, 2) void gemm_rows_kernel(mmmot_gemm_arg
         // fp16 range clamp and the zeroing of rows beyond the tile in ONE v_med3_f32 per value (bound 0 for such rows;
         // NORM_RELU values are >= 0 already, so the lower bound does no harm there)
         const float top = rval[i] ? 65000.f : 0.f;
-        f16x8 h, l;
+        u32x4 h, l;
+        float y[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float y0 = __builtin_amdgcn_fmed3f(x0[e], -top, top), y1 = __builtin_amdgcn_fmed3f(x1[e], -top, top);
-          h[e] = (_Float16)y0;
-          l[e] = (_Float16)(y0 - (float)h[e]);
-          h[4 + e] = (_Float16)y1;
-          l[4 + e] = (_Float16)(y1 - (float)h[4 + e]);
+          y[e] = __builtin_amdgcn_fmed3f(x0[e], -top, top);
+          y[4 + e] = __builtin_amdgcn_fmed3f(x1[e], -top, top);
         }
-        *reinterpret_cast<f16x8*>(&As_hi[(lrow + 32 * i) * G16_LDT + kq * 8]) = h;
-        *reinterpret_cast<f16x8*>(&As_lo[(lrow + 32 * i) * G16_LDT + kq * 8]) = l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {  // lo = (f16)(y - (float)hi) as one v_fma_mix per value (common.h)
+          unsigned h2, l2;
+          mm_split2(y[2 * e], y[2 * e + 1], h2, l2);
+          h[e] = h2;
+          l[e] = l2;
+        }
+        *reinterpret_cast<u32x4*>(&As_hi[(lrow + 32 * i) * G16_LDT + kq * 8]) = h;
+        *reinterpret_cast<u32x4*>(&As_lo[(lrow + 32 * i) * G16_LDT + kq * 8]) = l;
       }
 #pragma unroll
       for (int i = 0; i < BLD; ++i) {

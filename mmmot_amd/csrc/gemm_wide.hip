@@ -191,6 +191,8 @@ __global__ __launch_bounds__(256 * NH, 2 / NH) void gemm_wide_kernel(mmmot_gemm_
   // two elements of the A fragment of the next step: op / normalise, clamp, hi/lo split (the arithmetic of generate())
   auto gen_pair = [&](auto JTC, auto PC, float top) {
     constexpr int jt = decltype(JTC)::value, p = decltype(PC)::value;
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    float y2[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       constexpr int e0 = 2 * p;
@@ -204,10 +206,15 @@ __global__ __launch_bounds__(256 * NH, 2 / NH) void gemm_wide_kernel(mmmot_gemm_
       } else {
         y = fmaxf(fmaf(x, u, wv[e >> 2][e & 3]), 0.f);
       }
-      y = __builtin_amdgcn_fmed3f(y, -top, top);
-      fh[jt][e] = (_Float16)y;
-      fl[jt][e] = (_Float16)(y - (float)fh[jt][e]);
+      y2[q] = __builtin_amdgcn_fmed3f(y, -top, top);
     }
+    const f16x2 h2 = {(_Float16)y2[0], (_Float16)y2[1]};
+    const unsigned hb = __builtin_bit_cast(unsigned, h2);
+    const f16x2 l2 = __builtin_bit_cast(f16x2, mm_split_lo2(hb, y2[0], y2[1]));
+    fh[jt][2 * p] = h2[0];
+    fh[jt][2 * p + 1] = h2[1];
+    fl[jt][2 * p] = l2[0];
+    fl[jt][2 * p + 1] = l2[1];
   };
   auto dma2 = [&](const u32x4* wbase, int n, int slot, int g) {  // half of this wave's NDMA weight requests of step n
     constexpr int PER = NDMA / 2;

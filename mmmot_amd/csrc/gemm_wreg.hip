@@ -149,9 +149,13 @@ __global__ __launch_bounds__(512, 1) void gemm_wreg128_kernel(mmmot_gemm_ares_ar
   auto conv_val = [&](Conv& c, int e, int part, bool rv) {
     float y = fminf(fmaxf(fmaf(c.x[e], c.s[e], c.h[e]), 0.f), 65000.f);
     if (!rv) y = 0.f;
-    const _Float16 h = (_Float16)y;
-    c.hi[e] = h;
-    c.lo[e] = (_Float16)(y - (float)h);
+    c.x[e] = y;  // (the raw value is dead: its register carries the normalised one to the split)
+    if (e == 1) {  // both values of the piece are there: hi = one v_cvt_pk, lo = one v_fma_mix per value (common.h)
+      unsigned h2, l2;
+      mm_split2(c.x[0], c.x[1], h2, l2);
+      c.hi = __builtin_bit_cast(f16x2, h2);
+      c.lo = __builtin_bit_cast(f16x2, l2);
+    }
   };
   auto conv_write = [&](const Conv& c, int hbuf, int cb, int part) {
     const int r = 32 * cb + crow;

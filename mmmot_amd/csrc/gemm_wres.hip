@@ -107,17 +107,22 @@ __global__ __launch_bounds__(WR_THREADS) void gemm_wres64_kernel(mmmot_gemm_ares
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = sr + 32 * i;
-      f16x4 hi, lo;
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      u32x2 hi, lo;
+      float y[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float y = fminf(fmaxf(fmaf(x[i][e], s4[e], h4[e]), 0.f), 65000.f);
-        if (r >= m.nrows) y = 0.f;
-        hi[e] = (_Float16)y;
-        lo[e] = (_Float16)(y - (float)hi[e]);
+        y[e] = fminf(fmaxf(fmaf(x[i][e], s4[e], h4[e]), 0.f), 65000.f);
+        if (r >= m.nrows) y[e] = 0.f;
       }
+      unsigned h0_, l0_, h1_, l1_;
+      mm_split2(y[0], y[1], h0_, l0_);  // lo = (f16)(y - (float)hi) as one v_fma_mix per value (common.h)
+      mm_split2(y[2], y[3], h1_, l1_);
+      hi = u32x2{h0_, h1_};
+      lo = u32x2{l0_, l1_};
       const int off = wr_off(r, sch >> 1) + (sch & 1) * 4;
-      *reinterpret_cast<f16x4*>(&Ah[off]) = hi;
-      *reinterpret_cast<f16x4*>(&Al[off]) = lo;
+      *reinterpret_cast<u32x2*>(&Ah[off]) = hi;
+      *reinterpret_cast<u32x2*>(&Al[off]) = lo;
     }
   };
   // ---- per-channel epilogue constants of this wave's blocks: bias (fixed), per-tile bias row, output scale / shift.

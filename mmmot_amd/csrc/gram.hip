@@ -20,6 +20,15 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define GR_LD 136        // halves per transposed LDS row: [channel][row], 272 B
 #define GR_THREADS 256
 
+// Transposed planes [channel][row] are written 4 rows (8 bytes) at a time by threads whose channels lie CPT = K / 8 apart:
+// 68 dwords per channel row x 16 (8) channels = a multiple of 32 banks - all eight threads of a row quad on ONE bank pair
+// (PMC, round 6: 71 % of the LDS cycles of the K = 128 kernel were bank conflicts; 14 % with the permutation below).  The
+// row quads of a channel are therefore stored permuted inside aligned groups of 16 quads (64 rows): quad q of channel c
+// lives at q ^ (2 * ((c / CPT) & 7)) - the 16 lanes of a store (8 channels x 2 quads) then cover 16 different bank pairs.
+// q and q + 1 (q even) stay neighbours in order, so a 16-byte fragment read (8 consecutive rows) is still one aligned read.
+template <int CPT>
+__device__ __forceinline__ int gr_quad(int q, int c) { return q ^ (((c / CPT) & 7) << 1); }
+
 // Fast two-sum accumulate: (s, c) += x with the rounding error of s + x collected in c.
 __device__ __forceinline__ void gr_acc(float& s, float& c, float x) {
   const float t = s + x;
@@ -99,8 +108,9 @@ __global__ __launch_bounds__(GR_THREADS) void gram_rows_kernel(const float* __re
             lo[rr] = (_Float16)(y - (float)hi[rr]);
           }
           const int c = sq * CPT + c4 + e;
-          *reinterpret_cast<f16x4*>(&Th[c * GR_LD + sr4]) = hi;
-          *reinterpret_cast<f16x4*>(&Tl[c * GR_LD + sr4]) = lo;
+          const int o = c * GR_LD + (gr_quad<CPT>(sr4 >> 2, c) << 2);
+          *reinterpret_cast<f16x4*>(&Th[o]) = hi;
+          *reinterpret_cast<f16x4*>(&Tl[o]) = lo;
         }
       }
     }
@@ -131,13 +141,15 @@ __global__ __launch_bounds__(GR_THREADS) void gram_rows_kernel(const float* __re
       f16x8 ah[WT], al[WT], bh[WT], bl[WT];
 #pragma unroll
       for (int a = 0; a < WT; ++a) {
-        const int off = ((wi * WT + a) * 32 + lr) * GR_LD + k16 * 16 + kh;
+        const int ch = (wi * WT + a) * 32 + lr;
+        const int off = ch * GR_LD + (gr_quad<CPT>((k16 * 16 + kh) >> 2, ch) << 2);
         ah[a] = *reinterpret_cast<const f16x8*>(&Th[off]);
         al[a] = *reinterpret_cast<const f16x8*>(&Tl[off]);
       }
 #pragma unroll
       for (int b = 0; b < WT; ++b) {
-        const int off = ((wj * WT + b) * 32 + lr) * GR_LD + k16 * 16 + kh;
+        const int ch = (wj * WT + b) * 32 + lr;
+        const int off = ch * GR_LD + (gr_quad<CPT>((k16 * 16 + kh) >> 2, ch) << 2);
         bh[b] = *reinterpret_cast<const f16x8*>(&Th[off]);
         bl[b] = *reinterpret_cast<const f16x8*>(&Tl[off]);
       }
@@ -174,6 +186,152 @@ __global__ __launch_bounds__(GR_THREADS) void gram_rows_kernel(const float* __re
   (void)CT;
 }
 
+// K = 128, round 6: the UPPER TRIANGLE of the 4 x 4 grid of 32 x 32 blocks only (10 of 16; the matrix is symmetric and
+// gram_reduce_kernel mirrors), float64 running sums (one v_add_f64 per element and sub-tile instead of the six-operation
+// two-float merge: at least as accurate, a third of the instructions) and a register budget that lets TWO workgroups
+// share a CU.  The generic kernel above needs 413 registers at K = 128 (64 accumulators + 128 compensated sums + the
+// prefetched rows of the next sub-tile): one wave per SIMD, so its phases - convert + transpose to LDS (VALU), column sums
+// (VALU), Gram (MFMA), merge (VALU) - ran one after the other with the matrix cores idle through three of them (2.3 TB/s,
+// 0.29 of HBM).  Here a wave owns at most 3 blocks (48 accumulators + 96 registers of float64 sums, 250 registers in all)
+// and one workgroup's VALU phases run under the other's matrix phase: 3.3 - 3.6 TB/s.  Waves: 0 -> (0,0) (0,1) (0,2);
+// 1 -> (0,3) (1,3) (2,3); 2 -> (1,1) (1,2) (3,3); 3 -> (2,2); the column sums are spread over all 256 threads (channel,
+// 64-row half).  Block (i, j) needs the fragments of channel blocks i and j: the A fragment of block row i and the B
+// fragment of block column i are the same LDS data.  What is left (PMC): the waves sit in s_waitcnt half of their time -
+// the rows of a sub-tile are requested where they are converted, and two workgroups do not cover an HBM round trip per
+// 128 rows; holding the next sub-tile's rows in registers across the matrix phase (32 - 64 registers) spills (measured:
+// 1.7 - 2.1 ms against 1.29), a quarter of them (16 registers) is worth 4 % and was left out.
+template <int MASK, int NBLK, int A0, int B0, int A1, int B1, int A2, int B2>
+__device__ __forceinline__ void gr_blocks(const _Float16* Th, const _Float16* Tl, int lr, int kh, f32x16 (&acc)[3]) {
+#pragma unroll
+  for (int k16 = 0; k16 < GR_ROWS / 16; ++k16) {
+    f16x8 fh[4], fl[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+      if ((MASK >> f) & 1) {
+        const int ch = f * 32 + lr;
+        const int off = ch * GR_LD + (gr_quad<16>((k16 * 16 + kh) >> 2, ch) << 2);
+        fh[f] = *reinterpret_cast<const f16x8*>(&Th[off]);
+        fl[f] = *reinterpret_cast<const f16x8*>(&Tl[off]);
+      }
+    constexpr int AI[3] = {A0, A1, A2}, BI[3] = {B0, B1, B2};
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[AI[b]], fh[BI[b]], acc[b], 0, 0, 0);
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[AI[b]], fl[BI[b]], acc[b], 0, 0, 0);
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[AI[b]], fh[BI[b]], acc[b], 0, 0, 0);
+    }
+  }
+}
+
+__global__ __launch_bounds__(GR_THREADS, 2) void gram_rows128_kernel(const float* __restrict__ X, int ldx,
+                                                                      const float* __restrict__ sc,
+                                                                      const float* __restrict__ sh, int ldsc,
+                                                                      const int* __restrict__ tile_row0,
+                                                                      const int* __restrict__ tile_nrows,
+                                                                      const int* __restrict__ tile_group,
+                                                                      double* __restrict__ Gout, double* __restrict__ Sout) {
+  constexpr int K = 128;
+  __shared__ __attribute__((aligned(16))) _Float16 Th[K * GR_LD];  // hi plane, transposed [channel][row]: 34 KB
+  __shared__ __attribute__((aligned(16))) _Float16 Tl[K * GR_LD];  // lo plane
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, kh = (lane >> 5) * 8;
+  const int t = blockIdx.x;
+  const int row0 = tile_row0[t], nrows = tile_nrows[t];
+  const int grp = tile_group ? tile_group[t] : 0;
+  // staging: thread -> (4 consecutive rows sr4 .. sr4 + 3, 16 consecutive channels)
+  constexpr int TPR = GR_THREADS / (GR_ROWS / 4);  // 8
+  constexpr int CPT = K / TPR;                     // 16
+  const int sr4 = (tid / TPR) * 4, sq = tid % TPR;
+  double gd[3][16];
+#pragma unroll
+  for (int b = 0; b < 3; ++b)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) gd[b][e] = 0.0;
+  double sd = 0.0;  // column sum of channel tid & 127 over rows 64 (tid >> 7) .. + 63 of every sub-tile
+
+  for (int r0 = 0; r0 < nrows; r0 += GR_ROWS) {
+    const int nr = min(GR_ROWS, nrows - r0);
+    const bool full = (nr == GR_ROWS);  // workgroup-uniform: the row test leaves the arithmetic of every full sub-tile
+    // ---- load, normalise + ReLU + hi/lo split, transposed into LDS ([channel][row]) ----
+    {
+      const float* ps = sc + (long)grp * ldsc + sq * CPT;
+      const float* ph = sh + (long)grp * ldsc + sq * CPT;
+#pragma unroll
+      for (int c4 = 0; c4 < CPT; c4 += 4) {
+        f32x4 xr[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const bool rv = sr4 + rr < nr;  // rows past the end read row 0 of the sub-tile (mapped) and are zeroed below
+          xr[rr] = *reinterpret_cast<const f32x4*>(X + (long)(row0 + r0 + (rv ? sr4 + rr : 0)) * ldx + sq * CPT + c4);
+        }
+        const f32x4 s4 = *reinterpret_cast<const f32x4*>(ps + c4);
+        const f32x4 h4 = *reinterpret_cast<const f32x4*>(ph + c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float y[4];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            y[rr] = __builtin_amdgcn_fmed3f(fmaf(xr[rr][e], s4[e], h4[e]), 0.f, 65000.f);  // ReLU + fp16 range clamp
+            if (!full && sr4 + rr >= nr) y[rr] = 0.f;  // rows past the end of the super-tile contribute nothing
+          }
+          typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+          const f16x2 h01 = {(_Float16)y[0], (_Float16)y[1]}, h23 = {(_Float16)y[2], (_Float16)y[3]};
+          const u32x2 hi = {__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+          const u32x2 lo = {mm_split_lo2(hi[0], y[0], y[1]), mm_split_lo2(hi[1], y[2], y[3])};
+          const int c = sq * CPT + c4 + e;
+          const int o = c * GR_LD + (gr_quad<CPT>(sr4 >> 2, c) << 2);
+          *reinterpret_cast<u32x2*>(&Th[o]) = hi;
+          *reinterpret_cast<u32x2*>(&Tl[o]) = lo;
+        }
+      }
+    }
+    __syncthreads();
+    {  // column sums (deterministic order): thread -> one channel, 64 rows (stored permuted inside the 64: gr_quad), hi and
+       // lo; fp32 over the 64 rows, then float64
+      const int c = tid & 127, rb = (tid >> 7) * 64;
+      float a = 0.f;
+#pragma unroll 4
+      for (int r8 = 0; r8 < 64; r8 += 8) {
+        const f16x8 h = *reinterpret_cast<const f16x8*>(&Th[c * GR_LD + rb + r8]);
+        const f16x8 l = *reinterpret_cast<const f16x8*>(&Tl[c * GR_LD + rb + r8]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a += (float)h[e] + (float)l[e];
+      }
+      sd += (double)a;
+    }
+    f32x16 acc[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+    if (wave == 0) gr_blocks<0x7, 3, 0, 0, 0, 1, 0, 2>(Th, Tl, lr, kh, acc);
+    else if (wave == 1) gr_blocks<0xF, 3, 0, 3, 1, 3, 2, 3>(Th, Tl, lr, kh, acc);
+    else if (wave == 2) gr_blocks<0xE, 3, 1, 1, 1, 2, 3, 3>(Th, Tl, lr, kh, acc);
+    else gr_blocks<0x4, 1, 2, 2, 2, 2, 2, 2>(Th, Tl, lr, kh, acc);
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) gd[b][e] += (double)acc[b][e];
+    __syncthreads();  // the planes are rewritten by the next sub-tile
+  }
+  double* G = Gout + (long)t * K * K;
+  auto put = [&](int b, int bi, int bj) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) G[(long)(bi * 32 + mm_acc_row(e, lane)) * K + bj * 32 + lr] = gd[b][e];
+  };
+  if (wave == 0) { put(0, 0, 0); put(1, 0, 1); put(2, 0, 2); }
+  else if (wave == 1) { put(0, 0, 3); put(1, 1, 3); put(2, 2, 3); }
+  else if (wave == 2) { put(0, 1, 1); put(1, 1, 2); put(2, 3, 3); }
+  else put(0, 2, 2);
+  // the two row halves of every channel's sum meet in LDS (the planes are free: the loop ended with a barrier)
+  double* sx = reinterpret_cast<double*>(Th);
+  if (tid >= 128) sx[tid - 128] = sd;
+  __syncthreads();
+  if (tid < 128) Sout[(long)t * K + tid] = sd + sx[tid];
+}
+
 // sum of the super-tile partials of every group -> covariance and mean of the group's rows:
 // red[g][K*K + K] doubles = Cov(a) (K x K), then E[a] (K).  Every thread also re-adds the two column sums its element
 // needs (nt <= a few dozen terms each) so that the covariance is formed ONCE per group here instead of once per
@@ -207,7 +365,11 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restri
   };
   auto colsum = [&](int k) { return tile_sum(Sp + k, K); };
   if (idx < KK) {
-    const double s = tile_sum(Gp + idx, KK);
+    // K = 128: gram_rows128_kernel writes the blocks on and above the block diagonal only - element (i, j) of a block below
+    // it is element (j, i)
+    const int ei = idx / K, ej = idx % K;
+    const int src = (K == 128 && (ei >> 5) > (ej >> 5)) ? ej * K + ei : idx;
+    const double s = tile_sum(Gp + src, KK);
     const double mi = colsum(idx / K) / cnt, mj = colsum(idx % K) / cnt;
     red[(long)g * (KK + K) + idx] = s / cnt - mi * mj;
   } else {
@@ -306,7 +468,7 @@ extern "C" int mmmot_gram_rows(const float* X, int ldx, int K, const float* sc, 
   if ((K != 64 && K != 128) || ldx % 4 != 0 || ldsc % 4 != 0 || !mm_al16(X) || !mm_al16(sc) || !mm_al16(sh))
     return MMMOT_EINVAL;
   if (K == 128)
-    hipLaunchKernelGGL(gram_rows_kernel<128>, dim3(T), dim3(GR_THREADS), 0, s, X, ldx, sc, sh, ldsc, tile_row0, tile_nrows,
+    hipLaunchKernelGGL(gram_rows128_kernel, dim3(T), dim3(GR_THREADS), 0, s, X, ldx, sc, sh, ldsc, tile_row0, tile_nrows,
                        tile_group, Gout, Sout);
   else
     hipLaunchKernelGGL(gram_rows_kernel<64>, dim3(T), dim3(GR_THREADS), 0, s, X, ldx, sc, sh, ldsc, tile_row0, tile_nrows,

@@ -14,15 +14,14 @@ static __device__ u32x4 pt_zero_page[16];  // zero-initialised: source of out-of
 #define P_ROWB 128  // bytes per LDS record (pixel or weight row): 32 channels hi+lo
 
 __device__ __forceinline__ void pt_split8(f32x8 v, u32x4& hi, u32x4& lo) {
-  f16x8 h, l;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float x = fminf(fmaxf(v[e], -65000.f), 65000.f);
-    h[e] = (_Float16)x;
-    l[e] = (_Float16)(x - (float)h[e]);
+  for (int e = 0; e < 8; e += 2) {
+    const float x0 = fminf(fmaxf(v[e], -65000.f), 65000.f), x1 = fminf(fmaxf(v[e + 1], -65000.f), 65000.f);
+    unsigned h2, l2;
+    mm_split2(x0, x1, h2, l2);  // lo = (f16)(x - (float)hi) as one v_fma_mix per value (common.h)
+    hi[e >> 1] = h2;
+    lo[e >> 1] = l2;
   }
-  hi = __builtin_bit_cast(u32x4, h);
-  lo = __builtin_bit_cast(u32x4, l);
 }
 
 // hq8 encode of 16 consecutive channels: fp16 hi (two 16-byte pieces), e4m3(a * 2^-2), e4m3((a - hi) * 2^9)

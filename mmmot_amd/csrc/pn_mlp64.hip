@@ -70,16 +70,21 @@ __global__ __launch_bounds__(256) void pn_mlp64_kernel(const float* __restrict__
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int r = srow + 16 * i;
-        f16x4 hi, lo;
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        u32x2 hi, lo;
+        float y[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float y = fminf(fmaxf(fmaf(x[i][e], s0[e], h0[e]), 0.f), 65000.f);
-          if (r >= nrows) y = 0.f;
-          hi[e] = (_Float16)y;
-          lo[e] = (_Float16)(y - (float)hi[e]);
+          y[e] = fminf(fmaxf(fmaf(x[i][e], s0[e], h0[e]), 0.f), 65000.f);
+          if (r >= nrows) y[e] = 0.f;
         }
-        *reinterpret_cast<f16x4*>(&Ah[r * PM_LDT + sc0]) = hi;
-        *reinterpret_cast<f16x4*>(&Al[r * PM_LDT + sc0]) = lo;
+        unsigned h0_, l0_, h1_, l1_;
+        mm_split2(y[0], y[1], h0_, l0_);  // lo = (f16)(y - (float)hi) as one v_fma_mix per value (common.h)
+        mm_split2(y[2], y[3], h1_, l1_);
+        hi = u32x2{h0_, h1_};
+        lo = u32x2{l0_, l1_};
+        *reinterpret_cast<u32x2*>(&Ah[r * PM_LDT + sc0]) = hi;
+        *reinterpret_cast<u32x2*>(&Al[r * PM_LDT + sc0]) = lo;
       }
     }
     const int tn = t + gridDim.x;
