@@ -613,7 +613,10 @@ int mmmot_score_loss(const float* x, int ldx, const float* y, const float* mrow,
  * (float64, device) is the module's running state, updated in place: acc <- momentum * acc + (1 - momentum) * count for
  * every non-empty bin (momentum == 0: acc = count, acc_sum untouched); weight = float(tot / acc) / (non-empty bins),
  * tot = max(valid elements, 1).  g[r][c] = scale * w * (sigmoid(x) - y) / tot (weights are constants of the graph),
- * PL[0] (+)= scale * sum(w * bce) / tot (accumulate != 0: added, like mmmot_score_loss).  One workgroup; R * C <= 2^24. */
+ * PL[0] (+)= scale * sum(w * bce) / tot (accumulate != 0: added, like mmmot_score_loss).  One workgroup; R * C <= 2^24.
+ * momentum travels as fp32 and is widened to float64 on the device: bit-faithful to the
+ * reference's Python-float arithmetic for values fp32 represents exactly (the reference's hard-wired 0.75); any other value
+ * (0.9, say) differs from it by ~1e-8 relative per step. */
 int mmmot_ghm_loss(const float* x, int ldx, const float* y, float ignore, float scale, int R, int C, int bins,
                    float momentum, double* acc_sum, float* g, int ldg, float* PL, int accumulate, void* stream);
 

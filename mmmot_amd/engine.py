@@ -363,8 +363,19 @@ class Engine:
                     guard = self.trunk != 'f32'
         sync = guard and (first or (self.range_check_every > 0 and self._n_forward % self.range_check_every == 0))
         if sync:
-            self.read_range(reset=True)  # open the window of this forward (drops whatever a skipped read-back left)
+            # open the window of this forward.  What the counters hold at this point belongs to the forwards since the last
+            # inspected read-back (an asynchronous copy that had not completed when this check came round is superseded
+            # by this synchronous read): they get their verdict and event here instead of being dropped
+            sat, clamp, c11 = self.read_range(reset=True)
+            w0, w1 = self._range_win0, self._n_forward - 1
+            if self._range_pending is not None:  # the copy that did not complete: its forwards are in these counters too
+                w0 = min(w0, self._range_pending[1])
             self._range_pending = None
+            if w1 >= w0:
+                lower = self._range_verdict(plan, sat, clamp, c11, w1 - w0 + 1)
+                if lower is not None:
+                    self._range_event(plan, lower, sat, clamp, c11, recomputed=False, window=(w0, w1))
+                    sync = self.trunk != 'f32'  # lowered to the exact arithmetic: nothing left to check
             self._range_win0 = self._n_forward
         ops.trunk_range_bind(blk)
         try:

@@ -279,8 +279,10 @@ class TrackingLoss(nn.Module):
     def ghm_state(self, which, device=None):
         """running per-bin counts of the 'det' / 'end' GHMC_Loss (float64 [bins] device tensor; the reference's acc_sum)"""
         t = self._ghm_acc.get(which)
-        if t is None or (device is not None and t.device != torch.device(device)):
+        if t is None:
             t = self._ghm_acc[which] = torch.zeros(self.ghm_bins, dtype=torch.float64, device=device)
+        elif device is not None and t.device != torch.device(device):
+            t = self._ghm_acc[which] = t.to(device)  # the momentum history moves with the criterion (ADVICE r5: it was re-zeroed)
         return t
 
     def forward(self, det_split, gt_det, gt_link, gt_new, gt_end, det_score, link_score, new_score, end_score, trans=None):

@@ -184,6 +184,39 @@ def test_late_read_back_reports_the_forwards_it_covers():
     assert ev['affected_forwards'] == (3, 5) and ev['forward'] == 6 and eng.out_of_range_window == (3, 5)
 
 
+def test_synchronous_check_gives_the_superseded_read_back_its_verdict():
+    """with range_check_every > 0 a synchronous check may come round while the previous asynchronous read-back
+    has not completed.  The counters it reads (and resets) then cover forwards that were already returned: they get their
+    verdict and an event naming them instead of being dropped without one."""
+    m, sd, (dets, info, ds) = build('calibrated', 0, 1.0)
+    eng = m.engine()
+    eng.range_check_every = 4
+
+    class Slow:
+        def query(self):
+            return False
+
+    with torch.no_grad():
+        m(dets, info, ds)                      # forward 0: synchronous
+        m(dets, info, ds)                      # forward 1: read-back queued (1..1)
+        eng._range_pending = (Slow(),) + eng._range_pending[1:]   # ... and never completes
+        cv = eng.P['vgg'][4]
+        good = cv['bias']
+        cv['bias'] = good + 3000.0
+        m(dets, info, ds)                      # forward 2 leaves the range; nothing new is queued
+        cv['bias'] = good
+        m(dets, info, ds)                      # forward 3
+        assert not eng.range_events
+        with pytest.warns(RuntimeWarning, match='forwards 1..3 of this engine ran out of range'):
+            out = m(dets, info, ds)            # forward 4: the synchronous check reads what 1..3 left behind
+    ev = eng.range_events[0]
+    assert ev['recomputed'] is False and ev['affected_forwards'] == (1, 3) and ev['forward'] == 4
+    assert eng.out_of_range_window == (1, 3) and eng.trunk in ('f16x3', 'f32')
+    with torch.no_grad():
+        ref = R.tracking_forward(sd, CFG, dets, info['points'], info['points_split'], [2, 2])
+    assert linf(out, ref) < 1e-3               # forward 4 itself ran (in the lowered arithmetic) and is fine
+
+
 def test_per_channel_shifts_follow_the_folded_gains():
     """every output channel of every trunk layer lands in (2^13, 2^14] after its own power-of-two scale, whatever its
     BatchNorm gain; the scale vector undoes it exactly"""
