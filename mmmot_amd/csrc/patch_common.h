@@ -112,6 +112,20 @@ __device__ __forceinline__ void pt_dma16(const u32x4* src, unsigned char* dst) {
                                    (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
 }
 
+// LDS reads of the epilogue's staging area, written out.  The compiler cannot tell the staging buffer from the LDS-DMA
+// destinations of the successor tile (both are runtime offsets into one array), so it answers every LDS read it can see
+// with s_waitcnt vmcnt(0) - and vmcnt also counts this tile's own global STORES: each iteration of the store loop then
+// waited for the previous iteration's stores to reach the L2 (8 round trips per unpooled tile, ~10 % of the tile: the
+// "encode + issue stores" phase of profiles/HISTORY.md).  These reads are invisible to that pass; the buffer really is
+// disjoint from everything in flight (patch_setup.inc), and the wait for the reads themselves is written out too.
+__device__ __forceinline__ unsigned pt_lds_addr(const void* p) {
+  return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+__device__ __forceinline__ void pt_lds_read32(unsigned addr, f32x4& a, f32x4& b) {
+  asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(a), "=&v"(b) : "v"(addr));
+}
+__device__ __forceinline__ void pt_lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 template <int BS>
 struct PatchGeom {
   // WHOLE (BS <= 4): a block is a WHOLE feature map of at most BS x BS pixels (conv5 at 64-pixel crops: 4 x 4), so every
