@@ -78,7 +78,9 @@ extern "C" {
  * -DMMMOT_DEBUG builds; 5 = training backward of the pairwise block (mmmot_gn_bwd_*, mmmot_gemm_tn,
  * mmmot_pair_bwd, mmmot_pair_expand_bwd, mmmot_rowdot_bwd, mmmot_softmax_pairs_bwd, mmmot_fusion_c_bwd, mmmot_add_rows),
  * mmmot_pointnet_layer1 takes K = 3 | 4; mmmot_pn_mlp64 added (additive, still 5);
- * 6 = mmmot_trunk_range_bind (per-caller range-guard counter blocks). */
+ * 6 = mmmot_trunk_range_bind (per-caller range-guard counter blocks); 7 - 9: see the entry points marked so below;
+ * 10 = mmmot_gram_rows at K = 128 writes the 32 x 32 blocks on and above the block diagonal of Gout only (the finalize
+ * entry point mirrors), mmmot_set_gemm_rows_variant: 2 rejected, 3 / 4 = the two forms of the wide kernel. */
 int mmmot_abi_version(void);
 /* returns 0 and fills cu_count / gcn arch string (<=32 bytes) of device 0..; */
 int mmmot_device_info(int device, int* cu_count, char* arch, int arch_len);

@@ -861,7 +861,7 @@ extern "C" int mmmot_softmax_pairs(const float* logits, float* out, const int* g
 }
 
 // ---------------------------------------------------------------------------
-extern "C" int mmmot_abi_version(void) { return 9; }
+extern "C" int mmmot_abi_version(void) { return 10; }
 
 extern "C" int mmmot_device_info(int device, int* cu_count, char* arch, int arch_len) {
   hipDeviceProp_t p;

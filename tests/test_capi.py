@@ -40,7 +40,7 @@ def test_library_builds_and_exports_every_declared_symbol():
 
 def test_abi_version_and_argument_checks_without_gpu():
     lib = _lib.load()
-    assert lib.mmmot_abi_version() == 9
+    assert lib.mmmot_abi_version() == 10
     # contract violations are rejected before any launch (safe on a GPU-less host)
     assert lib.mmmot_gemm_rows(None, None) == -1
     assert lib.mmmot_conv3x3_bn_relu(None, None, None, None, 1, 8, 8, 64, 64, 0, 0, None) == -1

@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 # (--no-profile: the rocprof passes count exactly warm-up + timed steps; extra.kernels comes from the default run above)
 Q="--cpu-pairs 0 --extra-trunks none --no-latency --no-workloads --no-profile"
 # the driver's command line (defaults: cfg3, 16 pairs/step, f16x3; extra: f16q8, hipGraph, the other BASELINE configs, RCCL, latency)
-timeout 600 python $R/bench.py --steps 20 --warmup 5 > $O/bench_default.log 2>&1
+timeout 600 python $R/bench.py --steps 20 --warmup 5 > $O/bench_default.out 2> $O/bench_default.err; cp $R/gpurun_out/bench_detail_n1.json $O/bench_detail_n1.json
 # kernel tables: the headline workload and the other BASELINE configs at their batch sizes
 stats() {  # name, bench arguments
   local name=$1; shift
@@ -53,4 +53,4 @@ timeout 300 python $R/tools/bench_ares.py --rows 4194304 --n 1024 --variants 1 2
 cd $R
 # the tree compiles from clean on the box (no prebuilt objects reused), then the smoke check runs on that build
 ( MMMOT_FORCE_BUILD=1 timeout 900 python -c "import time, __graft_entry__ as g; t = time.time(); print(g.build()); print('forced rebuild of every HIP source: %.0f s' % (time.time() - t)); g.smoke()" ) > $O/smoke_forced_build.log 2>&1
-tail -c 1500 $O/bench_default.log; head -14 $O/rocprofv3_kernel_stats_cfg3_pairs16_f16x3.txt; tail -4 $O/smoke_forced_build.log
+cat $O/bench_default.out | head -c 1200; head -14 $O/rocprofv3_kernel_stats_cfg3_pairs16_f16x3.txt; tail -4 $O/smoke_forced_build.log
