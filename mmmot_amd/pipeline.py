@@ -13,7 +13,7 @@ Here, per frame t:   H2D (image, sweep)  ->  ``prep_points``  ->  ``crop_resize_
 the upload, the gather and the resize run beside / under the forward.  Both orders launch the same kernels on the same
 inputs: their outputs are bitwise equal (tests/test_pipeline_gpu.py).  The solver, ID bookkeeping and the ego-motion
 alignment of the reference's dataset code stay on the host and are not part of this module (the synthetic sequence has
-an identity ego motion).  No CPU fallback: every stage is a C-ABI kernel sequence on the device.
+an identity ego motion; `FrameFeed(point_transform=...)` is the hook for the alignment of a frame's extracted points).  No CPU fallback: every stage is a C-ABI kernel sequence on the device.
 """
 import time
 
@@ -28,10 +28,13 @@ from .tracker_glue import scores_for_solver
 class FrameFeed:
     """Host side of one frame: pinned staging copies of the image and the sweep (what a loader thread would hand over)."""
 
-    def __init__(self, img, sweep, info, dets):
+    def __init__(self, img, sweep, info, dets, point_transform=None):
         self.img = torch.from_numpy(np.ascontiguousarray(img)).pin_memory()
         self.sweep = torch.from_numpy(np.ascontiguousarray(sweep, dtype=np.float32)).pin_memory()
         self.info, self.dets = info, dets
+        # optional: applied to the EXTRACTED points (device tensor [Q, 3|4]) of this frame - where the reference aligns the
+        # second frame of a pair to the first one's coordinates (align_points, dataset/test_seq_dataset.py:199-210)
+        self.point_transform = point_transform
 
 
 class SequencePipeline:
@@ -58,12 +61,13 @@ class SequencePipeline:
         mark()
         # the image-frustum filter and the per-box gather in ONE launch sequence, one split read-back
         pc = prep_points_batched([sweep], [feed.info], [feed.dets], without_reflectivity=self.wo_refl)[0]
+        pts = pc['points'] if feed.point_transform is None else feed.point_transform(pc['points']).contiguous()
         mark()
         crops = crop_resize_u8(img, feed.dets['bbox'], self.size)
         mark()
         if ev is not None:
             ev.append(('prep', marks))
-        return {'crops': crops, 'points': pc['points'], 'split': np.asarray(pc['points_split'], dtype=np.int64),
+        return {'crops': crops, 'points': pts, 'split': np.asarray(pc['points_split'], dtype=np.int64),
                 'n': int(crops.shape[0]), 'ready': None}
 
     def prepare(self, feed):
