@@ -249,6 +249,31 @@ def compact_line(out, limit=LINE_LIMIT):
     return s
 
 
+# stdout belongs to the ONE line: libraries write to the process's stdout too - RCCL prints a version banner through C stdio
+# (block-buffered when stdout is a file or a pipe, so it comes out at EXIT, behind the JSON line: measured on an MI355X with
+# --force-dist), gloo prints its rank lines - and the driver parses the LAST line.  claim_stdout() therefore points file
+# descriptor 1 at stderr for the rest of the process (Python's and every library's output follows it there) and keeps a
+# private duplicate of the real stdout that only emit_line() writes to.
+_REAL_STDOUT = None
+
+
+def claim_stdout():
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_line(text):
+    data = (text + '\n').encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(text + '\n')
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, data)
+
+
 def emit(out, world, detail='stderr'):
     """rank 0: the full record to gpurun_out/bench_detail_n<world>.json and a BENCH_DETAIL line, then the ONE stdout line"""
     name = 'gpurun_out/bench_detail_n%d.json' % world
@@ -261,10 +286,10 @@ def emit(out, world, detail='stderr'):
         out['detail_file'] = None
     full = 'BENCH_DETAIL ' + json.dumps(out)
     if detail == 'stdout':
-        print(full, flush=True)
+        emit_line(full)
     elif detail == 'stderr':
         print(full, file=sys.stderr, flush=True)
-    print(compact_line(out), flush=True)
+    emit_line(compact_line(out))
 
 
 def dry_record(args, world, G, dt, per_rank, gather_ok, place):
@@ -909,6 +934,7 @@ def main():
         return
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         relaunch_under_torchrun(args)  # does not return
+    claim_stdout()
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -971,7 +997,7 @@ def main():
     place = bind_to_gpu_numa_node(local_rank, enable=not args.no_bind)
     telemetry = Telemetry(local_rank)
     if args.latency_only:
-        print(json.dumps(latency_b1(dev, args.trunk)), flush=True)
+        emit_line(json.dumps(latency_b1(dev, args.trunk)))
         return
     dist_on = world > 1 or args.force_dist
     if dist_on:

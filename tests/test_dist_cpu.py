@@ -86,8 +86,10 @@ def test_bench_single_command_launcher_dry_run():
                         '--steps', '3', '--warmup', '1', '--pairs', '3'], capture_output=True, text=True, timeout=300,
                        env=env, cwd=root)
     assert p.returncode == 0, p.stderr[-2000:]
-    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
-    assert len(lines) == 1, p.stdout  # rank 0 only
+    lines = p.stdout.splitlines()
+    # rank 0 only, and NOTHING else on stdout: gloo's rank banners (like RCCL's version banner on the device) go to stderr -
+    # bench.claim_stdout() - because the driver parses the last stdout line
+    assert len(lines) == 1 and lines[0].startswith('{'), p.stdout
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['steps'] == 3 and out['warmup'] == 1 and out['gather_ok'] is True
     assert out['scaling'] == 'weak' and out['config']['pairs_per_step_per_gpu'] == 3
@@ -114,8 +116,8 @@ def test_bench_eight_ranks_uneven_shards_dry_run():
                         '--steps', '2', '--warmup', '1', '--global-pairs', '250'], capture_output=True, text=True,
                        timeout=600, env=env, cwd=root)
     assert p.returncode == 0, p.stderr[-2000:]
-    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
-    assert len(lines) == 1 and len(lines[0]) <= 6000
+    lines = p.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith('{') and len(lines[0]) <= 6000, p.stdout[:2000]
     out = json.loads(lines[0])
     assert out['n_gpus'] == 8 and out['config']['global_pairs'] == 250
     pr = out['per_rank']
