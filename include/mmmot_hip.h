@@ -308,6 +308,11 @@ int mmmot_set_gemm_ares_variant(int v);
 int mmmot_gram_rows(const float* X, int ldx, int K, const float* sc, const float* sh, int ldsc,
                     const int* tile_row0, const int* tile_nrows, const int* tile_group, int T,
                     double* Gout, double* Sout, void* stream);
+/* ABI 10.  tests / A-B: which kernel serves mmmot_gram_rows at K = 128 - 0 = automatic (by the number of super-tiles),
+ * 1 = the four-wave form (two workgroups per CU), 2 = the pipelined eight-wave form (one workgroup per CU, both LDS plane
+ * pairs, two sub-tiles of rows in flight in registers).  Gout / Sout do not depend on it, bit for bit (same blocks, same
+ * summation order per block and per column sum). */
+int mmmot_set_gram128_variant(int v);
 int mmmot_gn_finalize_gram(const double* Gp, const double* Sp, const int* grp_tile0, const int* grp_ntiles,
                            const int* grp_count, int G, int K, const float* W, const float* bias, int N,
                            const float* gamma, const float* beta, float eps, double* work, float* sc,

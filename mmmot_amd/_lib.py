@@ -88,6 +88,7 @@ SIGNATURES = {
     'mmmot_gemm_ares': [ctypes.POINTER(GemmAresArgs), c_f],
     'mmmot_set_gemm_ares_variant': [c_i],
     'mmmot_gram_rows': [c_f, c_i, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_f, c_f, c_f],
+    'mmmot_set_gram128_variant': [c_i],
     'mmmot_gn_finalize_gram': [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_i, c_f, c_f, ctypes.c_float, c_f, c_f, c_f, c_f],
     # Gp, Sp, grp_tile0, grp_ntiles, grp_count, G, tile_nrows, tile_det, K, W, dbias, lddb, N, gamma, beta, eps, work, sc, sh, stream
     'mmmot_gn_finalize_gram_dbias': [c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_f, c_i, c_f, c_f, c_i, c_i, c_f, c_f, ctypes.c_float,

@@ -12,6 +12,8 @@
 //   * Gram tiles are accumulated over 128 rows in fp32 on the matrix cores (3-term hi/lo split of the fp16
 //     operands: products exact to 2^-22), then merged into a COMPENSATED (two-float) running sum per element
 //     and written as float64; tiles/groups are merged and the quadratic forms evaluated in float64.
+#include <atomic>
+
 #include "common.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -332,6 +334,184 @@ __global__ __launch_bounds__(GR_THREADS, 2) void gram_rows128_kernel(const float
   if (tid < 128) Sout[(long)t * K + tid] = sd + sx[tid];
 }
 
+// K = 128, pipelined form: EIGHT waves, both LDS plane pairs (2 x 69.6 KB: sub-tile t is multiplied while sub-tile t + 1
+// is converted into the other pair), the raw rows of sub-tiles t + 2 and t + 3 in flight in registers (2 x 32), ONE barrier
+// per sub-tile.  A wave owns at most 2 of the 10 upper-triangle blocks (32 accumulators + 64 registers of float64 sums), so
+// the prefetch registers fit where the four-wave form above spills.  Blocks per wave (SIMD = wave & 3 in dispatch order
+// 0, 2, 1, 3: at most 3 blocks per SIMD): 0 -> (0,0) (0,1); 1 -> (0,2) (0,3); 2 -> (1,1) (1,2); 3 -> (1,3) (2,2); 4 -> (3,3);
+// 5 -> (2,3); 6, 7 -> none.  Same arithmetic and summation order per block as the four-wave form: bit-identical partials.
+template <int MASK, int NBLK, int A0, int B0, int A1, int B1>
+__device__ __forceinline__ void gr_blocks2(const _Float16* Th, const _Float16* Tl, int lr, int kh, f32x16 (&acc)[2]) {
+#pragma unroll
+  for (int k16 = 0; k16 < GR_ROWS / 16; ++k16) {
+    f16x8 fh[4], fl[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+      if ((MASK >> f) & 1) {
+        const int ch = f * 32 + lr;
+        const int off = ch * GR_LD + (gr_quad<16>((k16 * 16 + kh) >> 2, ch) << 2);
+        fh[f] = *reinterpret_cast<const f16x8*>(&Th[off]);
+        fl[f] = *reinterpret_cast<const f16x8*>(&Tl[off]);
+      }
+    constexpr int AI[2] = {A0, A1}, BI[2] = {B0, B1};
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[AI[b]], fh[BI[b]], acc[b], 0, 0, 0);
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[AI[b]], fl[BI[b]], acc[b], 0, 0, 0);
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[AI[b]], fh[BI[b]], acc[b], 0, 0, 0);
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 1) void gram_rows128p_kernel(const float* __restrict__ X, int ldx,
+                                                                const float* __restrict__ sc, const float* __restrict__ sh,
+                                                                int ldsc, const int* __restrict__ tile_row0,
+                                                                const int* __restrict__ tile_nrows,
+                                                                const int* __restrict__ tile_group,
+                                                                double* __restrict__ Gout, double* __restrict__ Sout) {
+  constexpr int K = 128;
+  constexpr int PLANE = K * GR_LD;  // halves per plane
+  __shared__ __attribute__((aligned(16))) _Float16 T[4 * PLANE];  // [pair 0: hi, lo | pair 1: hi, lo]: 139 KB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, kh = (lane >> 5) * 8;
+  const int t = blockIdx.x;
+  const int row0 = tile_row0[t], nrows = tile_nrows[t];
+  const int grp = tile_group ? tile_group[t] : 0;
+  // staging: thread -> (4 consecutive rows, 8 consecutive channels).  The 16 lanes of a store group are 8 channel octets
+  // x 2 row quads (tid bits: [0:2] octet low, [3] quad bit 0, [4] octet high, [5:8] quad / 2): with gr_quad's permutation
+  // they hit 16 different bank pairs
+  constexpr int CPT = 8;
+  const int sq = (tid & 7) | ((tid >> 1) & 8);
+  const int sr4 = 4 * (((tid >> 3) & 1) | ((tid >> 5) << 1));
+  const float* ps = sc + (long)grp * ldsc + sq * CPT;
+  const float* ph = sh + (long)grp * ldsc + sq * CPT;
+  double gd[2][16];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) gd[b][e] = 0.0;
+  double sd = 0.0;  // threads < 256: column sum of channel tid & 127 over rows 64 (tid >> 7) .. + 63 of every sub-tile
+  const int nsub = (nrows + GR_ROWS - 1) / GR_ROWS;
+
+  f32x4 xr[2][2][4];  // [buffer][channel quad][row]: two sub-tiles in flight
+  auto load_sub = [&](int u, f32x4 (&dst)[2][4]) {
+    const int r0 = u * GR_ROWS;
+    const int nr = min(GR_ROWS, nrows - r0);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const bool rv = sr4 + rr < nr;  // rows past the end read row 0 of the sub-tile (mapped) and are zeroed when converted
+        dst[q][rr] = *reinterpret_cast<const f32x4*>(X + (long)(row0 + r0 + (rv ? sr4 + rr : 0)) * ldx + sq * CPT + 4 * q);
+      }
+  };
+  auto convert_sub = [&](int u, const f32x4 (&src)[2][4], int pair) {
+    const int nr = min(GR_ROWS, nrows - u * GR_ROWS);
+    const bool full = (nr == GR_ROWS);
+    _Float16* Th = T + pair * 2 * PLANE;
+    _Float16* Tl = Th + PLANE;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      // (scale / shift of the 8 channels are re-read per sub-tile - L2 hits - instead of held in 16 registers)
+      const f32x4 s4 = *reinterpret_cast<const f32x4*>(ps + 4 * q), h4 = *reinterpret_cast<const f32x4*>(ph + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float y[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          y[rr] = __builtin_amdgcn_fmed3f(fmaf(src[q][rr][e], s4[e], h4[e]), 0.f, 65000.f);  // ReLU + fp16 range clamp
+          if (!full && sr4 + rr >= nr) y[rr] = 0.f;
+        }
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        unsigned h01, l01, h23, l23;
+        mm_split2(y[0], y[1], h01, l01);
+        mm_split2(y[2], y[3], h23, l23);
+        const int c = sq * CPT + 4 * q + e;
+        const int o = c * GR_LD + (gr_quad<16>(sr4 >> 2, c) << 2);
+        *reinterpret_cast<u32x2*>(&Th[o]) = u32x2{h01, h23};
+        *reinterpret_cast<u32x2*>(&Tl[o]) = u32x2{l01, l23};
+      }
+    }
+  };
+  // prologue: sub-tiles 0 and 1 requested, 0 converted, 2 requested
+  load_sub(0, xr[0]);
+  if (nsub > 1) load_sub(1, xr[1]);
+  convert_sub(0, xr[0], 0);
+  if (nsub > 2) load_sub(2, xr[0]);
+  __syncthreads();
+  for (int u = 0; u < nsub; ++u) {
+    const int pair = u & 1;
+    const _Float16* Th = T + pair * 2 * PLANE;
+    const _Float16* Tl = Th + PLANE;
+    // the next sub-tile into the other plane pair (every wave finished reading it before the previous barrier), then its
+    // registers take the sub-tile after next
+    if (u + 1 < nsub) {
+      if (pair == 0) convert_sub(u + 1, xr[1], 1);
+      else convert_sub(u + 1, xr[0], 0);
+    }
+    if (u + 3 < nsub) {
+      if (pair == 0) load_sub(u + 3, xr[1]);
+      else load_sub(u + 3, xr[0]);
+    }
+    if (tid < 256) {  // column sums: thread -> one channel, 64 rows - the partition and order of the four-wave form (same bits)
+      const int c = tid & 127, rb = (tid >> 7) * 64;
+      float a = 0.f;
+#pragma unroll 4
+      for (int r8 = 0; r8 < 64; r8 += 8) {
+        const f16x8 hh = *reinterpret_cast<const f16x8*>(&Th[c * GR_LD + rb + r8]);
+        const f16x8 ll = *reinterpret_cast<const f16x8*>(&Tl[c * GR_LD + rb + r8]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a += (float)hh[e] + (float)ll[e];
+      }
+      sd += (double)a;
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+    if (wave == 0) gr_blocks2<0x3, 2, 0, 0, 0, 1>(Th, Tl, lr, kh, acc);
+    else if (wave == 1) gr_blocks2<0xD, 2, 0, 2, 0, 3>(Th, Tl, lr, kh, acc);
+    else if (wave == 2) gr_blocks2<0x6, 2, 1, 1, 1, 2>(Th, Tl, lr, kh, acc);
+    else if (wave == 3) gr_blocks2<0xE, 2, 1, 3, 2, 2>(Th, Tl, lr, kh, acc);
+    else if (wave == 4) gr_blocks2<0x8, 1, 3, 3, 3, 3>(Th, Tl, lr, kh, acc);
+    else if (wave == 5) gr_blocks2<0xC, 1, 2, 3, 2, 3>(Th, Tl, lr, kh, acc);
+    if (wave < 6) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) gd[b][e] += (double)acc[b][e];
+    }
+    __syncthreads();
+  }
+  double* G = Gout + (long)t * K * K;
+  auto put = [&](int b, int bi, int bj) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) G[(long)(bi * 32 + mm_acc_row(e, lane)) * K + bj * 32 + lr] = gd[b][e];
+  };
+  if (wave == 0) { put(0, 0, 0); put(1, 0, 1); }
+  else if (wave == 1) { put(0, 0, 2); put(1, 0, 3); }
+  else if (wave == 2) { put(0, 1, 1); put(1, 1, 2); }
+  else if (wave == 3) { put(0, 1, 3); put(1, 2, 2); }
+  else if (wave == 4) put(0, 3, 3);
+  else if (wave == 5) put(0, 2, 3);
+  // the two row halves of every channel's sum meet in LDS (the planes are free: the loop ended with a barrier)
+  double* sx = reinterpret_cast<double*>(T);
+  if (tid >= 128 && tid < 256) sx[tid - 128] = sd;
+  __syncthreads();
+  if (tid < 128) Sout[(long)t * K + tid] = sd + sx[tid];
+}
+
+static std::atomic<int> g_gram128_variant{0};
+// Test / A-B knob: 0 = automatic (by the number of super-tiles), 1 = the four-wave form with two workgroups per CU,
+// 2 = the pipelined eight-wave form.  Gout / Sout do not depend on it (bit for bit).
+extern "C" int mmmot_set_gram128_variant(int v) {
+  if (v < 0 || v > 2) return MMMOT_EINVAL;
+  g_gram128_variant.store(v);
+  return MMMOT_OK;
+}
+
 // sum of the super-tile partials of every group -> covariance and mean of the group's rows:
 // red[g][K*K + K] doubles = Cov(a) (K x K), then E[a] (K).  Every thread also re-adds the two column sums its element
 // needs (nt <= a few dozen terms each) so that the covariance is formed ONCE per group here instead of once per
@@ -467,7 +647,15 @@ extern "C" int mmmot_gram_rows(const float* X, int ldx, int K, const float* sc, 
   if (!X || !sc || !sh || !tile_row0 || !tile_nrows || !Gout || !Sout || T <= 0) return MMMOT_EINVAL;
   if ((K != 64 && K != 128) || ldx % 4 != 0 || ldsc % 4 != 0 || !mm_al16(X) || !mm_al16(sc) || !mm_al16(sh))
     return MMMOT_EINVAL;
-  if (K == 128)
+  // (measured, tools/bench_gram.py: 245 super-tiles 0.163 ms pipelined / 0.222 four-wave; 1 024: 0.70 / 0.65; 2 048: 1.31 / 1.28 -
+  // one workgroup per CU with everything prefetched wins while the launch is a single round of workgroups, two workgroups
+  // per CU once there are several)
+  const int gv = g_gram128_variant.load();
+  const bool pipelined = gv == 2 || (gv == 0 && T <= 2 * mm_num_cu());
+  if (K == 128 && pipelined)
+    hipLaunchKernelGGL(gram_rows128p_kernel, dim3(T), dim3(512), 0, s, X, ldx, sc, sh, ldsc, tile_row0, tile_nrows,
+                       tile_group, Gout, Sout);
+  else if (K == 128)
     hipLaunchKernelGGL(gram_rows128_kernel, dim3(T), dim3(GR_THREADS), 0, s, X, ldx, sc, sh, ldsc, tile_row0, tile_nrows,
                        tile_group, Gout, Sout);
   else

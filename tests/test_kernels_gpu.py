@@ -676,6 +676,17 @@ def test_gram_statistics_match_direct_statistics(hip, K, N):
     else:
         Gp_full = Gp
     close(Gp_full.float(), Ge.float(), 2e-6, 'Gram partials')
+    if K == 128:  # the two forms of the K = 128 kernel (four waves x two workgroups per CU / eight waves, pipelined): same bits
+        from mmmot_amd import _lib
+        lib = _lib.load()
+        outs = []
+        for v in (1, 2):
+            assert lib.mmmot_set_gram128_variant(v) == 0
+            G2, S2 = torch.zeros_like(Gp), torch.zeros_like(Sp)
+            hip.gram_rows(X.cuda(), K, sc.cuda(), sh.cuda(), gpu, G2, S2)
+            outs.append((G2, S2))
+        assert lib.mmmot_set_gram128_variant(0) == 0
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     scg, shg = torch.zeros(2, N).cuda(), torch.zeros(2, N).cuda()
     work = torch.zeros(2, K * K + K, dtype=torch.float64).cuda()
     hip.gn_finalize_gram(Gp, Sp, gpu, K, W.cuda(), bias.cuda(), N, gamma.cuda(), beta.cuda(), 1e-5, work, scg, shg)
