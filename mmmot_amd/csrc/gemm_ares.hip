@@ -424,6 +424,7 @@ __global__ __launch_bounds__(AR_THREADS) void gemm_ares_kernel(mmmot_gemm_ares_a
 
 int mmmot_gemm_wres64_launch(const mmmot_gemm_ares_args* a, int mode, int n_cu, hipStream_t s);  // gemm_wres.hip
 int mmmot_gemm_wreg128_try(const mmmot_gemm_ares_args* a, int mode, int n_cu, hipStream_t s, int* status);  // gemm_wreg.hip
+int mmmot_ares_variant();                                                                                  // gemm_wreg.hip
 
 extern "C" int mmmot_gemm_ares(const mmmot_gemm_ares_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -444,7 +445,8 @@ extern "C" int mmmot_gemm_ares(const mmmot_gemm_ares_args* a, void* stream) {
     const char* e = getenv("MMMOT_ARES_WRES");
     return !(e && e[0] == '0');
   }();
-  if (use_wres && a->K == 64 && a->N <= 512) return mmmot_gemm_wres64_launch(a, mode, n_cu, s);
+  const bool stream_only = mmmot_ares_variant() == 1 && a->N % AR_BN == 0;  // mmmot_set_gemm_ares_variant(1)
+  if (use_wres && !stream_only && a->K == 64 && a->N <= 512) return mmmot_gemm_wres64_launch(a, mode, n_cu, s);
   // K = 128 consumer pass on a launch that fills the chip: the wave's weights live in registers (gemm_wreg.hip)
   int wst = MMMOT_OK;
   if (mmmot_gemm_wreg128_try(a, mode, n_cu, s, &wst)) return wst;

@@ -386,14 +386,16 @@ __global__ __launch_bounds__(512, 1) void gemm_wreg128_kernel(mmmot_gemm_ares_ar
 }
 
 static std::atomic<int> g_ares_variant{0};
-// Test knob: 0 = automatic (the register-resident kernel for the K = 128 consumer pass when the launch fills the chip),
-// 1 = the streaming kernel only, 2 = the register-resident kernel whenever the layer is eligible.  Results do not depend
-// on it (bit for bit).
+// Test knob: 0 = automatic (K = 128: the register-resident kernel for the consumer pass when the launch fills the chip;
+// K = 64: the independent-wave kernel of gemm_wres.hip for a column-sum pass that gives every wave a run of half tiles),
+// 1 = the streaming kernel only, 2 = the register-resident / independent-wave kernel whenever the layer is eligible,
+// 3 = K = 64: the two-barrier weight-resident kernel only (K = 128: as 0).  Results do not depend on it (bit for bit).
 extern "C" int mmmot_set_gemm_ares_variant(int v) {
-  if (v < 0 || v > 2) return MMMOT_EINVAL;
+  if (v < 0 || v > 3) return MMMOT_EINVAL;
   g_ares_variant.store(v);
   return MMMOT_OK;
 }
+int mmmot_ares_variant() { return g_ares_variant.load(); }
 
 // Called by mmmot_gemm_ares after its argument checks; returns 1 when this kernel took the launch.
 int mmmot_gemm_wreg128_try(const mmmot_gemm_ares_args* a, int mode, int n_cu, hipStream_t s, int* status) {
@@ -403,7 +405,7 @@ int mmmot_gemm_wreg128_try(const mmmot_gemm_ares_args* a, int mode, int n_cu, hi
   if (a->ldosc % 4 != 0 || a->ldsc % 4 != 0 || (a->dbias && a->lddb % 4 != 0)) return 0;  // 16-byte LDS-DMA pieces
   const int nh = a->N / 512;
   // the launch must fill the chip with whole (tile sequence x channel half) groups of 8 workgroups per XCD
-  if (variant == 0 && (long)a->T * nh < 2L * n_cu) return 0;
+  if (variant != 2 && (long)a->T * nh < 2L * n_cu) return 0;
   int groups = n_cu / (8 * nh);                 // sequences of 8 workgroups per channel half
   if (groups < 1) groups = 1;
   const int need = (a->T + 7) / 8;              // sequences of 8 tiles there are

@@ -283,8 +283,252 @@ __global__ __launch_bounds__(WR_THREADS) void gemm_wres64_kernel(mmmot_gemm_ares
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Column-sum pass with INDEPENDENT waves (round 6).  The two-barrier kernel above sat at 52 % MFMA-busy: eight waves meet
+// twice per 128-row tile around a staging area, and a wave's register epilogue overlaps nothing of its own.  Here
+//   * a wave owns a 64-row half tile for ALL of the layer's 32-channel blocks (up to 16): its A fragments are generated in
+//     registers straight from global loads in fragment layout (lane = row, 32 B per 16-k step - the pattern of
+//     gemm_wide's source rows), so the rows never pass through LDS and no other wave needs them;
+//   * the only shared state is the weight planes, written once: after that barrier a wave never synchronises again, and
+//     the two waves of a SIMD drift apart until one's epilogue / conversion VALU runs under the other's MFMAs;
+//   * a wave walks a CONTIGUOUS run of half tiles, so the prologue scale / shift (a 512 B LDS slot per wave) and the
+//     epilogue constants change once per detection, not once per item.  The epilogue table costs 16 registers: lanes
+//     0-31 of tab[i] hold m1 of channel 32 i + lane, lanes 32-63 hold m0, one v_permlane32_swap per block hands both to
+//     every lane;
+//   * the next item's rows (64 registers) are requested right after the conversion of the current ones and land during
+//     its 384 MFMAs; tile-table words come by s_load.
+// Same MFMA order per accumulator, same per-lane summation order, same half-wave exchange as above and as gemm_ares:
+// the column sums are bit-identical (tests/test_kernels_gpu.py).  Ragged half tiles (a detection's tail) take a compact
+// loop with the constants read per block.
+#ifndef WI_PIN
+#define WI_PIN 0
+#endif
+struct WiItem {
+  int row0, nrows, grp, dbrow;  // of the item's 128-row tile
+};
+
+__global__ __launch_bounds__(WR_THREADS) void gemm_wres64i_kernel(mmmot_gemm_ares_args a) {
+  __shared__ __attribute__((aligned(16))) _Float16 Wh[WR_NMAX * 64];
+  __shared__ __attribute__((aligned(16))) _Float16 Wl[WR_NMAX * 64];
+  __shared__ __attribute__((aligned(16))) float Nrm[WR_THREADS / 64][2][64];  // per wave: prologue scale | shift
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  const int nblk = a.N >> 5;  // 32-channel blocks: 4, 8, 12 or 16
+  {
+    const u32x4* wp = reinterpret_cast<const u32x4*>(a.W);
+    for (int idx = tid; idx < a.N * 8; idx += WR_THREADS) {
+      const int n = idx >> 3, u = idx & 7;
+      const u32x4 hi = wp[(long)idx * 2], lo = wp[(long)idx * 2 + 1];
+      *reinterpret_cast<u32x4*>(&Wh[wr_off(n, u)]) = hi;
+      *reinterpret_cast<u32x4*>(&Wl[wr_off(n, u)]) = lo;
+    }
+  }
+  __syncthreads();  // the only one
+  // this wave's run of half tiles: [h, hend)
+  const int H = 2 * a.T, nw = gridDim.x * (WR_THREADS / 64), gw = blockIdx.x * (WR_THREADS / 64) + wave;
+  const int q = H / nw, rem = H % nw;
+  int h = gw * q + (gw < rem ? gw : rem);
+  const int hend = h + q + (gw < rem ? 1 : 0);
+  if (h >= hend) return;
+
+  // tile-table words of item hh by scalar loads (see gemm_wreg.hip: one asm block with its wait, early-clobber outputs)
+  auto item = [&](int hh) {
+    const int t = hh >> 1;
+    const int* p0 = a.tile_row0 + t;
+    const int* p1 = a.tile_nrows + t;
+    const int* p2 = a.tile_group ? a.tile_group + t : p0;
+    const int* p3 = a.dbias ? a.tile_dbrow + t : p0;
+    int v0, v1, v2, v3;
+    asm volatile(
+        "s_load_dword %0, %4, 0x0\n\t"
+        "s_load_dword %1, %5, 0x0\n\t"
+        "s_load_dword %2, %6, 0x0\n\t"
+        "s_load_dword %3, %7, 0x0\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(v0), "=&s"(v1), "=&s"(v2), "=&s"(v3)
+        : "s"(p0), "s"(p1), "s"(p2), "s"(p3)
+        : "memory");
+    WiItem m;
+    m.row0 = v0;
+    m.nrows = v1;
+    m.grp = a.tile_group ? v2 : 0;
+    m.dbrow = a.dbias ? v3 : 0;
+    return m;
+  };
+  // the item's 64 rows in fragment layout: lane (lr, lh) holds k = 16 j + 8 lh .. + 7 of rows lr and 32 + lr; rows past
+  // the tile read its first row (their fragments are zeroed)
+  f32x4 raw[2][4][2];
+  auto request = [&](const WiItem& m, int wm) {
+    const float* base = a.X + (long)m.row0 * a.ldx;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int rr = wm * 64 + b * 32 + lr;
+      const float* p = base + (unsigned)(rr < m.nrows ? rr : 0) * (unsigned)a.ldx + 8 * lh;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        raw[b][j][0] = *reinterpret_cast<const f32x4*>(p + 16 * j);
+        raw[b][j][1] = *reinterpret_cast<const f32x4*>(p + 16 * j + 4);
+      }
+    }
+  };
+  f16x8 af[4][4];  // [k16 step][hi rows 0-31, lo rows 0-31, hi rows 32-63, lo rows 32-63]
+  auto convert = [&](int nsub) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float* ps = &Nrm[wave][0][16 * j + 8 * lh];
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(ps), s1 = *reinterpret_cast<const f32x4*>(ps + 4);
+      const f32x4 t0 = *reinterpret_cast<const f32x4*>(ps + 64), t1 = *reinterpret_cast<const f32x4*>(ps + 68);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const bool ok = b * 32 + lr < nsub;
+        float y[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          y[e] = fminf(fmaxf(fmaf(raw[b][j][0][e], s0[e], t0[e]), 0.f), 65000.f);
+          y[4 + e] = fminf(fmaxf(fmaf(raw[b][j][1][e], s1[e], t1[e]), 0.f), 65000.f);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (!ok) y[e] = 0.f;
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mm_split2(y[2 * e], y[2 * e + 1], hi[e], lo[e]);
+        af[j][2 * b] = __builtin_bit_cast(f16x8, u32x4{hi[0], hi[1], hi[2], hi[3]});
+        af[j][2 * b + 1] = __builtin_bit_cast(f16x8, u32x4{lo[0], lo[1], lo[2], lo[3]});
+      }
+    }
+  };
+  // epilogue constants of channel n under (grp, dbrow): the consumer's relu(acc * m1 + m0), as in the kernel above
+  auto consts_of = [&](const WiItem& m, int n, float& m1v, float& m0v) {
+    const float pb = a.bias ? a.bias[n] : 0.f;
+    const float db = (a.dbias ? a.dbias + (long)m.dbrow * a.lddb : wr_zeros)[n];
+    const float o = a.osc[(long)m.grp * a.ldosc + n];
+    const float cb = pb + db;
+    m1v = a.oscale * o;
+    m0v = fmaf(cb, o, a.osh[(long)m.grp * a.ldosc + n]);
+  };
+  float tab[16];
+  auto build_tab = [&](const WiItem& m) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      tab[i] = 0.f;
+      if (i < nblk) {
+        float m1v, m0v;
+        consts_of(m, i * 32 + lr, m1v, m0v);
+        tab[i] = lh ? m0v : m1v;
+      }
+    }
+  };
+  f16x8 bh[2], bl[2];
+  auto read_b = [&](int n, int j, int slot) {
+    bh[slot] = *reinterpret_cast<const f16x8*>(&Wh[wr_off(n, 2 * j + lh)]);
+    bl[slot] = *reinterpret_cast<const f16x8*>(&Wl[wr_off(n, 2 * j + lh)]);
+  };
+  auto mma_block = [&](f32x16 (&acc)[2], int n_next, bool have_next) {
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[tm][e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int sl = j & 1;
+      if (j < 3) read_b(n_next - 32, j + 1, sl ^ 1);
+      else if (have_next) read_b(n_next, 0, sl ^ 1);
+#if WI_PIN
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j][1], bh[sl], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j][3], bh[sl], acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j][0], bl[sl], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j][2], bl[sl], acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j][0], bh[sl], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j][2], bh[sl], acc[1], 0, 0, 0);
+    }
+  };
+
+  WiItem cur = item(h), nxt = cur;
+  if (h + 1 < hend) nxt = item(h + 1);
+  request(cur, h & 1);
+  int tab_grp = -1, tab_db = -1, nrm_grp = -1;
+  for (;;) {
+    const int wm = h & 1;
+    const int nsub = min(max(cur.nrows - 64 * wm, 0), 64);  // valid rows of the item
+    const bool more = h + 1 < hend;
+    if (nsub > 0) {
+      if (cur.grp != nrm_grp) {
+        const float sv = a.sc[(long)cur.grp * a.ldsc + lane], hv = a.sh[(long)cur.grp * a.ldsc + lane];
+        Nrm[wave][0][lane] = sv;
+        Nrm[wave][1][lane] = hv;
+        nrm_grp = cur.grp;
+      }
+      if (nsub == 64 && (cur.grp != tab_grp || cur.dbrow != tab_db)) {
+        build_tab(cur);
+        tab_grp = cur.grp;
+        tab_db = cur.dbrow;
+      }
+      convert(nsub);
+    }
+    WiItem nn = nxt;
+    if (more) {
+      request(nxt, (h + 1) & 1);
+      if (h + 2 < hend) nn = item(h + 2);
+    }
+    float* out = a.colsum + (long)h * a.N;
+    if (nsub == 64) {
+      read_b(lr, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (i < nblk) {
+          float m1i = tab[i], m0i = tab[i];  // -> (lanes 0-31 of tab[i], lanes 32-63 of tab[i]) on every lane
+          asm volatile("s_nop 3\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 3" : "+v"(m1i), "+v"(m0i));
+          f32x16 acc[2];
+          mma_block(acc, (i + 1) * 32 + lr, i + 1 < nblk);
+          float s3 = mm_relu_sum32(acc[0], acc[1], m1i, m0i);
+          s3 = mm_xor32_sum(s3);
+          if (lane < 32) out[i * 32 + lr] = s3;
+        }
+      }
+    } else if (nsub > 0) {
+      const int lim = nsub - 4 * lh;  // row of accumulator element (tm, e) = tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh
+      read_b(lr, 0, 0);
+      for (int i = 0; i < nblk; ++i) {
+        float m1i, m0i;
+        consts_of(cur, i * 32 + lr, m1i, m0i);
+        f32x16 acc[2];
+        mma_block(acc, (i + 1) * 32 + lr, i + 1 < nblk);
+        float s3 = 0.f;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            if (tm * 32 + (e & 3) + 8 * (e >> 2) < lim) s3 += fmaxf(fmaf(acc[tm][e], m1i, m0i), 0.f);
+        s3 = mm_xor32_sum(s3);
+        if (lane < 32) out[i * 32 + lr] = s3;
+      }
+    } else {
+      if (lane < 32)
+        for (int i = 0; i < nblk; ++i) out[i * 32 + lr] = 0.f;
+    }
+    if (!more) break;
+    cur = nxt;
+    nxt = nn;
+    ++h;
+  }
+}
+
+int mmmot_ares_variant();  // gemm_wreg.hip
+
 // K = 64, N <= 512: called by mmmot_gemm_ares (gemm_ares.hip) after its argument checks
 int mmmot_gemm_wres64_launch(const mmmot_gemm_ares_args* a, int mode, int n_cu, hipStream_t s) {
+  // column-sum pass: independent waves when every wave gets a run of half tiles (a small launch is better balanced in
+  // 128-row tiles over eight waves); variant 2 = whenever eligible, 3 = never (tests, A/B).  Bit-identical either way.
+  const int variant = mmmot_ares_variant();
+  if (mode == 2 && variant != 3 && (variant == 2 || 2L * a->T >= 4L * 8 * n_cu)) {
+    const int wgs = (2 * a->T + 7) / 8;
+    hipLaunchKernelGGL(gemm_wres64i_kernel, dim3(wgs < n_cu ? wgs : n_cu), dim3(WR_THREADS), 0, s, *a);
+    return mm_check(hipGetLastError());
+  }
   const int grid = a->T < n_cu ? a->T : n_cu;  // persistent: one workgroup per CU (LDS: all 160 KB)
   if (mode == 1)
     hipLaunchKernelGGL(gemm_wres64_kernel<1>, dim3(grid), dim3(WR_THREADS), 0, s, *a);

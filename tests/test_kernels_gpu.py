@@ -592,6 +592,67 @@ def test_gemm_ares_weights_in_registers_kernel(hip, N, dets, with_dbias):
         assert torch.equal(outs[2], outs[1]), 'register-resident and streaming kernels differ'
 
 
+@pytest.mark.parametrize('seed', [0, 1, 2, 3, 4, 5, 6, 7])
+def test_gemm_ares_k64_independent_wave_kernel_bitwise(hip, seed):
+    """the K = 64 column-sum pass on the independent-wave kernel (csrc/gemm_wres.hip, gemm_wres64i_kernel: a wave owns a
+    64-row half tile for every channel block, A fragments straight from global loads) against the two-barrier
+    weight-resident kernel and the streaming kernel: random detection sizes (ragged tiles, empty second halves, one-row
+    tiles; seed 7: more waves than half tiles), with and without per-detection bias rows, N = 128 .. 512 - bitwise, twice;
+    and against the float64 emulation"""
+    from mmmot_amd import _lib
+    from mmmot_amd.pack import hl16_weight_shift, to_hl16
+    from mmmot_amd.plan import HalfTiles
+    lib = _lib.load()
+    rng = np.random.default_rng(2000 + seed)
+    K = 64
+    N = int(rng.choice([128, 256, 384, 512]))
+    G = int(rng.integers(1, 4))
+    sizes = [1, 31, 32, 33, 64, 65, 127, 128, 129, 300, 1000, 2048, 3000]
+    ndets = int(rng.integers(3, 40)) if seed != 7 else 2
+    dets = [[int(v) for v in rng.choice(sizes, size=ndets)] for _ in range(G)]
+    if seed in (2, 3):  # long runs of full tiles: every wave walks several items, the table changes mid-run
+        dets = [d + [2048] * 150 for d in dets]
+    with_dbias = bool(seed & 1)
+    counts = [sum(d) for d in dets]
+    gpu = RowTiles(counts, 'cuda', sub_counts=dets)
+    cpu = RowTiles(counts, 'cpu', sub_counts=dets)
+    hc = HalfTiles(cpu, 'cpu')
+    flat = [c for d in dets for c in d]
+    ndet, R = len(flat), sum(counts)
+    X = rnd(R, K, seed=400 + seed) + 0.5
+    W = rnd(N, K, seed=401 + seed, scale=K ** -0.5)
+    bias = rnd(N, seed=402 + seed)
+    sc, sh = rnd(G, K, seed=403 + seed).abs() + 0.5, rnd(G, K, seed=404 + seed)
+    dbias = rnd(ndet, N, seed=405 + seed) if with_dbias else None
+    tile_det = torch.repeat_interleave(torch.arange(ndet), torch.tensor(cpu.h_sub_ntiles).long()).int()
+    osc, osh = rnd(G, N, seed=406 + seed).abs() + 0.5, rnd(G, N, seed=407 + seed)
+    shift = hl16_weight_shift(W)
+    W16 = to_hl16(W.double() * 2.0 ** shift)
+    outs = []
+    try:
+        for v in (3, 2, 2, 1, 0):
+            assert lib.mmmot_set_gemm_ares_variant(v) == 0
+            cg = torch.full((hc.T, N), float('nan')).cuda()
+            hip.gemm_ares(W16.cuda(), 2.0 ** -shift, gpu, N, K, X.cuda(), sc.cuda(), sh.cuda(), bias=bias.cuda(),
+                          dbias=dbias.cuda() if with_dbias else None, tile_dbrow=tile_det.cuda() if with_dbias else None,
+                          osc=osc.cuda(), osh=osh.cuda(), colsum=cg)
+            outs.append(cg.cpu())
+    finally:
+        assert lib.mmmot_set_gemm_ares_variant(0) == 0
+    assert not torch.isnan(outs[1]).any()
+    assert torch.equal(outs[1], outs[2]), 'independent-wave kernel: two launches differ'
+    assert torch.equal(outs[1], outs[0]), 'independent-wave and two-barrier kernels differ'
+    assert torch.equal(outs[1], outs[4]), 'automatic choice differs'
+    if N % 256 == 0:
+        assert torch.equal(outs[1], outs[3]), 'independent-wave and streaming kernels differ'
+    if seed < 2:
+        emu = TorchOps(torch.float64)
+        cs = torch.zeros(hc.T, N, dtype=torch.float64)
+        emu.gemm_ares(W16, 2.0 ** -shift, cpu, N, K, X, sc, sh, bias=bias, dbias=dbias,
+                      tile_dbrow=tile_det if with_dbias else None, osc=osc, osh=osh, colsum=cs)
+        close(outs[1], cs.float(), 1e-5, 'independent-wave kernel: column sums')
+
+
 @pytest.mark.parametrize('seed', [0, 1, 2, 3, 4, 5])
 def test_gemm_ares_register_kernel_random_tilings_bitwise(hip, seed):
     """the pipelined register-weights kernel against the streaming kernel on random detection sizes (1 .. 3000 points:

@@ -18,9 +18,10 @@ from mmmot_amd.plan import HalfTiles, RowTiles  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--rows', type=int, default=1 << 20)
+    ap.add_argument('--modes', nargs='*', default=['stats', 'colsum'])
     ap.add_argument('--k', type=int, default=128)
     ap.add_argument('--n', type=int, nargs='*', default=[128, 256, 512, 1024])
-    ap.add_argument('--variants', type=int, nargs='*', default=[0], help='mmmot_set_gemm_ares_variant values to time (1 = streaming kernel, 2 = weights in registers)')
+    ap.add_argument('--variants', type=int, nargs='*', default=[0], help='mmmot_set_gemm_ares_variant values to time (1 = streaming kernel, 2 = weights in registers / independent waves, 3 = K = 64 two-barrier kernel)')
     a = ap.parse_args()
     ops = HipOps()
     R, K = a.rows, a.k
@@ -37,7 +38,7 @@ def main():
         part = torch.empty(half.T, 2, N).cuda()
         cs = torch.empty(half.T, N).cuda()
         osc, osh = torch.ones(1, N).cuda(), torch.zeros(1, N).cuda()
-        for mode, var in [(m, v) for m in ('stats', 'colsum') for v in a.variants]:
+        for mode, var in [(m, v) for m in a.modes for v in a.variants]:
             ops.lib.mmmot_set_gemm_ares_variant(var)
             kw = dict(part=part) if mode == 'stats' else dict(osc=osc, osh=osh, colsum=cs)
             ts = []
