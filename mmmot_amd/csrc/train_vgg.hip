@@ -200,121 +200,166 @@ extern "C" int mmmot_conv3x3_wgrad(const float* dZ, const float* A, int L, int H
   return mm_check(hipGetLastError());
 }
 
-// ---- the same weight gradient on the fp16 matrix cores (3-term hi/lo split), round 4 ----
+// ---- the same weight gradient on the fp16 matrix cores (3-term hi/lo split) ----
 // The fp32 kernel above feeds v_mfma_f32_32x32x2_f32 two pixels per instruction from two scalar global loads per lane and
 // re-reads dZ / A once per (channel tile, tap): it is load-latency-bound and was most of the 63 ms of the whole-network
-// backward (round 3).  Here, like gemm_tn_f16.hip: a chunk of 128 pixels of dZ (TN output channels, scaled by the power of
-// two that puts max |dZ| at 2^10 - gradients sit in fp16's subnormals otherwise) and of the tap-shifted, image-masked A
-// (TK input channels) is staged TRANSPOSED into LDS as hi / lo fp16 planes ([channel][pixel]), the pixel axis is the
-// K = 16 of v_mfma_f32_32x32x16_f16, 4 waves own 2 x 2 quadrants of the TN x TK tile.  grid = (Cout / TN, Cin / TK,
-// 9 * nsplit); partial dW per pixel share like the fp32 kernel (same layout: [share][tap][Cout][Cin]).
+// backward (round 3).  Round 4 moved it to the fp16 matrix cores with one workgroup per (channel tile, tap, pixel share):
+// load -> convert -> transposed LDS store -> barrier -> MFMA, strictly in sequence, dZ and A re-read and re-converted by
+// each of the nine taps (0.1 of the matrix-core ceiling; the 64-channel layers were bound by 5 GB of re-reads).
+// Round 6 (this kernel): a workgroup owns a ROW of taps (dy fixed, dx = -1, 0, 1):
+//   * a chunk of 64 pixels of dZ (TN output channels, scaled by the power of two that puts max |dZ| at 2^10 - gradients
+//     sit in fp16's subnormals otherwise) is staged ONCE for the three taps; the 66 pixels of A the three taps touch are
+//     loaded once, converted once, and written as three dx-shifted, image-masked copies (fragment reads stay 16-byte
+//     aligned): a third of the loads and conversions per tap, dZ read 3 times per layer instead of 9;
+//   * the NEXT chunk's rows are requested (80 registers per thread) before the chunk's 144 MFMAs per wave and land under
+//     them; the only serial part is convert + transposed store;
+//   * LDS rows are [channel][pixel] hi / lo fp16 planes with the pixel axis as the K = 16 of v_mfma_f32_32x32x16_f16;
+//     channel 4 q + e of the tile lives in row e * (T / 4) + q, so that the staging lanes (consecutive q: one coalesced
+//     row segment per pixel in global memory) write consecutive LDS rows - 144-byte stride, every bank once - instead
+//     of rows four apart (eight lanes per bank); the epilogue undoes the relabelling.
+// 4 waves own 2 x 2 quadrants of the TN x TK tile, three accumulator sets each.  grid = (Cout / TN, Cin / TK, 3 * nsplit);
+// partial dW per pixel share in the fp32 kernel's layout [share][tap][Cout][Cin].
 typedef _Float16 wg_f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 wg_f16x4 __attribute__((ext_vector_type(4)));
-#define WG_ROWS 128
-#define WG_LD 136
+typedef unsigned int wg_u32x2 __attribute__((ext_vector_type(2)));
+#define WG_PX 64  // pixels per chunk
+#define WG_LD 72  // halves per LDS row: 144 B (36 dwords: 32 consecutive rows x 16 bytes touch every bank once)
 
 template <int TN, int TK>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_f16_kernel(const float* __restrict__ dZ, const float* __restrict__ A,
                                                                 int L, int H, int W, int Cin, int Cout, int nsplit,
                                                                 float* __restrict__ dW, const float* __restrict__ dzamax) {
-  constexpr int WN = TN / 64, WK = TK / 64;
+  constexpr int WN = TN / 64, WK = TK / 64;  // 32 x 32 blocks per wave and axis
+  constexpr int QN = TN / 4, QK = TK / 4;    // channel quads per tile
+  constexpr int UN = 16 * QN / 256, UK = 16 * QK / 256;  // staging units (4 pixels x 4 channels) per thread: 1 or 2
   __shared__ __attribute__((aligned(16))) _Float16 Dh[TN * WG_LD];
   __shared__ __attribute__((aligned(16))) _Float16 Dl[TN * WG_LD];
-  __shared__ __attribute__((aligned(16))) _Float16 Ah[TK * WG_LD];
-  __shared__ __attribute__((aligned(16))) _Float16 Al[TK * WG_LD];
+  __shared__ __attribute__((aligned(16))) _Float16 Ah[3][TK * WG_LD];
+  __shared__ __attribute__((aligned(16))) _Float16 Al[3][TK * WG_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wj = wave & 1;
   const int lr = lane & 31, kh = (lane >> 5) * 8;
   const int n0 = blockIdx.x * TN, k0 = blockIdx.y * TK;
-  const int tap = blockIdx.z / nsplit, share = blockIdx.z - tap * nsplit;
-  const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+  const int trow = blockIdx.z / nsplit, share = blockIdx.z - trow * nsplit;
+  const int dy = trow - 1;
   const float amax = dzamax ? *dzamax : 0.f;
   const int shift = mm_pow2_shift(amax, 11);
   const float sd = ldexpf(1.f, shift), inv_sd = ldexpf(1.f, -shift);
   const long P = (long)L * H * W;
-  const long nchunk = (P + WG_ROWS - 1) / WG_ROWS;
+  const long nchunk = (P + WG_PX - 1) / WG_PX;
   const long c_lo = nchunk * share / nsplit, c_hi = nchunk * (share + 1) / nsplit;
   const int HW = H * W;
 
-  f32x16 tot[WN][WK];
+  f32x16 acc[3][WN][WK];
 #pragma unroll
-  for (int x = 0; x < WN; ++x)
-#pragma unroll
-    for (int y = 0; y < WK; ++y)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) tot[x][y][e] = 0.f;
-  const int sr4 = (tid >> 3) * 4, sq = tid & 7;
-  constexpr int CPN = TN / 8, CPK = TK / 8;
-
-  for (long c = c_lo; c < c_hi; ++c) {
-    const long p0 = c * WG_ROWS;
-    long prow[4], arow[4];
-    bool pv[4], av[4];
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const long p = p0 + sr4 + rr;
-      pv[rr] = p < P;
-      prow[rr] = pv[rr] ? p : p0;
-      const int rem = (int)(prow[rr] % HW);
-      const int y = rem / W, x = rem - y * W;
-      av[rr] = pv[rr] && (unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W;
-      arow[rr] = av[rr] ? prow[rr] + (long)dy * W + dx : prow[rr];
-    }
-#pragma unroll
-    for (int c4 = 0; c4 < CPN; c4 += 4) {
-      f32x4 x[4];
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        x[rr] = *reinterpret_cast<const f32x4*>(dZ + prow[rr] * Cout + n0 + sq * CPN + c4);
-        if (!pv[rr]) x[rr] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        wg_f16x4 hi, lo;
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const float yv = x[rr][e] * sd;
-          hi[rr] = (_Float16)yv;
-          lo[rr] = (_Float16)(yv - (float)hi[rr]);
-        }
-        const int ch = sq * CPN + c4 + e;
-        *reinterpret_cast<wg_f16x4*>(&Dh[ch * WG_LD + sr4]) = hi;
-        *reinterpret_cast<wg_f16x4*>(&Dl[ch * WG_LD + sr4]) = lo;
-      }
-    }
-#pragma unroll
-    for (int c4 = 0; c4 < CPK; c4 += 4) {
-      f32x4 x[4];
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        x[rr] = *reinterpret_cast<const f32x4*>(A + arow[rr] * Cin + k0 + sq * CPK + c4);
-        if (!av[rr]) x[rr] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        wg_f16x4 hi, lo;
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const float yv = fminf(fmaxf(x[rr][e], -65000.f), 65000.f);
-          hi[rr] = (_Float16)yv;
-          lo[rr] = (_Float16)(yv - (float)hi[rr]);
-        }
-        const int ch = sq * CPK + c4 + e;
-        *reinterpret_cast<wg_f16x4*>(&Ah[ch * WG_LD + sr4]) = hi;
-        *reinterpret_cast<wg_f16x4*>(&Al[ch * WG_LD + sr4]) = lo;
-      }
-    }
-    __syncthreads();
-    f32x16 acc[WN][WK];
+  for (int t = 0; t < 3; ++t)
 #pragma unroll
     for (int x = 0; x < WN; ++x)
 #pragma unroll
       for (int y = 0; y < WK; ++y)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[x][y][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[t][x][y][e] = 0.f;
+
+  // staging unit u of a tile with Q channel quads: channel quad u % Q, pixel quad u / Q (lanes: consecutive channel quads)
+  f32x4 zr[UN][4], ar[UK][6];
+  auto request = [&](long c) {
+    const long p0 = c * WG_PX;
 #pragma unroll
-    for (int k16 = 0; k16 < WG_ROWS / 16; ++k16) {
-      wg_f16x8 dh[WN], dl[WN], ah[WK], al[WK];
+    for (int i = 0; i < UN; ++i) {
+      const int u = tid + 256 * i, cq = u % QN, pq = u / QN;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long p = p0 + 4 * pq + r;
+        zr[i][r] = *reinterpret_cast<const f32x4*>(dZ + (p < P ? p : P - 1) * Cout + n0 + 4 * cq);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < UK; ++i) {
+      const int u = tid + 256 * i, cq = u % QK, pq = u / QK;
+      const long pf = p0 + 4 * pq + (long)dy * W - 1;  // source pixel of slot 0
+#pragma unroll
+      for (int sl = 0; sl < 6; ++sl) {
+        long q = pf + sl;
+        q = q < 0 ? 0 : (q < P ? q : P - 1);
+        ar[i][sl] = *reinterpret_cast<const f32x4*>(A + q * Cin + k0 + 4 * cq);
+      }
+    }
+  };
+  auto stage = [&](long c) {
+    const long p0 = c * WG_PX;
+#pragma unroll
+    for (int i = 0; i < UN; ++i) {
+      const int u = tid + 256 * i, cq = u % QN, pq = u / QN;
+      const long pb = p0 + 4 * pq;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float y[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[r] = pb + r < P ? zr[i][r][e] * sd : 0.f;
+        wg_u32x2 hi, lo;
+        unsigned h0, l0, h1, l1;
+        mm_split2(y[0], y[1], h0, l0);
+        mm_split2(y[2], y[3], h1, l1);
+        hi = wg_u32x2{h0, h1};
+        lo = wg_u32x2{l0, l1};
+        const int off = (e * QN + cq) * WG_LD + 4 * pq;
+        *reinterpret_cast<wg_u32x2*>(&Dh[off]) = hi;
+        *reinterpret_cast<wg_u32x2*>(&Dl[off]) = lo;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < UK; ++i) {
+      const int u = tid + 256 * i, cq = u % QK, pq = u / QK;
+      const long pb = p0 + 4 * pq;
+      // image coordinates of the unit's four pixels -> per copy (dx = t - 1) a 32-bit keep mask per pixel pair
+      unsigned mk[3][2];
+      {
+        const long pc = pb < P ? pb : P - 1;
+        const int rem = (int)(pc % HW);
+        int yy = rem / W, xx = rem - yy * W;
+        bool ok[3][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool in = pb + r < P && (unsigned)(yy + dy) < (unsigned)H;
+#pragma unroll
+          for (int t = 0; t < 3; ++t) ok[t][r] = in && (unsigned)(xx + t - 1) < (unsigned)W;
+          if (++xx == W) {
+            xx = 0;
+            if (++yy == H) yy = 0;
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          mk[t][0] = (ok[t][0] ? 0xffffu : 0u) | (ok[t][1] ? 0xffff0000u : 0u);
+          mk[t][1] = (ok[t][2] ? 0xffffu : 0u) | (ok[t][3] ? 0xffff0000u : 0u);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v[6];
+#pragma unroll
+        for (int sl = 0; sl < 6; ++sl) v[sl] = fminf(fmaxf(ar[i][sl][e], -65000.f), 65000.f);
+        unsigned hp[5], lp[5];  // packed (slot k, slot k + 1) hi / lo halves
+#pragma unroll
+        for (int k = 0; k < 5; ++k) mm_split2(v[k], v[k + 1], hp[k], lp[k]);
+        const int off = (e * QK + cq) * WG_LD + 4 * pq;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {  // copy dx = t - 1: pixel r reads slot r + t
+          *reinterpret_cast<wg_u32x2*>(&Ah[t][off]) = wg_u32x2{hp[t] & mk[t][0], hp[t + 2] & mk[t][1]};
+          *reinterpret_cast<wg_u32x2*>(&Al[t][off]) = wg_u32x2{lp[t] & mk[t][0], lp[t + 2] & mk[t][1]};
+        }
+      }
+    }
+  };
+
+  if (c_lo < c_hi) request(c_lo);
+  for (long c = c_lo; c < c_hi; ++c) {
+    __syncthreads();  // the previous chunk's fragments are read
+    stage(c);
+    __syncthreads();
+    if (c + 1 < c_hi) request(c + 1);  // lands under the MFMAs below
+#pragma unroll
+    for (int k16 = 0; k16 < WG_PX / 16; ++k16) {
+      wg_f16x8 dh[WN], dl[WN];
 #pragma unroll
       for (int x = 0; x < WN; ++x) {
         const int off = ((wi * WN + x) * 32 + lr) * WG_LD + k16 * 16 + kh;
@@ -322,39 +367,39 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16_kernel(const float* __r
         dl[x] = *reinterpret_cast<const wg_f16x8*>(&Dl[off]);
       }
 #pragma unroll
-      for (int y = 0; y < WK; ++y) {
-        const int off = ((wj * WK + y) * 32 + lr) * WG_LD + k16 * 16 + kh;
-        ah[y] = *reinterpret_cast<const wg_f16x8*>(&Ah[off]);
-        al[y] = *reinterpret_cast<const wg_f16x8*>(&Al[off]);
-      }
-#pragma unroll
-      for (int x = 0; x < WN; ++x)
+      for (int t = 0; t < 3; ++t) {
+        wg_f16x8 ah[WK], al[WK];
 #pragma unroll
         for (int y = 0; y < WK; ++y) {
-          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dl[x], ah[y], acc[x][y], 0, 0, 0);
-          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh[x], al[y], acc[x][y], 0, 0, 0);
-          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh[x], ah[y], acc[x][y], 0, 0, 0);
+          const int off = ((wj * WK + y) * 32 + lr) * WG_LD + k16 * 16 + kh;
+          ah[y] = *reinterpret_cast<const wg_f16x8*>(&Ah[t][off]);
+          al[y] = *reinterpret_cast<const wg_f16x8*>(&Al[t][off]);
         }
+#pragma unroll
+        for (int x = 0; x < WN; ++x)
+#pragma unroll
+          for (int y = 0; y < WK; ++y) {
+            acc[t][x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dl[x], ah[y], acc[t][x][y], 0, 0, 0);
+            acc[t][x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh[x], al[y], acc[t][x][y], 0, 0, 0);
+            acc[t][x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh[x], ah[y], acc[t][x][y], 0, 0, 0);
+          }
+      }
     }
+  }
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    float* out = dW + ((long)share * 9 + trow * 3 + t) * Cout * Cin;
 #pragma unroll
     for (int x = 0; x < WN; ++x)
 #pragma unroll
       for (int y = 0; y < WK; ++y)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) tot[x][y][e] += acc[x][y][e];
-    __syncthreads();
+        for (int e = 0; e < 16; ++e) {
+          const int rn = (wi * WN + x) * 32 + mm_acc_row(e, lane), rk = (wj * WK + y) * 32 + lr;  // LDS rows
+          const int n = n0 + 4 * (rn % QN) + rn / QN, k = k0 + 4 * (rk % QK) + rk / QK;         // -> channels
+          out[(long)n * Cin + k] = acc[t][x][y][e] * inv_sd;
+        }
   }
-  float* out = dW + ((long)share * 9 + tap) * Cout * Cin;
-#pragma unroll
-  for (int x = 0; x < WN; ++x)
-#pragma unroll
-    for (int y = 0; y < WK; ++y)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int n = n0 + (wi * WN + x) * 32 + mm_acc_row(e, lane);
-        const int k = k0 + (wj * WK + y) * 32 + lr;
-        out[(long)n * Cin + k] = tot[x][y][e] * inv_sd;
-      }
 }
 
 // dzamax: device pointer to max |dZ| (mmmot_absmax), NULL = no scaling.  Same layout and contract as mmmot_conv3x3_wgrad.
@@ -366,7 +411,7 @@ extern "C" int mmmot_conv3x3_wgrad_f16(const float* dZ, const float* A, int L, i
   hipStream_t s = (hipStream_t)stream;
   const bool n128 = Cout % 128 == 0, k128 = Cin % 128 == 0;
 #define WG_LAUNCH(TNV, TKV)                                                                                              \
-  hipLaunchKernelGGL((conv3x3_wgrad_f16_kernel<TNV, TKV>), dim3(Cout / TNV, Cin / TKV, 9 * nsplit), dim3(256), 0, s, dZ, A, \
+  hipLaunchKernelGGL((conv3x3_wgrad_f16_kernel<TNV, TKV>), dim3(Cout / TNV, Cin / TKV, 3 * nsplit), dim3(256), 0, s, dZ, A, \
                      L, H, W, Cin, Cout, nsplit, dW, dzamax)
   if (n128 && k128) WG_LAUNCH(128, 128);
   else if (n128) WG_LAUNCH(128, 64);

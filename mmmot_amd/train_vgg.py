@@ -223,6 +223,21 @@ def _head_backward(eng, plan, hd, dOut, g):
     return dP
 
 
+def _wgrad_shares(dev, cin, cout, rows, f16):
+    """pixel shares of one layer's weight-gradient launch.  f16x3 kernel (csrc/train_vgg.hip): a workgroup owns a
+    (128- or 64-channel tile pair, tap row, share) and the whole LDS of a CU (two fit with 64 x 64 tiles) - as many shares
+    as give ONE round of workgroups over the chip (288 workgroups on 256 CUs ran two rounds, the second an eighth full),
+    each with at least four 64-pixel chunks.  fp32 kernel: 64 x 64 tiles per tap, about a thousand workgroups."""
+    if not f16:
+        tiles_w = (cout // 64) * (cin // 64) * 9
+        return int(max(1, min(64, -(-1024 // tiles_w), rows // 256)))
+    tn, tk = (128 if cout % 128 == 0 else 64), (128 if cin % 128 == 0 else 64)
+    tiles = (cout // tn) * (cin // tk) * 3
+    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == 'cuda' else 256
+    slots = n_cu * (2 if tn == 64 and tk == 64 else 1)
+    return int(max(1, min(256, slots // tiles, rows // 256)))
+
+
 def appearance_backward(eng, model, plan, crops, tape, dF):
     """dF [L][512] -> {appearance-relative key: gradient}"""
     ops, L = eng.ops, plan.Lt
@@ -271,10 +286,9 @@ def appearance_backward(eng, model, plan, crops, tape, dF):
             g[pre + '%d.weight' % cidx] = pw[:, :27].reshape(64, 3, 3, 3).permute(0, 3, 1, 2)  # [n][ky][kx][c] -> [n][c][ky][kx]
             dA = None
         else:
-            tiles_w = (cout // 64) * (cin // 64) * 9
-            ns = int(max(1, min(64, -(-1024 // tiles_w), rows // 256)))
-            dWp = new(ns, 9 * cout * cin)
             f16 = _f16_convs(ops) and ly['amw'] is not None
+            ns = _wgrad_shares(dev, cin, cout, rows, f16)
+            dWp = new(ns, 9 * cout * cin)
             if f16:
                 amz = new(1)
                 ops.absmax(dZ, amz)  # one maximum for both uses of dZ

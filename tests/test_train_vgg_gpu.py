@@ -115,7 +115,8 @@ def test_rows_stats_and_bn_relu_pool(hip):
 @pytest.mark.parametrize('f16', [True, False])
 @pytest.mark.parametrize('L,H,W,Cin,Cout,ns,scale', [(2, 6, 5, 64, 64, 1, 1.0), (3, 8, 8, 128, 64, 3, 1.0), (1, 4, 4, 64, 256, 2, 1.0),
                                                      (5, 14, 14, 128, 128, 4, 1e-6), (2, 28, 20, 256, 128, 7, 3e-5),
-                                                     (3, 7, 9, 64, 128, 2, 1.0)])
+                                                     (3, 7, 9, 64, 128, 2, 1.0), (2, 31, 17, 128, 128, 5, 1.0),
+                                                     (4, 3, 3, 64, 64, 2, 1.0), (1, 70, 66, 64, 64, 9, 1e-4)])
 def test_conv3x3_wgrad(hip, f16, L, H, W, Cin, Cout, ns, scale):
     """both arithmetics of the trunk's weight gradient (MMMOT_GEMM_TN: f16x3 = 3-term split on the fp16 matrix cores with a
     device-side power-of-two scale of dZ, f32 = exact fp32 MFMA): gradients of 1e-6 keep fp32-class RELATIVE accuracy"""
