@@ -216,38 +216,35 @@ def affinity_forward_train(eng, plan, F):
     return link, ne[0], ne[1], t
 
 
-COLSUM_CHUNK = 2048  # rows per first-level segment of _colsum
+COLSUM_CHUNK = 128  # rows per segment of one level of _colsum
 
 
 def _colsum(eng, X):
     """column sums of a [rows][C] tensor (C % 4 == 0) through the strided-mean kernel with divisor 1.  One segment = one
-    workgroup per 256 channels: a single segment over the 1.1 M rows of a trunk layer's gradient walked 283 MB on ONE
-    workgroup (0.9 ms per call, a fifth of the kernel time of a training step: profiles/r05/rocprofv3_kernel_stats_train.txt),
-    so tall tensors are summed in two levels - COLSUM_CHUNK-row chunks, then the chunk sums."""
+    workgroup per 256 channels, and a workgroup walks its rows sixteen at a time: the 2 048-row chunks this used to cut
+    took 180 us each however few there were (the bias gradients of the trunk: 2.6 ms of a training step,
+    profiles/r06/train_segment_calls.txt), a single segment over a trunk layer's 1.1 M rows 0.9 ms.  So: COLSUM_CHUNK-row
+    chunks, level after level, until at most 2 * COLSUM_CHUNK rows are left (1.1 M rows: 8 624 -> 68 -> 1)."""
     rows, C = int(X.shape[0]), int(X.shape[1])
     cache = eng.__dict__.setdefault('_colsum_segs', {})  # the segment tables per row count: small uploads saved per call
-    key = (rows, str(X.device))
-    seg = cache.get(key)
-    if seg is None:
-        if len(cache) > 256:
-            cache.clear()
-        if rows > 4 * COLSUM_CHUNK:
-            n = -(-rows // COLSUM_CHUNK)
-            start = [i * COLSUM_CHUNK for i in range(n)]
-            count = [min(COLSUM_CHUNK, rows - st) for st in start]
-            seg = (Segments(start, count, [1] * n, [0] * n, X.device, div=[1] * n),
-                   Segments([0], [n], [1], [0], X.device, div=[1]))
-        else:
-            seg = (Segments([0], [rows], [1], [0], X.device, div=[1]), None)
-        cache[key] = seg
-    out = torch.empty(1, C, dtype=torch.float32, device=X.device)
-    if seg[1] is None:
-        eng.ops.segment_mean(X, C, seg[0], out, use_group=False)
-    else:
-        part = torch.empty(seg[0].n, C, dtype=torch.float32, device=X.device)
-        eng.ops.segment_mean(X, C, seg[0], part, use_group=False)
-        eng.ops.segment_mean(part, C, seg[1], out, use_group=False)
-    return out[0]
+    while True:
+        key = (rows, str(X.device))
+        seg = cache.get(key)
+        if seg is None:
+            if len(cache) > 256:
+                cache.clear()
+            if rows > 2 * COLSUM_CHUNK:
+                n = -(-rows // COLSUM_CHUNK)
+                start = np.arange(n) * COLSUM_CHUNK
+                seg = Segments(start, np.minimum(COLSUM_CHUNK, rows - start), np.ones(n), np.zeros(n), X.device, div=np.ones(n))
+            else:
+                seg = Segments([0], [rows], [1], [0], X.device, div=[1])
+            cache[key] = seg
+        out = torch.empty(seg.n, C, dtype=torch.float32, device=X.device)
+        eng.ops.segment_mean(X, C, seg, out, use_group=False)
+        if seg.n == 1:
+            return out[0]
+        X, rows = out, seg.n
 
 
 def _gn_backward(eng, plan, L, dA, out=None, relu=True):

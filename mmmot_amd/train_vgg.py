@@ -45,23 +45,8 @@ def _ident_rows(cache, n, dev):
 
 
 def _colsum_big(eng, X):
-    """column sums of a tall [rows][C] tensor in two levels (one workgroup per 2048-row chunk, then the chunks)"""
-    R, C = X.shape
-    if R <= 4096:
-        return _colsum(eng, X)
-    n = (R + 2047) // 2048
-    cache = eng.__dict__.setdefault('_colsum_big_segs', {})  # chunk table per row count (uploaded once)
-    key = (R, str(X.device))
-    seg = cache.get(key)
-    if seg is None:
-        if len(cache) > 64:
-            cache.clear()
-        start = np.arange(n) * 2048
-        count = np.minimum(2048, R - start)
-        seg = cache[key] = Segments(start, count, np.ones(n), np.zeros(n), X.device, div=np.ones(n))
-    part = torch.empty(n, C, dtype=torch.float32, device=X.device)
-    eng.ops.segment_mean(X, C, seg, part, use_group=False)
-    return _colsum(eng, part)
+    """column sums of a tall [rows][C] tensor (the bias gradient of a trunk layer): _colsum's levels of 128-row chunks"""
+    return _colsum(eng, X)
 
 
 def _f16_convs(ops):
