@@ -24,6 +24,41 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(
     const int* __restrict__ tile_group, float* __restrict__ P) {
   const int t = blockIdx.x;
   const int row0 = tile_row0[t], nrows = tile_nrows[t], g = tile_group ? tile_group[t] : 0;
+  const int C4 = C >> 2;
+  if (C4 <= 128) {
+    // narrow rows (64 .. 512 channels): 256 / (C / 4) rows at a time, the row phases added in a fixed order through LDS
+    // (with one thread per 4 channels walking the whole tile, a 64-channel layer kept 16 threads of a workgroup busy)
+    __shared__ __attribute__((aligned(16))) float red[2][256 * 4];
+    const int RP = 256 / C4, tid = threadIdx.x, cq = tid % C4, ph = tid / C4, c = cq * 4;
+    const f32x4 s = *reinterpret_cast<const f32x4*>(&sc1[(long)g * ldsc + c]);
+    const f32x4 h = *reinterpret_cast<const f32x4*>(&sh1[(long)g * ldsc + c]);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(&gamma[c]);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(&beta[c]);
+    f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0;
+    if (ph < RP)
+      for (int r = ph; r < nrows; r += RP) {
+        const f32x4 y = *reinterpret_cast<const f32x4*>(&Y[(long)(row0 + r) * ldy + c]);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(&dA[(long)(row0 + r) * ldda + c]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float yh = fmaf(y[e], s[e], h[e]);
+          const float z = fmaf(yh, ga[e], be[e]);
+          const float dz = (relu && !(z > 0.f)) ? 0.f : d[e];
+          p0[e] += dz;
+          p1[e] = fmaf(dz, yh, p1[e]);
+        }
+      }
+    *reinterpret_cast<f32x4*>(&red[0][tid * 4]) = p0;
+    *reinterpret_cast<f32x4*>(&red[1][tid * 4]) = p1;
+    __syncthreads();
+    if (tid < 2 * C4) {
+      const int w = tid / C4, q = tid - w * C4;
+      f32x4 tot = *reinterpret_cast<const f32x4*>(&red[w][q * 4]);
+      for (int k = 1; k < RP; ++k) tot += *reinterpret_cast<const f32x4*>(&red[w][(k * C4 + q) * 4]);
+      *reinterpret_cast<f32x4*>(&P[((long)t * 2 + w) * C + q * 4]) = tot;
+    }
+    return;
+  }
   for (int c = (blockIdx.y * 256 + threadIdx.x) * 4; c < C; c += gridDim.y * 1024) {
     const f32x4 s = *reinterpret_cast<const f32x4*>(&sc1[(long)g * ldsc + c]);
     const f32x4 h = *reinterpret_cast<const f32x4*>(&sh1[(long)g * ldsc + c]);

@@ -18,10 +18,48 @@ __global__ __launch_bounds__(256) void rows_stats_kernel(const float* __restrict
                                                          const int* __restrict__ tile_nrows, float* __restrict__ part) {
   const int t = blockIdx.x;
   const int row0 = tile_row0[t], nrows = tile_nrows[t];
+  const float inv = nrows > 0 ? 1.f / (float)nrows : 0.f;
+  const int C4 = C >> 2;
+  if (C4 <= 128) {
+    // narrow rows (the trunk's 64 .. 512 channels): C / 4 lanes cover a row, so the 256 threads take 256 / (C / 4) rows
+    // at a time instead of 16 .. 128 of them walking the tile alone (the 64-channel layers ran at 1 TB/s); the row
+    // phases are added in a fixed order through LDS
+    __shared__ __attribute__((aligned(16))) float red[256 * 4];
+    __shared__ __attribute__((aligned(16))) float smu[128 * 4];
+    const int RP = 256 / C4, tid = threadIdx.x, cq = tid % C4, ph = tid / C4;
+    const bool live = ph < RP;
+    const float* base = Y + (long)row0 * ldy + cq * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (live)
+      for (int r = ph; r < nrows; r += RP) s += *reinterpret_cast<const f32x4*>(base + (long)r * ldy);
+    *reinterpret_cast<f32x4*>(&red[tid * 4]) = s;
+    __syncthreads();
+    if (tid < C4) {
+      f32x4 tot = *reinterpret_cast<const f32x4*>(&red[tid * 4]);
+      for (int k = 1; k < RP; ++k) tot += *reinterpret_cast<const f32x4*>(&red[(k * C4 + tid) * 4]);
+      *reinterpret_cast<f32x4*>(&part[((long)t * 2 + 0) * C + tid * 4]) = tot;
+      *reinterpret_cast<f32x4*>(&smu[tid * 4]) = tot * inv;
+    }
+    __syncthreads();
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(&smu[cq * 4]);
+    f32x4 q = {0.f, 0.f, 0.f, 0.f};
+    if (live)
+      for (int r = ph; r < nrows; r += RP) {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(base + (long)r * ldy) - mu;
+        q += d * d;
+      }
+    *reinterpret_cast<f32x4*>(&red[tid * 4]) = q;
+    __syncthreads();
+    if (tid < C4) {
+      f32x4 tot = *reinterpret_cast<const f32x4*>(&red[tid * 4]);
+      for (int k = 1; k < RP; ++k) tot += *reinterpret_cast<const f32x4*>(&red[(k * C4 + tid) * 4]);
+      *reinterpret_cast<f32x4*>(&part[((long)t * 2 + 1) * C + tid * 4]) = tot;
+    }
+    return;
+  }
   for (int c = (blockIdx.y * 256 + threadIdx.x) * 4; c < C; c += gridDim.y * 1024) {
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     for (int r = 0; r < nrows; ++r) s += *reinterpret_cast<const f32x4*>(&Y[(long)(row0 + r) * ldy + c]);
-    const float inv = nrows > 0 ? 1.f / (float)nrows : 0.f;
     const f32x4 mu = s * inv;
     f32x4 q = {0.f, 0.f, 0.f, 0.f};
     for (int r = 0; r < nrows; ++r) {

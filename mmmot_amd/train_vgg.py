@@ -160,7 +160,17 @@ def _head_forward(eng, plan, cache, s, x, hw, C, P, feats, drop=None):
     T1 = _tiles(cache, L, dev, each=1)
     key = ('pool', L, hw)  # cached with the plan: a Segments table is five small host-to-device copies (4.5 ms per step
     if key not in cache:   # over the four heads, cProfile round 4)
-        cache[key] = Segments(np.arange(L) * hw, np.full(L, hw), np.ones(L), np.zeros(L), dev)
+        if hw > 512:
+            # a crop's map in 128-row chunks (sums), then the chunks of a crop (divided by hw): 22 workgroups walking
+            # 3 136 rows each took 0.2 - 0.3 ms
+            nch = -(-hw // 128)
+            k = np.arange(nch)
+            s1 = (np.arange(L)[:, None] * hw + k[None] * 128).reshape(-1)
+            c1 = np.tile(np.minimum(128, hw - k * 128), L)
+            cache[key] = (Segments(s1, c1, np.ones(len(s1)), np.zeros(len(s1)), dev, div=np.ones(len(s1))),
+                          Segments(np.arange(L) * nch, np.full(L, nch), np.ones(L), np.zeros(L), dev, div=np.full(L, hw)))
+        else:
+            cache[key] = Segments(np.arange(L) * hw, np.full(L, hw), np.ones(L), np.zeros(L), dev)
     seg = cache[key]
     Pm = new(L, C)
     if drop is not None:                                        # x * block_mask * numel / sum (dropblock.py:50-53)
@@ -168,7 +178,12 @@ def _head_forward(eng, plan, cache, s, x, hw, C, P, feats, drop=None):
         xd = new(L * hw, C)
         ops.rows_gather_scale(x, ident, drop, xd, C)
         x = xd
-    ops.segment_mean(x, C, seg, Pm, use_group=False)           # AdaptiveAvgPool2d(1)
+    if isinstance(seg, tuple):                                  # AdaptiveAvgPool2d(1)
+        chunk_sums = new(seg[0].n, C)
+        ops.segment_mean(x, C, seg[0], chunk_sums, use_group=False)
+        ops.segment_mean(chunk_sums, C, seg[1], Pm, use_group=False)
+    else:
+        ops.segment_mean(x, C, seg, Pm, use_group=False)
     part = new(T1.T, 2, C)
     ops.rows_stats(Pm, C, T1, part)
     L0 = _norm_layer(eng, part, T1, Pm, C, 1, P[pre + '0.weight'], P[pre + '0.bias'])
