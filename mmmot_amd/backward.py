@@ -224,9 +224,17 @@ def _colsum(eng, X):
     workgroup per 256 channels, and a workgroup walks its rows sixteen at a time: the 2 048-row chunks this used to cut
     took 180 us each however few there were (the bias gradients of the trunk: 2.6 ms of a training step,
     profiles/r06/train_segment_calls.txt), a single segment over a trunk layer's 1.1 M rows 0.9 ms.  So: COLSUM_CHUNK-row
-    chunks, level after level, until at most 2 * COLSUM_CHUNK rows are left (1.1 M rows: 8 624 -> 68 -> 1)."""
+    chunks, level after level, until at most 2 * COLSUM_CHUNK rows are left (1.1 M rows of 64 channels: viewed as 276 k rows
+    of 256, 2 156 -> 17 -> 1)."""
     rows, C = int(X.shape[0]), int(X.shape[1])
     cache = eng.__dict__.setdefault('_colsum_segs', {})  # the segment tables per row count: small uploads saved per call
+    # narrow rows: a lane of the kernel owns 4 channels, so a 64-channel tensor would keep 16 lanes of a wave busy - k
+    # consecutive rows are viewed as one row of k * C channels (the sums of the rows = r mod k classes), folded at the end
+    fold, C0 = 1, C
+    if X.is_contiguous():
+        while C * 2 <= 256 and rows % 2 == 0 and rows > 2 * COLSUM_CHUNK:
+            fold, C, rows = fold * 2, C * 2, rows // 2
+        X = X.view(rows, C)
     while True:
         key = (rows, str(X.device))
         seg = cache.get(key)
@@ -243,7 +251,7 @@ def _colsum(eng, X):
         out = torch.empty(seg.n, C, dtype=torch.float32, device=X.device)
         eng.ops.segment_mean(X, C, seg, out, use_group=False)
         if seg.n == 1:
-            return out[0]
+            return out[0] if fold == 1 else out.view(fold, C0).sum(0)
         X, rows = out, seg.n
 
 

@@ -139,14 +139,23 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
     const int* __restrict__ tile_nrows, const int* __restrict__ tile_group, float* __restrict__ dY, int lddy) {
   const int t = blockIdx.x;
   const int row0 = tile_row0[t], nrows = tile_nrows[t], g = tile_group ? tile_group[t] : 0;
-  for (int c = (blockIdx.y * 256 + threadIdx.x) * 4; c < C; c += gridDim.y * 1024) {
+  // narrow rows (C <= 512): C / 4 threads per row, 256 / (C / 4) rows at a time (elementwise: the mapping does not touch
+  // the values); wider rows: a thread per 4 channels walks the tile
+  const int C4 = C >> 2;
+  const bool narrow = C4 <= 128;
+  const int RP = narrow ? 256 / C4 : 1;
+  const int ph = narrow ? (int)threadIdx.x / C4 : 0;
+  const int cbeg = narrow ? ((int)threadIdx.x % C4) * 4 : (blockIdx.y * 256 + threadIdx.x) * 4;
+  const int cstep = narrow ? C : gridDim.y * 1024;
+  if (narrow && ph >= RP) return;
+  for (int c = cbeg; c < C; c += cstep) {
     const f32x4 s = *reinterpret_cast<const f32x4*>(&sc1[(long)g * ldsc + c]);
     const f32x4 h = *reinterpret_cast<const f32x4*>(&sh1[(long)g * ldsc + c]);
     const f32x4 ga = *reinterpret_cast<const f32x4*>(&gamma[c]);
     const f32x4 be = *reinterpret_cast<const f32x4*>(&beta[c]);
     const f32x4 m1 = *reinterpret_cast<const f32x4*>(&M[((long)g * 2 + 0) * C + c]);
     const f32x4 m2 = *reinterpret_cast<const f32x4*>(&M[((long)g * 2 + 1) * C + c]);
-    for (int r = 0; r < nrows; ++r) {
+    for (int r = ph; r < nrows; r += RP) {
       const f32x4 y = *reinterpret_cast<const f32x4*>(&Y[(long)(row0 + r) * ldy + c]);
       const f32x4 d = *reinterpret_cast<const f32x4*>(&dA[(long)(row0 + r) * ldda + c]);
       f32x4 o;

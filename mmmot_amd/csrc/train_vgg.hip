@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) void conv3x3_first_wgrad_kernel(const float* _
   // WAVE-UNIFORM (scalar loads, scalar bounds tests, no per-lane address arithmetic); the coordinates advance
   // incrementally (no division in the loop).  The earlier form computed them per lane behind per-tap branches and took
   // 1.4 ms per training step for 2 G fp64 fmas (latency-bound).
-  __shared__ double red[4][64][28];
+  __shared__ float red[4][64][28];  // a wave's fp64 sums, rounded once (28 KB: five workgroups per CU; as doubles two)
   const int c = threadIdx.x & 63;
   const int ph = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int P = L * H * W;  // the launcher checks that this fits an int
@@ -480,8 +480,10 @@ __global__ __launch_bounds__(256) void conv3x3_first_wgrad_kernel(const float* _
   const int HW = H * W;
   int p = p_lo + ph;
   int crop = p / HW, y = (p - crop * HW) / W, x = p - crop * HW - y * W;
+  float dn = p < p_hi ? dZ[(long)p * 64 + c] : 0.f;
   for (; p < p_hi; p += 4) {
-    const double d = (double)dZ[(long)p * 64 + c];
+    const double d = (double)dn;
+    if (p + 4 < p_hi) dn = dZ[(long)(p + 4) * 64 + c];  // the next pixel's row is in flight during this one's 55 VALU ops
     float xv[27];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -507,11 +509,11 @@ __global__ __launch_bounds__(256) void conv3x3_first_wgrad_kernel(const float* _
     }
   }
 #pragma unroll
-  for (int k = 0; k < 28; ++k) red[ph][c][k] = acc[k];
+  for (int k = 0; k < 28; ++k) red[ph][c][k] = (float)acc[k];
   __syncthreads();
   for (int idx = threadIdx.x; idx < 64 * 28; idx += 256) {
     const int cc = idx / 28, k = idx - cc * 28;
-    PW[(long)blockIdx.x * 64 * 28 + idx] = (float)(red[0][cc][k] + red[1][cc][k] + red[2][cc][k] + red[3][cc][k]);
+    PW[(long)blockIdx.x * 64 * 28 + idx] = (red[0][cc][k] + red[1][cc][k]) + (red[2][cc][k] + red[3][cc][k]);
   }
 }
 
