@@ -289,7 +289,11 @@ int mmmot_gemm_ares(const mmmot_gemm_ares_args* a, void* stream);
 /* ABI 7.  tests: which kernel serves the K = 128 consumer pass (colsum only) of mmmot_gemm_ares - 0 = automatic (the
  * weights-in-registers kernel of csrc/gemm_wreg.hip when N % 512 == 0 and the launch fills the chip), 1 = the streaming
  * kernel only (the kernel before ABI 7), 2 = the register kernel whenever the layer is eligible.  Results do not depend on
- * it, bit for bit. */
+ * it, bit for bit.
+ * K = 64, N <= 512 (PointNet_v1.conv1, csrc/gemm_wres.hip), since round 6: 0 = the independent-wave kernel for a column-sum
+ * pass that gives every wave at least four 64-row half tiles, the two-barrier weight-resident kernel otherwise; 1 = the
+ * streaming kernel (N % 256 == 0); 2 = the independent-wave kernel for every column-sum pass; 3 = the two-barrier kernel
+ * only (K = 128: as 0).  Bit for bit the same column sums. */
 int mmmot_set_gemm_ares_variant(int v);
 
 /* ---------------------------------------------------------------------------

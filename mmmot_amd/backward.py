@@ -222,8 +222,8 @@ COLSUM_CHUNK = 128  # rows per segment of one level of _colsum
 def _colsum(eng, X):
     """column sums of a [rows][C] tensor (C % 4 == 0) through the strided-mean kernel with divisor 1.  One segment = one
     workgroup per 256 channels, and a workgroup walks its rows sixteen at a time: the 2 048-row chunks this used to cut
-    took 180 us each however few there were (the bias gradients of the trunk: 2.6 ms of a training step,
-    profiles/r06/train_segment_calls.txt), a single segment over a trunk layer's 1.1 M rows 0.9 ms.  So: COLSUM_CHUNK-row
+    took 180 us each however few there were (the bias gradients of the trunk: 2.6 ms of a training step -
+    profiles/HISTORY.md round 6; tools/train_segment_calls.py lists the call sites), a single segment over a trunk layer's 1.1 M rows 0.9 ms.  So: COLSUM_CHUNK-row
     chunks, level after level, until at most 2 * COLSUM_CHUNK rows are left (1.1 M rows of 64 channels: viewed as 276 k rows
     of 256, 2 156 -> 17 -> 1)."""
     rows, C = int(X.shape[0]), int(X.shape[1])

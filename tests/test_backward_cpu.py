@@ -212,4 +212,14 @@ def test_two_level_segment_sums_equal_the_direct_sums():
     assert not isinstance(short, tuple)
     tall = torch.randn(9000, C, generator=g)
     assert (_colsum(eng, tall).double() - tall.double().sum(0)).abs().max().item() < 1e-3
-    assert isinstance(eng._colsum_segs[(9000, 'cpu')], tuple) and eng._colsum_segs[(9000, 'cpu')][1] is not None
+    # 9000 x 8 is viewed as 1125 rows of 64 (three halvings, 1125 is odd), summed as 9 chunks of 128 rows, then the 9 chunk
+    # sums, then the eight row classes are folded
+    assert eng._colsum_segs[(1125, 'cpu')].n == 9 and eng._colsum_segs[(9, 'cpu')].n == 1
+    assert (9000, 'cpu') not in eng._colsum_segs
+    odd = torch.randn(1001, 12, generator=g)                      # odd row count: no folding, 8 chunks, then one segment
+    assert (_colsum(eng, odd).double() - odd.double().sum(0)).abs().max().item() < 1e-3
+    assert eng._colsum_segs[(1001, 'cpu')].n == 8
+    wide = torch.randn(4096, 520, generator=g)[:, :512]           # a column slice (not contiguous): summed as it lies
+    assert (_colsum(eng, wide).double() - wide.double().sum(0)).abs().max().item() < 2e-3
+    small = torch.randn(7, 16, generator=g)
+    assert (_colsum(eng, small).double() - small.double().sum(0)).abs().max().item() < 1e-5

@@ -46,6 +46,8 @@ python $R/tools/rocpd_summary.py stats $(find /tmp/prof_lat -name "*_results.db"
 rm -rf /tmp/prof_train
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_train -- python $R/tools/profile_train_step.py --whole > $O/rocprof_train_run.log 2>&1
 python $R/tools/rocpd_summary.py stats $(find /tmp/prof_train -name "*_results.db" | head -1) > $O/rocprofv3_kernel_stats_train.txt 2>&1
+python $R/tools/rocpd_summary.py detail $(find /tmp/prof_train -name "*_results.db" | head -1) 60 > $O/rocprofv3_kernel_detail_train.txt 2>&1
+timeout 300 python $R/tools/train_segment_calls.py 2>&1 | grep "calls  nseg" > $O/train_segment_calls.txt
 timeout 300 python $R/tools/bench_backward.py > $O/bench_backward.log 2>&1
 timeout 300 python $R/tools/bench_train.py > $O/bench_train.log 2>&1
 timeout 300 python $R/tools/bench_conv_small_maps.py > $O/conv_small_maps_ab.log 2>&1

@@ -1,3 +1,10 @@
+#!/usr/bin/env python
+"""Which call sites launch mmmot_segment_mean during a whole-network training step, and with what shapes (segments,
+channels, longest segment): the strided-sum kernel serves a dozen different reductions of the backward pass, and its
+launches only show up as one name in a kernel trace.  GPU box only.
+
+    python tools/train_segment_calls.py | grep "calls  nseg"
+"""
 import sys, os, traceback, collections, torch
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 sys.argv = [sys.argv[0], '--whole']
