@@ -598,7 +598,10 @@ int mmmot_conv3x3_wgrad(const float* dZ, const float* A, int L, int H, int W, in
                         void* stream);
 /* ABI 7.  The same weight gradient on the fp16 matrix cores (3-term hi/lo split, the pixel axis as the K of the MFMA like
  * mmmot_gemm_tn_f16): dZ is scaled by the power of two that puts dzamax[0] = max |dZ| (device scalar, mmmot_absmax; NULL =
- * no scaling) at 2^10 and the result scaled back exactly.  Same output layout; fp32-class (products exact to 2^-22). */
+ * no scaling) at 2^10 and the result scaled back exactly.  Same output layout; fp32-class (products exact to 2^-22).
+ * Since round 6 a workgroup owns a (channel-tile pair, tap ROW, share): nsplit such that (Cout/T)(Cin/T) * 3 * nsplit fills
+ * the CUs once (T = 128 where the channel count allows, else 64) is the fast choice (mmmot_amd/train_vgg.py:_wgrad_shares);
+ * a share sums 64-pixel chunks in fp32 on the matrix cores' accumulators. */
 int mmmot_conv3x3_wgrad_f16(const float* dZ, const float* A, int L, int H, int W, int Cin, int Cout, int nsplit, float* dW,
                             const float* dzamax, void* stream);
 /* first layer (NCHW crops X [L][3][H][W], Cout = 64): PW[b][co][28] partial sums over block b's pixels of

@@ -300,9 +300,6 @@ __global__ __launch_bounds__(WR_THREADS) void gemm_wres64_kernel(mmmot_gemm_ares
 // Same MFMA order per accumulator, same per-lane summation order, same half-wave exchange as above and as gemm_ares:
 // the column sums are bit-identical (tests/test_kernels_gpu.py).  Ragged half tiles (a detection's tail) take a compact
 // loop with the constants read per block.
-#ifndef WI_PIN
-#define WI_PIN 0
-#endif
 struct WiItem {
   int row0, nrows, grp, dbrow;  // of the item's 128-row tile
 };
@@ -435,9 +432,6 @@ __global__ __launch_bounds__(WR_THREADS) void gemm_wres64i_kernel(mmmot_gemm_are
       const int sl = j & 1;
       if (j < 3) read_b(n_next - 32, j + 1, sl ^ 1);
       else if (have_next) read_b(n_next, 0, sl ^ 1);
-#if WI_PIN
-      __builtin_amdgcn_sched_barrier(0);
-#endif
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j][1], bh[sl], acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j][3], bh[sl], acc[1], 0, 0, 0);
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j][0], bl[sl], acc[0], 0, 0, 0);
