@@ -513,47 +513,73 @@ extern "C" int mmmot_set_gram128_variant(int v) {
 }
 
 // sum of the super-tile partials of every group -> covariance and mean of the group's rows:
-// red[g][K*K + K] doubles = Cov(a) (K x K), then E[a] (K).  Every thread also re-adds the two column sums its element
-// needs (nt <= a few dozen terms each) so that the covariance is formed ONCE per group here instead of once per
-// workgroup of the finalize kernel (16 per group, 64 float64 divisions per thread each); sums, quotients and the
-// product are those of the round-4 kernels, in their order: bit-identical scale / shift.
+// red[g][K*K + K] doubles = Cov(a) (K x K), then E[a] (K), formed ONCE per group here instead of once per workgroup of the
+// finalize kernel.  A workgroup owns 64 consecutive elements (one row of the K x K matrix, or 64 of the means); its four
+// waves take the super-tiles t = w, w + 4, ... of the group (a detection-aligned tiling has one per detection: 64 - 128
+// per sample, and one thread walking them - plus the two column sums its element needs - was a chain of round trips:
+// 0.23 ms at 32 LiDAR pairs), four tiles in flight each, and the four partial sums are added in wave order.  The order
+// depends on the group's own tiles only (batched == single, bit for bit).
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restrict__ Gp, const double* __restrict__ Sp,
                                                           const int* __restrict__ grp_tile0,
                                                           const int* __restrict__ grp_ntiles,
                                                           const int* __restrict__ grp_count, int K,
                                                           double* __restrict__ red) {
+  __shared__ double part[3][4][64];
   const int g = blockIdx.y;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  const int KK = K * K;
-  if (idx >= KK + K) return;
+  const int e = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int KK = K * K;  // a multiple of 64: a workgroup's elements are all of the matrix or all of the means
+  const int idx0 = blockIdx.x * 64, idx = idx0 + e;
+  const bool mat = idx0 < KK;
+  const int ei = mat ? idx0 / K : 0;               // the row of this workgroup's matrix elements
+  const int cj = mat ? idx - ei * K : idx - KK;    // this thread's column
   const int t0 = grp_tile0[g], nt = grp_ntiles[g];
-  const double cnt = (double)grp_count[g];
-  // (eight loads in flight per trip, added in tile order: the loops are chains of L2 / HBM round trips - 128 super-tiles
-  // of a detection-aligned tiling cost 0.13 ms one load at a time)
-  auto tile_sum = [&](const double* base, long stride) {
-    double s = 0.0;
-    int t = 0;
-    for (; t + 8 <= nt; t += 8) {
-      double v[8];
+  // K = 128: gram_rows128_kernel writes the blocks on and above the block diagonal only.  An element of a block above the
+  // diagonal is also written to its mirror position below it (same value: the product of the two means commutes); the
+  // threads of the blocks below the diagonal have nothing to do (reading (j, i) for (i, j) there was one cache line per
+  // lane - the 0.2 ms of this kernel at 32 LiDAR pairs)
+  const bool upper = K == 128 && mat && (ei >> 5) < (cj >> 5);
+  const bool live = cj < K && !(K == 128 && mat && (ei >> 5) > (cj >> 5));
+  double s = 0.0, cs = 0.0, rs = 0.0;
+  if (live) {
+    const double* gp = Gp + (long)t0 * KK + idx;
+    const double* cp = Sp + (long)t0 * K + cj;
+    const double* rp = Sp + (long)t0 * K + ei;
+    int t = ph;
+    for (; t + 12 < nt; t += 16) {
+      double v[4], c[4], r[4];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = base[(long)(t0 + t + u) * stride];
+      for (int u = 0; u < 4; ++u) {
+        v[u] = mat ? gp[(long)(t + 4 * u) * KK] : 0.0;
+        c[u] = cp[(long)(t + 4 * u) * K];
+        r[u] = mat ? rp[(long)(t + 4 * u) * K] : 0.0;
+      }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) s += v[u];
+      for (int u = 0; u < 4; ++u) {
+        s += v[u];
+        cs += c[u];
+        rs += r[u];
+      }
     }
-    for (; t < nt; ++t) s += base[(long)(t0 + t) * stride];
-    return s;
-  };
-  auto colsum = [&](int k) { return tile_sum(Sp + k, K); };
-  if (idx < KK) {
-    // K = 128: gram_rows128_kernel writes the blocks on and above the block diagonal only - element (i, j) of a block below
-    // it is element (j, i)
-    const int ei = idx / K, ej = idx % K;
-    const int src = (K == 128 && (ei >> 5) > (ej >> 5)) ? ej * K + ei : idx;
-    const double s = tile_sum(Gp + src, KK);
-    const double mi = colsum(idx / K) / cnt, mj = colsum(idx % K) / cnt;
-    red[(long)g * (KK + K) + idx] = s / cnt - mi * mj;
-  } else {
-    red[(long)g * (KK + K) + idx] = colsum(idx - KK) / cnt;
+    for (; t < nt; t += 4) {
+      if (mat) {
+        s += gp[(long)t * KK];
+        rs += rp[(long)t * K];
+      }
+      cs += cp[(long)t * K];
+    }
+  }
+  part[0][ph][e] = s;
+  part[1][ph][e] = cs;
+  part[2][ph][e] = rs;
+  __syncthreads();
+  if (ph == 0 && live) {
+    const double cnt = (double)grp_count[g];
+    const double S = ((part[0][0][e] + part[0][1][e]) + part[0][2][e]) + part[0][3][e];
+    const double C = ((part[1][0][e] + part[1][1][e]) + part[1][2][e]) + part[1][3][e];
+    const double R = ((part[2][0][e] + part[2][1][e]) + part[2][2][e]) + part[2][3][e];
+    const double val = mat ? S / cnt - (R / cnt) * (C / cnt) : C / cnt;
+    red[(long)g * (KK + K) + idx] = val;
+    if (upper) red[(long)g * (KK + K) + cj * K + ei] = val;
   }
 }
 
@@ -672,7 +698,7 @@ extern "C" int mmmot_gn_finalize_gram(const double* Gp, const double* Sp, const 
   if (!Gp || !Sp || !grp_tile0 || !grp_ntiles || !grp_count || !W || !gamma || !beta || !work || !sc || !sh)
     return MMMOT_EINVAL;
   if ((K != 64 && K != 128) || G <= 0 || N <= 0) return MMMOT_EINVAL;
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3((K * K + K + 255) / 256, G), dim3(256), 0, s, Gp, Sp, grp_tile0,
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3((K * K + K + 63) / 64, G), dim3(256), 0, s, Gp, Sp, grp_tile0,
                      grp_ntiles, grp_count, K, work);
   if (K == 128)
     hipLaunchKernelGGL(gn_finalize_gram_kernel<128>, dim3(G, (N + GF_CH - 1) / GF_CH), dim3(256), 0, s, work, grp_count, W, bias,
@@ -792,7 +818,7 @@ extern "C" int mmmot_gn_finalize_gram_dbias(const double* Gp, const double* Sp, 
       !beta || !work || !sc || !sh)
     return MMMOT_EINVAL;
   if (K != 64 || G <= 0 || N <= 0 || lddb < N) return MMMOT_EINVAL;
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3((K * K + K + 255) / 256, G), dim3(256), 0, s, Gp, Sp, grp_tile0,
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3((K * K + K + 63) / 64, G), dim3(256), 0, s, Gp, Sp, grp_tile0,
                      grp_ntiles, grp_count, K, work);
   hipLaunchKernelGGL(gn_finalize_gram_dbias_kernel<64>, dim3(G, (N + 63) / 64), dim3(256), 0, s, work, Sp, grp_tile0,
                      grp_ntiles, grp_count, tile_nrows, tile_det, W, dbias, lddb, N, gamma, beta, eps, sc, sh);
