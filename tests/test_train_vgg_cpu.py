@@ -152,3 +152,22 @@ def test_training_step_matches_the_reference_fixture(name):
     worst = compare_train_step(g, outs, loss, grad_of, buffers, out_tol=5e-5, loss_tol=5e-6, grad_tol=2e-2, norm_tol=1e-2,
                                bn_tol=1e-5, what=name)
     print('%s: product (emulated C-ABI) vs the reference training step: %s' % (name, ' '.join('%s=%.1e' % kv for kv in worst.items())))
+
+
+def test_weight_gradient_shares_fill_the_chip_once():
+    """_wgrad_shares: the f16x3 weight-gradient kernel runs one workgroup per (channel-tile pair, tap row, share) and one
+    (two with 64 x 64 tiles) per CU - the share count gives at most one round of workgroups on 256 CUs, at least one share,
+    at most the 256 the C entry point accepts, and never more shares than 256-pixel runs of the layer"""
+    from mmmot_amd.train_vgg import _wgrad_shares
+    dev = torch.device('cpu')  # no device properties on the CPU: 256 CUs assumed
+    for cin, cout, rows in [(64, 64, 1103872), (64, 128, 275968), (128, 128, 275968), (128, 256, 68992),
+                            (256, 256, 68992), (256, 512, 17248), (512, 512, 17248), (512, 512, 4312), (512, 512, 200)]:
+        ns = _wgrad_shares(dev, cin, cout, rows, True)
+        tn, tk = (128 if cout % 128 == 0 else 64), (128 if cin % 128 == 0 else 64)
+        wgs = (cout // tn) * (cin // tk) * 3 * ns
+        slots = 256 * (2 if (tn, tk) == (64, 64) else 1)
+        assert 1 <= ns <= 256 and ns <= max(1, rows // 256)
+        assert wgs <= slots or ns == 1, (cin, cout, rows, ns)
+        if rows // 256 >= slots:                       # enough pixels: the single round is nearly full
+            assert wgs > slots - (cout // tn) * (cin // tk) * 3
+    assert _wgrad_shares(dev, 512, 512, 17248, False) == 2  # fp32 kernel: the round-3 rule (64 x 64 tiles per tap)
