@@ -282,9 +282,9 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16_kernel(const float* __r
   const float amax = dzamax ? *dzamax : 0.f;
   const int shift = mm_pow2_shift(amax, 11);
   const float sd = ldexpf(1.f, shift), inv_sd = ldexpf(1.f, -shift);
-  const long P = (long)L * H * W;
-  const long nchunk = (P + WG_PX - 1) / WG_PX;
-  const long c_lo = nchunk * share / nsplit, c_hi = nchunk * (share + 1) / nsplit;
+  const int P = L * H * W;  // (the launcher checks that the pixel count fits an int: 32-bit index arithmetic below)
+  const int nchunk = (P + WG_PX - 1) / WG_PX;
+  const int c_lo = (int)((long)nchunk * share / nsplit), c_hi = (int)((long)nchunk * (share + 1) / nsplit);
   const int HW = H * W;
 
   f32x16 acc[3][WN][WK];
@@ -299,40 +299,39 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16_kernel(const float* __r
 
   // staging unit u of a tile with Q channel quads: channel quad u % Q, pixel quad u / Q (lanes: consecutive channel quads)
   f32x4 zr[UN][4], ar[UK][6];
-  auto request = [&](long c) {
-    const long p0 = c * WG_PX;
+  auto request = [&](int c) {
+    const int p0 = c * WG_PX;
 #pragma unroll
     for (int i = 0; i < UN; ++i) {
       const int u = tid + 256 * i, cq = u % QN, pq = u / QN;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const long p = p0 + 4 * pq + r;
-        zr[i][r] = *reinterpret_cast<const f32x4*>(dZ + (p < P ? p : P - 1) * Cout + n0 + 4 * cq);
+        const int p = min(p0 + 4 * pq + r, P - 1);
+        zr[i][r] = *reinterpret_cast<const f32x4*>(dZ + (long)p * Cout + n0 + 4 * cq);
       }
     }
 #pragma unroll
     for (int i = 0; i < UK; ++i) {
       const int u = tid + 256 * i, cq = u % QK, pq = u / QK;
-      const long pf = p0 + 4 * pq + (long)dy * W - 1;  // source pixel of slot 0
+      const int pf = p0 + 4 * pq + dy * W - 1;  // source pixel of slot 0
 #pragma unroll
       for (int sl = 0; sl < 6; ++sl) {
-        long q = pf + sl;
-        q = q < 0 ? 0 : (q < P ? q : P - 1);
-        ar[i][sl] = *reinterpret_cast<const f32x4*>(A + q * Cin + k0 + 4 * cq);
+        const int q = min(max(pf + sl, 0), P - 1);
+        ar[i][sl] = *reinterpret_cast<const f32x4*>(A + (long)q * Cin + k0 + 4 * cq);
       }
     }
   };
-  auto stage = [&](long c) {
-    const long p0 = c * WG_PX;
+  auto stage = [&](int c) {
+    const int p0 = c * WG_PX;
 #pragma unroll
     for (int i = 0; i < UN; ++i) {
       const int u = tid + 256 * i, cq = u % QN, pq = u / QN;
-      const long pb = p0 + 4 * pq;
+      const int nv = P - (p0 + 4 * pq);  // pixels of this quad inside the tensor (<= 0: none)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float y[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) y[r] = pb + r < P ? zr[i][r][e] * sd : 0.f;
+        for (int r = 0; r < 4; ++r) y[r] = r < nv ? zr[i][r][e] * sd : 0.f;
         wg_u32x2 hi, lo;
         unsigned h0, l0, h1, l1;
         mm_split2(y[0], y[1], h0, l0);
@@ -347,23 +346,23 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16_kernel(const float* __r
 #pragma unroll
     for (int i = 0; i < UK; ++i) {
       const int u = tid + 256 * i, cq = u % QK, pq = u / QK;
-      const long pb = p0 + 4 * pq;
+      const int pb = p0 + 4 * pq;
       // image coordinates of the unit's four pixels -> per copy (dx = t - 1) a 32-bit keep mask per pixel pair
+      // (unsigned 32-bit divisions, selects instead of branches: a 64-bit modulo and four branches stood here)
       unsigned mk[3][2];
       {
-        const long pc = pb < P ? pb : P - 1;
-        const int rem = (int)(pc % HW);
-        int yy = rem / W, xx = rem - yy * W;
+        const unsigned pc = (unsigned)min(pb, P - 1);
+        const unsigned rem = pc % (unsigned)HW;
+        int yy = (int)(rem / (unsigned)W), xx = (int)(rem - (unsigned)yy * (unsigned)W);
         bool ok[3][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const bool in = pb + r < P && (unsigned)(yy + dy) < (unsigned)H;
 #pragma unroll
           for (int t = 0; t < 3; ++t) ok[t][r] = in && (unsigned)(xx + t - 1) < (unsigned)W;
-          if (++xx == W) {
-            xx = 0;
-            if (++yy == H) yy = 0;
-          }
+          const bool wrap = xx + 1 == W;
+          xx = wrap ? 0 : xx + 1;
+          yy = wrap ? (yy + 1 == H ? 0 : yy + 1) : yy;
         }
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
@@ -390,7 +389,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16_kernel(const float* __r
   };
 
   if (c_lo < c_hi) request(c_lo);
-  for (long c = c_lo; c < c_hi; ++c) {
+  for (int c = c_lo; c < c_hi; ++c) {
     __syncthreads();  // the previous chunk's fragments are read
     stage(c);
     __syncthreads();
@@ -446,6 +445,7 @@ extern "C" int mmmot_conv3x3_wgrad_f16(const float* dZ, const float* A, int L, i
   if (!dZ || !A || !dW || L <= 0 || H <= 0 || W <= 0 || Cin % 64 != 0 || Cout % 64 != 0 || Cin <= 0 || Cout <= 0)
     return MMMOT_EINVAL;
   if (nsplit < 1 || nsplit > 256 || !mm_al16(dZ) || !mm_al16(A)) return MMMOT_EINVAL;
+  if ((long)L * H * W > 0x7fffffffL - 4096) return MMMOT_EINVAL;  // the kernel indexes pixels with 32-bit integers
   hipStream_t s = (hipStream_t)stream;
   const bool n128 = Cout % 128 == 0, k128 = Cin % 128 == 0;
 #define WG_LAUNCH(TNV, TKV)                                                                                              \
